@@ -1,0 +1,312 @@
+// fe.h -- secp256k1 base field Fp, p = 2^256 - 2^32 - 977, for the gfx950 vector ALU.
+//
+// Role of the reference's src/field_5x52_impl.h + field_5x52_int128_impl.h (fe_mul_inner :18-152,
+// fe_sqr_inner :154-272, normalize family field_5x52_impl.h:43-199, codecs :228-304) and of the
+// addition chains in src/field_impl.h:37-146 -- re-designed, not translated:
+//
+//  * Layout: 9 limbs x 29 bits in 9 VGPRs (value = sum n[i] * 2^(29 i)), lazily reduced.  Measured on
+//    MI355X (tools/ubench): v_mad_u64_u32 issues at half rate (4.4 cyc/wave64/SIMD) and the 2-cycle
+//    VALU->carry-in hazard makes saturated carry chains expensive, so the fastest exact product is the
+//    one with the fewest 32x32->64 multiply-accumulates and *no* carry flags: 81 MACs straight into a
+//    64-bit column accumulator (9x29), versus 100 for 10x26 and 124 + 128-bit carry chains for the
+//    reference's 5x52 under the compiler.  fe_mul 9x29 = 1.97e11/s chip-wide vs 1.69e11 (10x26) vs
+//    1.13e11 (5x52/__int128).
+//  * Reduction: 2^261 = 2^5 * 2^256 == 2^37 + 31264 (mod p), i.e. a limb at index 9+k folds to
+//    31264*h at limb k plus h<<8 at limb k+1.  Bits >= 2^256 of the top limb fold with 2^256 == 2^32+977.
+//
+// Magnitude contract (checked in the VERIFY host build, tests/host_emul):
+//    magnitude m  <=>  n[i] <= m*(2^29 + 2^20) for i<8  and  n[8] <= m*(2^24 + 2^10).
+//    fe_mul / fe_sqr inputs need  m_a * m_b <= 7  (9 products of 58+ bits must fit a u64 column);
+//    outputs have magnitude 1.  fe_neg(a, m) has magnitude m+1, fe_add adds magnitudes.
+// Bit-exactness is defined on the canonical 32-byte encodings (fe_get_b32 after fe_normalize), never on limbs.
+#pragma once
+#include "s2k_common.h"
+
+#define FE_LIMBS 9
+#define FE_BITS 29
+#define FE_M 0x1FFFFFFFu
+#define FE_TOPM 0x00FFFFFFu
+
+struct fe { u32 n[FE_LIMBS]; };
+
+// S2K_VERIFY (host test build only): abort when a lazy-limb operation would wrap -- the dynamic counterpart of
+// the reference's VERIFY magnitude tracking (field.h:32-38).
+#ifdef S2K_VERIFY
+#include <stdio.h>
+#include <stdlib.h>
+#define S2K_CHECK(c) do { if (!(c)) { fprintf(stderr, "S2K_VERIFY failed: %s (%s:%d)\n", #c, __FILE__, __LINE__); abort(); } } while (0)
+#else
+#define S2K_CHECK(c) do { } while (0)
+#endif
+
+// p in 9x29
+#define FE_P0 0x1FFFFC2Fu
+#define FE_P1 0x1FFFFFF7u
+
+S2K_HD u32 fe_p_limb(int i) { return i == 0 ? FE_P0 : (i == 1 ? FE_P1 : (i == 8 ? FE_TOPM : FE_M)); }
+
+S2K_HD void fe_set_zero(fe& r) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.n[i] = 0;
+}
+S2K_HD void fe_set_int(fe& r, u32 v) { fe_set_zero(r); r.n[0] = v; }   // v < 2^29
+
+// ---- codecs -------------------------------------------------------------------------------
+// w[0] = least significant 32-bit word of the 256-bit integer.
+S2K_HD void fe_from_words(fe& r, const u32 w[8]) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+        const int bit = FE_BITS * i, idx = bit >> 5, sh = bit & 31;
+        u32 v = w[idx] >> sh;
+        if (sh > 32 - FE_BITS && idx + 1 < 8) v |= w[idx + 1] << (32 - sh);
+        r.n[i] = v & FE_M;
+    }
+}
+// requires a fully normalised input
+S2K_HD void fe_to_words(u32 w[8], const fe& a) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int bit = 32 * j, i = bit / FE_BITS, sh = bit % FE_BITS;   // word j starts inside limb i at bit sh
+        u32 v = a.n[i] >> sh;
+        if (i + 1 < FE_LIMBS) v |= a.n[i + 1] << (FE_BITS - sh);
+        if (FE_BITS - sh + FE_BITS < 32 && i + 2 < FE_LIMBS) v |= a.n[i + 2] << (2 * FE_BITS - sh);
+        w[j] = v;
+    }
+}
+// big-endian 32 bytes -> field element, no reduction (value < 2^256, magnitude 1, maybe >= p).
+// cf. secp256k1_fe_set_b32_mod (field_5x52_impl.h:228-245)
+S2K_HD void fe_set_b32_mod(fe& r, const unsigned char* b) {
+    u32 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = s2k_load_be32(b + 4 * (7 - j));
+    fe_from_words(r, w);
+}
+// returns 0 when the encoded integer is >= p (cf. secp256k1_fe_set_b32_limit :247-250)
+S2K_HD int fe_set_b32_limit(fe& r, const unsigned char* b) {
+    u32 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = s2k_load_be32(b + 4 * (7 - j));
+    fe_from_words(r, w);
+    const u32 hi = w[2] & w[3] & w[4] & w[5] & w[6] & w[7];
+    const int ge_p = (hi == 0xFFFFFFFFu) && (w[1] == 0xFFFFFFFFu || (w[1] == 0xFFFFFFFEu && w[0] >= 0xFFFFFC2Fu));
+    return !ge_p;
+}
+// requires normalised input (cf. secp256k1_fe_get_b32 :253-287)
+S2K_HD void fe_get_b32(unsigned char* b, const fe& a) {
+    u32 w[8];
+    fe_to_words(w, a);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s2k_store_be32(b + 4 * (7 - j), w[j]);
+}
+
+// ---- linear ops (lazy) ----------------------------------------------------------------------
+S2K_HD void fe_add(fe& r, const fe& a) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { S2K_CHECK((u64)r.n[i] + a.n[i] < (1ull << 32)); r.n[i] += a.n[i]; }
+}
+S2K_HD void fe_add2(fe& r, const fe& a, const fe& b) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { S2K_CHECK((u64)a.n[i] + b.n[i] < (1ull << 32)); r.n[i] = a.n[i] + b.n[i]; }
+}
+// r = (m+1)*p - a : magnitude m -> m+1  (cf. secp256k1_fe_negate_unchecked :306-322)
+S2K_HD void fe_neg(fe& r, const fe& a, u32 m) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+        S2K_CHECK((u64)(m + 1) * fe_p_limb(i) < (1ull << 32) && (m + 1) * fe_p_limb(i) >= a.n[i]);
+        r.n[i] = (m + 1) * fe_p_limb(i) - a.n[i];
+    }
+}
+// r *= k (k small; magnitude multiplies)
+S2K_HD void fe_mul_int(fe& r, u32 k) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { S2K_CHECK((u64)r.n[i] * k < (1ull << 32)); r.n[i] *= k; }
+}
+S2K_HD void fe_select(fe& r, const fe& a, const fe& b, int take_a) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.n[i] = take_a ? a.n[i] : b.n[i];
+}
+S2K_HD void fe_cmov(fe& r, const fe& a, int flag) {
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.n[i] = flag ? a.n[i] : r.n[i];
+}
+
+// ---- normalisation ----------------------------------------------------------------------------
+// Parallel (dependency-free) weak normalisation: any magnitude <= 7 -> magnitude 1.  Value unchanged mod p.
+// (role of secp256k1_fe_normalize_weak, field_5x52_impl.h:79-104)
+S2K_HD void fe_norm_weak(fe& r) {
+    u32 c[FE_LIMBS];
+    const u32 t = r.n[8] >> 24;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = r.n[i] >> FE_BITS;
+    r.n[8] = (r.n[8] & FE_TOPM) + c[7];
+#pragma unroll
+    for (int i = 7; i >= 1; i--) r.n[i] = (r.n[i] & FE_M) + c[i - 1];
+    r.n[0] = (r.n[0] & FE_M) + t * 977u;
+    r.n[1] += t << 3;
+}
+// Sequential carry pass: limbs 0..7 become < 2^29 exactly; top limb may keep bit 24.
+S2K_HD void fe_norm_seq(fe& r) {
+    const u32 t = r.n[8] >> 24;
+    r.n[8] &= FE_TOPM;
+    r.n[0] += t * 977u;
+    r.n[1] += t << 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r.n[i + 1] += r.n[i] >> FE_BITS; r.n[i] &= FE_M; }
+}
+// Full normalisation to the canonical representative in [0, p) (cf. secp256k1_fe_normalize :43-77)
+S2K_HD void fe_normalize(fe& r) {
+    fe_norm_seq(r);                 // value < 2^256 + 2^237 < 2p, limbs 0..7 clean
+    fe u = r;                       // u = r + (2^256 - p)
+    u.n[0] += 977u; u.n[1] += 8u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u.n[i + 1] += u.n[i] >> FE_BITS; u.n[i] &= FE_M; }
+    const int ge = (u.n[8] >> 24) != 0;     // r >= p  <=>  r + 2^256 - p >= 2^256
+    u.n[8] &= FE_TOPM;
+    fe_cmov(r, u, ge);
+}
+// after fe_norm_seq: is the value 0 mod p?  (cf. secp256k1_fe_normalizes_to_zero :138-167)
+S2K_HD int fe_seq_is_zero(const fe& a) {
+    u32 z0 = 0, z1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { z0 |= a.n[i]; z1 &= (a.n[i] ^ ~fe_p_limb(i)); }
+    // z1 == all-ones  <=>  every limb equals the corresponding limb of p
+    return (z0 == 0) | (z1 == 0xFFFFFFFFu);
+}
+S2K_HD int fe_normalizes_to_zero(const fe& a) { fe t = a; fe_norm_seq(t); return fe_seq_is_zero(t); }
+// requires normalised input
+S2K_HD int fe_is_odd(const fe& a) { return a.n[0] & 1; }
+S2K_HD int fe_is_zero_normalized(const fe& a) {
+    u32 z = 0;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) z |= a.n[i];
+    return z == 0;
+}
+// equality mod p; magnitudes of a, b <= 1 (cf. secp256k1_fe_equal field_impl.h:25-35)
+S2K_HD int fe_equal(const fe& a, const fe& b) {
+    fe t; fe_neg(t, a, 1); fe_add(t, b);
+    return fe_normalizes_to_zero(t);
+}
+// r = a/2 (cf. secp256k1_fe_half field_5x52_impl.h:358-398).  Magnitude m -> floor(m/2)+1.
+S2K_HD void fe_half(fe& r) {
+    const u32 odd = 0u - (r.n[0] & 1u);
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) r.n[i] += fe_p_limb(i) & odd;   // now even
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.n[i] = (r.n[i] >> 1) + ((r.n[i + 1] & 1u) << (FE_BITS - 1));
+    r.n[8] >>= 1;
+}
+
+// ---- multiplication ----------------------------------------------------------------------------
+// fold an 18-limb (29-bit limbs, t[17] < 2^32) product into 9 limbs of magnitude 1
+S2K_HD void fe_reduce18(fe& r, const u32 t[18]) {
+    u64 d = 0;
+#pragma unroll
+    for (int k = 0; k < FE_LIMBS; k++) {
+        d += t[k];
+        d += (u64)t[k + 9] * 31264u;
+        if (k > 0) d += (u64)t[k + 8] << 8;
+        r.n[k] = (u32)d & FE_M;
+        d >>= FE_BITS;
+    }
+    d += (u64)t[17] << 8;                                   // weight 2^261
+    const u64 hi = (u64)(r.n[8] >> 24) + (d << 5);           // everything >= 2^256, in units of 2^256
+    r.n[8] &= FE_TOPM;
+    u64 e = (u64)r.n[0] + hi * 977u;
+    r.n[0] = (u32)e & FE_M; e >>= FE_BITS;
+    e += (u64)r.n[1] + (hi << 3);
+    r.n[1] = (u32)e & FE_M; e >>= FE_BITS;
+    r.n[2] += (u32)e;
+}
+// r = a*b; needs mag(a)*mag(b) <= 7.  (role of secp256k1_fe_mul_inner, field_5x52_int128_impl.h:18-152)
+S2K_HD void fe_mul(fe& r, const fe& a, const fe& b) {
+    u32 t[18];
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < FE_LIMBS; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= FE_LIMBS) continue;
+            S2K_CHECK(c + (u64)a.n[i] * b.n[j] >= c);
+            c += (u64)a.n[i] * b.n[j];
+        }
+        t[k] = (u32)c & FE_M;
+        c >>= FE_BITS;
+    }
+    t[17] = (u32)c;
+    fe_reduce18(r, t);
+}
+// r = a^2; needs mag(a) <= 2.  (role of secp256k1_fe_sqr_inner :154-272)
+S2K_HD void fe_sqr(fe& r, const fe& a) {
+    u32 t[18], a2[FE_LIMBS];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) a2[i] = a.n[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < FE_LIMBS; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= FE_LIMBS || i > j) continue;
+            S2K_CHECK(a.n[i] < (1u << 31));
+            const u64 pr = (i == j) ? (u64)a.n[i] * a.n[i] : (u64)a2[i] * a.n[j];
+            S2K_CHECK(c + pr >= c);
+            c += pr;
+        }
+        t[k] = (u32)c & FE_M;
+        c >>= FE_BITS;
+    }
+    t[17] = (u32)c;
+    fe_reduce18(r, t);
+}
+
+// ---- exponentiation chains ------------------------------------------------------------------------
+// r = x^(2^n) * y  -- the only place the chains below instantiate fe_sqr/fe_mul, kept out of line so that
+// an inversion costs ~15 calls instead of ~36 KB of inlined code.
+S2K_HD_NOINLINE void fe_sqrn_mul(fe& r, const fe& x, int n, const fe& y) {
+    fe t = x;
+    for (int i = 0; i < n; i++) fe_sqr(t, t);
+    fe_mul(r, t, y);
+}
+S2K_HD_NOINLINE void fe_sqrn(fe& r, const fe& x, int n) {
+    fe t = x;
+    for (int i = 0; i < n; i++) fe_sqr(t, t);
+    r = t;
+}
+// x^(2^223 - 1) and helpers x2 = x^3, x22 = x^(2^22 - 1): the common prefix of a^(p-2) and a^((p+1)/4)
+S2K_HD void fe_pow_x223(fe& x223, fe& x22, fe& x2, const fe& a) {
+    fe x3, x6, x9, x11, x44, x88, x176, x220;
+    fe_sqrn_mul(x2, a, 1, a);
+    fe_sqrn_mul(x3, x2, 1, a);
+    fe_sqrn_mul(x6, x3, 3, x3);
+    fe_sqrn_mul(x9, x6, 3, x3);
+    fe_sqrn_mul(x11, x9, 2, x2);
+    fe_sqrn_mul(x22, x11, 11, x11);
+    fe_sqrn_mul(x44, x22, 22, x22);
+    fe_sqrn_mul(x88, x44, 44, x44);
+    fe_sqrn_mul(x176, x88, 88, x88);
+    fe_sqrn_mul(x220, x176, 44, x44);
+    fe_sqrn_mul(x223, x220, 3, x3);
+}
+// r = a^(p-2) (Fermat).  Same value as secp256k1_fe_inv_var (safegcd, field_5x52_impl.h:481-499); a = 0 -> 0.
+// Input magnitude <= 2.
+S2K_HD void fe_inv(fe& r, const fe& a) {
+    fe x223, x22, x2, t;
+    fe_pow_x223(x223, x22, x2, a);
+    fe_sqrn_mul(t, x223, 23, x22);
+    fe_sqrn_mul(t, t, 5, a);
+    fe_sqrn_mul(t, t, 3, x2);
+    fe_sqrn_mul(r, t, 2, a);
+}
+// r = a^((p+1)/4); returns 1 iff r^2 == a, i.e. a is a square (cf. secp256k1_fe_sqrt, field_impl.h:37-146).
+// Input magnitude <= 1.
+S2K_HD int fe_sqrt(fe& r, const fe& a) {
+    fe x223, x22, x2, t, chk;
+    fe_pow_x223(x223, x22, x2, a);
+    fe_sqrn_mul(t, x223, 23, x22);
+    fe_sqrn_mul(t, t, 6, x2);
+    fe_sqrn(t, t, 2);
+    fe_sqrn(chk, t, 1);
+    r = t;
+    return fe_equal(chk, a);
+}

@@ -1,0 +1,163 @@
+// group.h -- secp256k1 group law, one point per lane, all coordinates in VGPRs (fe.h limbs).
+//
+// Role of the reference's src/group_impl.h: gej_double (:468-501), gej_add_var (:534-596),
+// gej_add_ge_var (:598-659), ge_set_gej_var (:177-196), ge_set_xquad (:347-355), ge_set_xo_var (:357-373),
+// ge_mul_lambda (:925-932).  The formulas are the standard a=0 Jacobian ones; what is different from the
+// reference is everything around them:
+//   * the `_var` early-outs (a = inf, b = inf, same x) become per-lane flags + selects, so a wavefront never
+//     branches on point data; the one case that needs *different arithmetic* (P + P) is reported to the caller
+//     (`GEJ_ADD_NEEDS_DOUBLE`), which re-issues it through its single doubling site (ecmult.h);
+//   * magnitudes follow the 9x29 contract of fe.h (product of input magnitudes <= 7), with weak
+//     normalisations placed where the contract needs them rather than where the 5x52 code has them.
+// Output contract: gej_double -> (x,y,z) magnitudes (5,3,1); gej_add_ge -> (1,3,1); both accept (5,3,1) inputs.
+#pragma once
+#include "fe.h"
+
+struct ge  { fe x, y; };                 // affine, never infinity (callers carry a flag where needed)
+struct gej { fe x, y, z; int inf; };     // Jacobian
+
+#define GEJ_ADD_NEEDS_DOUBLE 1
+
+// beta: cube root of unity in Fp, lambda*(x,y) = (beta*x, y)  (group_impl.h:925-932)
+S2K_HD void fe_set_beta(fe& r) {
+    const u32 b[9] = {0x119501EEu, 0x09CB6143u, 0x1D626570u, 0x0092EA25u, 0x034E99CFu, 0x03CF561Au, 0x1C41B991u, 0x056CAF80u, 0x007AE96Au};
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.n[i] = b[i];
+}
+
+S2K_HD void gej_set_infinity(gej& r) { fe_set_zero(r.x); fe_set_zero(r.y); fe_set_zero(r.z); r.inf = 1; }
+S2K_HD void gej_set_ge(gej& r, const ge& a) { r.x = a.x; r.y = a.y; fe_set_int(r.z, 1); r.inf = 0; }
+S2K_HD void ge_neg(ge& r, const ge& a) { r.x = a.x; fe_neg(r.y, a.y, 1); fe_norm_weak(r.y); }
+
+// r = 2a.  3M + 4S + half (cf. secp256k1_gej_double, group_impl.h:468-501: L = 3/2 X^2, S = Y^2, T = -X S,
+// X3 = L^2 + 2T, Y3 = -(L (X3 + T) + S^2), Z3 = Y Z).  Input magnitudes up to (7,7,7); infinity stays infinity
+// (Z3 = Y*0), the flag is carried through unchanged.
+S2K_HD void gej_double(gej& r, const gej& a) {
+    fe x = a.x, y = a.y, l, s, t;
+    fe_norm_weak(x); fe_norm_weak(y);
+    fe_mul(r.z, y, a.z);                       // Z3 = Y*Z            (1)
+    fe_sqr(s, y);                              // S = Y^2             (1)
+    fe_sqr(l, x);                              // X^2                 (1)
+    fe_mul_int(l, 3); fe_half(l);              // L = 3/2 X^2         (<= 2.5)
+    fe_norm_weak(l);                           //                     (1)
+    fe_mul(t, x, s); fe_neg(t, t, 1);          // T = -X*S            (2)
+    fe_sqr(r.x, l);                            // L^2                 (1)
+    fe_add(r.x, t); fe_add(r.x, t);            // X3 = L^2 + 2T       (5)
+    fe_sqr(s, s);                              // S^2                 (1)
+    fe_add(t, r.x);                            // X3 + T              (7)
+    fe_mul(r.y, t, l);                         // L*(X3+T)            (1)   7*1 <= 7
+    fe_add(r.y, s);                            //                     (2)
+    fe_neg(r.y, r.y, 2);                       // Y3                  (3)
+    r.inf = a.inf;
+}
+
+// r = a + b, b affine and finite.  8M + 3S (cf. secp256k1_gej_add_ge_var, group_impl.h:598-659).
+// Returns GEJ_ADD_NEEDS_DOUBLE when a == b (then r is set to b with Z = 1 and the caller must double it);
+// a == -b gives r.inf = 1; a.inf gives r = b.  Inputs: a magnitudes up to (5,3,1), b up to (1,2).  Output (1,3,1).
+S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b) {
+    fe z12, u2, s2, h, i, h2, h3, t, i2;
+    fe_sqr(z12, a.z);
+    fe_mul(u2, b.x, z12);
+    fe_mul(s2, b.y, z12); fe_mul(s2, s2, a.z);
+    fe_neg(h, a.x, 5); fe_add(h, u2);          // h = u2 - X1         (7)
+    fe_neg(i, a.y, 3); fe_add(i, s2);          // i = s2 - Y1         (5)
+    fe_norm_seq(h); fe_norm_seq(i);            // exact limbs: needed for the zero tests, and magnitude 1 for the products
+    const int hz = fe_seq_is_zero(h), iz = fe_seq_is_zero(i);
+    fe_sqr(i2, i);
+    fe_sqr(h2, h);
+    fe_mul(h3, h, h2);
+    fe_mul(t, a.x, h2);                        // t = X1*h2           (6*1)
+    fe zz; fe_mul(zz, a.z, h);                 // Z3 = Z1*h
+    fe x3, y3, tn;
+    fe_neg(x3, h3, 1);                         // -h3                 (2)
+    fe_neg(tn, t, 1);                          // -t                  (2)
+    fe_add(x3, tn); fe_add(x3, tn); fe_add(x3, i2);   // X3 = i2 - h3 - 2t   (7)
+    fe_norm_weak(x3);                          //                     (1)
+    fe_neg(tn, x3, 1); fe_add(tn, t);          // t - X3              (3)
+    fe_mul(y3, tn, i);                         // i*(t - X3)          (1)
+    fe_mul(h3, h3, a.y);                       // Y1*h3               (5*1)
+    fe_neg(h3, h3, 1);
+    fe_add(y3, h3);                            // Y3                  (3)
+    // case resolution (per lane, no branches)
+    const int dbl = (!a.inf) & hz & iz;
+    const int inf = (!a.inf) & hz & (!iz);
+    const int take_b = a.inf | dbl;
+    fe one; fe_set_int(one, 1);
+    fe_select(r.x, b.x, x3, take_b);
+    fe_select(r.y, b.y, y3, take_b);
+    fe_select(r.z, one, zz, take_b);
+    r.inf = inf;
+    return dbl ? GEJ_ADD_NEEDS_DOUBLE : 0;
+}
+
+// r = a + b, both Jacobian.  12M + 4S (cf. secp256k1_gej_add_var, group_impl.h:534-596).  Complete: handles
+// infinity, a == b (by doubling -- this function is only used in cold prologue/epilogue code) and a == -b.
+// Inputs magnitudes up to (5,3,1).
+S2K_HD_NOINLINE void gej_add_var(gej& r, const gej& a, const gej& b) {
+    fe z22, z12, u1, u2, s1, s2, h, i, h2, h3, t, i2;
+    fe_sqr(z22, b.z); fe_sqr(z12, a.z);
+    fe_mul(u1, a.x, z22); fe_mul(u2, b.x, z12);
+    fe_mul(s1, a.y, z22); fe_mul(s1, s1, b.z);
+    fe_mul(s2, b.y, z12); fe_mul(s2, s2, a.z);
+    fe_neg(h, u1, 1); fe_add(h, u2);
+    fe_neg(i, s1, 1); fe_add(i, s2);
+    fe_norm_seq(h); fe_norm_seq(i);
+    const int hz = fe_seq_is_zero(h), iz = fe_seq_is_zero(i);
+    gej res;
+    if ((!a.inf) & (!b.inf) & hz & iz) {
+        gej_double(res, a);
+    } else {
+        fe_sqr(i2, i); fe_sqr(h2, h); fe_mul(h3, h, h2);
+        fe_mul(t, u1, h2);
+        fe_mul(res.z, a.z, b.z); fe_mul(res.z, res.z, h);
+        fe x3, tn;
+        fe_neg(x3, h3, 1); fe_neg(tn, t, 1);
+        fe_add(x3, tn); fe_add(x3, tn); fe_add(x3, i2);
+        fe_norm_weak(x3);
+        fe_neg(tn, x3, 1); fe_add(tn, t);
+        fe_mul(res.y, tn, i);
+        fe_mul(h3, h3, s1); fe_neg(h3, h3, 1);
+        fe_add(res.y, h3);
+        res.x = x3;
+        res.inf = hz & (!iz);
+        if (a.inf) res = b;
+        else if (b.inf) res = a;
+    }
+    r = res;
+}
+
+// Jacobian -> affine: one inversion + 1S + 3M (cf. secp256k1_ge_set_gej_var :177-196).  Output normalised.
+// Caller must handle a.inf.
+S2K_HD void ge_set_gej(ge& r, const gej& a) {
+    fe zi, zi2, zi3;
+    fe_inv(zi, a.z);
+    fe_sqr(zi2, zi); fe_mul(zi3, zi2, zi);
+    fe_mul(r.x, a.x, zi2); fe_mul(r.y, a.y, zi3);
+    fe_normalize(r.x); fe_normalize(r.y);
+}
+
+// y^2 = x^3 + 7
+S2K_HD void ge_curve_rhs(fe& c, const fe& x) {
+    fe x2; fe_sqr(x2, x); fe_mul(c, x2, x);
+    c.n[0] += 7u;
+}
+// lift x to the point whose y is a quadratic residue (cf. secp256k1_ge_set_xquad :347-355).
+// Returns 1 iff x is on the curve; y = (x^3+7)^((p+1)/4) is produced either way, as in the reference.
+S2K_HD int ge_set_xquad(ge& r, const fe& x) {
+    fe c; ge_curve_rhs(c, x);
+    fe_norm_weak(c);
+    r.x = x;
+    return fe_sqrt(r.y, c);
+}
+// lift x with chosen parity (cf. secp256k1_ge_set_xo_var :357-373)
+S2K_HD int ge_set_xo(ge& r, const fe& x, int odd) {
+    if (!ge_set_xquad(r, x)) return 0;
+    fe_normalize(r.y);
+    if (fe_is_odd(r.y) != odd) { fe_neg(r.y, r.y, 1); fe_normalize(r.y); }
+    return 1;
+}
+// y^2 == x^3 + 7 ?  (cf. secp256k1_ge_is_valid_var)
+S2K_HD int ge_is_valid(const ge& a) {
+    fe y2, c; fe_sqr(y2, a.y); ge_curve_rhs(c, a.x); fe_norm_weak(c);
+    return fe_equal(y2, c);
+}

@@ -1,0 +1,43 @@
+// gtable.h -- device-resident fixed-base table for the generator G.
+//
+// Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
+// src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine
+// that would rather gather 72 bytes than execute 8 doublings: entry (w, b) = b * 256^w * G for every byte value of
+// every one of the 32 byte-windows of a scalar, in the engine's own 9x29 limb format (18 words, affine), so
+// ng*G is 32 mixed additions and zero doublings.  8160 useful entries * 72 B = 574 KiB: resident in every XCD's L2.
+// The table is *computed on the device* when an engine is created (two tiny kernels), never shipped as data.
+#pragma once
+#include "ecmult.h"
+
+S2K_HD void ge_set_generator(ge& g) {
+    const u32 gx[9] = {0x16F81798u, 0x0F940AD8u, 0x138A3656u, 0x17F9B65Bu, 0x10B07029u, 0x114AE743u, 0x0EB15681u, 0x0FDF3B97u, 0x0079BE66u};
+    const u32 gy[9] = {0x1B10D4B8u, 0x023E847Fu, 0x01550667u, 0x0F68914Du, 0x108A8FD1u, 0x1DFE0708u, 0x11957693u, 0x0EE4D478u, 0x00483ADAu};
+#pragma unroll
+    for (int i = 0; i < 9; i++) { g.x.n[i] = gx[i]; g.y.n[i] = gy[i]; }
+}
+
+// step 1 (one thread per window w): base[w] = 256^w * G, affine, stored as entry (w, 1).
+S2K_HD void gtab_build_base(u32* gtab, u32 w) {
+    ge g; ge_set_generator(g);
+    gej j; gej_set_ge(j, g);
+    for (u32 i = 0; i < 8 * w; i++) { gej t; gej_double(t, j); j = t; }
+    ge a; ge_set_gej(a, j);
+    u32* p = gtab + (size_t)(w * 256u + 1u) * S2K_GTAB_ENTRY_WORDS;
+    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+}
+// step 2 (one thread per (w, b), b = 2..255): entry = b * base[w] by left-to-right double-and-add.
+S2K_HD void gtab_build_entry(u32* gtab, u32 w, u32 b) {
+    ge base; gtab_load(base, gtab, w, 1);
+    gej acc; gej_set_infinity(acc);
+    for (int bit = 7; bit >= 0; bit--) {
+        gej t; gej_double(t, acc); acc = t;
+        if ((b >> bit) & 1u) {
+            const int f = gej_add_ge(t, acc, base);
+            acc = t;
+            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+        }
+    }
+    ge a; ge_set_gej(a, acc);
+    u32* p = gtab + (size_t)(w * 256u + b) * S2K_GTAB_ENTRY_WORDS;
+    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+}
