@@ -1,0 +1,123 @@
+/* secp256k1_zkp_amd.h -- C ABI of the MI355X (gfx950) batch-verification engine.
+ *
+ * This is the drop-in boundary for the multi-scalar / double-scalar multiplication hot path of
+ * BlockstreamResearch/secp256k1-zkp.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Conventions (identical to the reference, include/secp256k1.h):
+ *   - return 1 = success / valid, 0 = failure / invalid; verification never "errors" on malformed input.
+ *   - scalars and field elements are 32-byte big-endian; affine points are 64 bytes x||y big-endian
+ *     (the byte layout of `secp256k1_generator`, include/secp256k1_generator.h) with a separate infinity flag.
+ *   - the caller owns every buffer; the engine keeps no pointer past a call.
+ * Engine-level failures (no device, HIP error) make the *call* return 0 and set s2k_last_error(); a batch that
+ * did not complete never reports an item as valid.
+ *
+ * `_dev` variants take pointers to device (HBM) memory of the engine's GPU and a hipStream_t passed as void*
+ * (0 = the engine's own stream); they are asynchronous with respect to the host and are what bench.py times.
+ * All device buffers must be 8-byte aligned.
+ */
+#ifndef SECP256K1_ZKP_AMD_H
+#define SECP256K1_ZKP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2K_API __attribute__((visibility("default")))
+
+typedef struct s2k_engine s2k_engine;
+
+/* Create an engine on HIP device `device` (builds the generator table on the GPU).  NULL on failure. */
+S2K_API s2k_engine* s2k_engine_create(int device);
+S2K_API void s2k_engine_destroy(s2k_engine* e);
+/* Last engine-level error of the calling thread ("" if none). */
+S2K_API const char* s2k_last_error(void);
+/* Make sure the per-batch HBM workspace can hold `n_items` rangeproofs (optional; calls grow it on demand). */
+S2K_API int s2k_engine_reserve(s2k_engine* e, size_t n_items);
+/* Block until everything queued on the engine's stream has finished. */
+S2K_API int s2k_engine_sync(s2k_engine* e);
+/* Device pointer + size (bytes) of the generator table, for tests. */
+S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
+/* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
+ * `which`: 0 = whole call, 1 = dominant kernel only.  Valid after s2k_engine_sync(). */
+S2K_API float s2k_engine_last_ms(s2k_engine* e, int which);
+
+/* ---- batch double multiplication ---------------------------------------------------------------------------
+ * r[i] = na[i]*A[i] + ng[i]*G          replaces: static void secp256k1_ecmult(secp256k1_gej *r,
+ *                                       const secp256k1_gej *a, const secp256k1_scalar *na,
+ *                                       const secp256k1_scalar *ng)            (src/ecmult.h:47)
+ * a_xy: n*64, a_inf: n bytes or NULL (all finite), na: n*32, ng: n*32 or NULL (treated as 0, as the reference's
+ * ng == NULL).  Outputs: r_xy n*64 (zeroed when infinite), r_inf n*int32. */
+S2K_API int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* a_xy,
+                             const unsigned char* a_inf, const unsigned char* na, const unsigned char* ng, size_t n);
+S2K_API int s2k_ecmult_batch_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* a_xy,
+                                 const unsigned char* a_inf, const unsigned char* na, const unsigned char* ng, size_t n);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------------------------------
+ * r = g_sc*G + sum_i sc[i]*pt[i]        replaces: static int secp256k1_ecmult_multi_var(const secp256k1_callback*,
+ *                                       secp256k1_scratch*, secp256k1_gej *r, const secp256k1_scalar *inp_g_sc,
+ *                                       secp256k1_ecmult_multi_callback cb, void *cbdata, size_t n)
+ *                                                                               (src/ecmult.h:62, ecmult_impl.h:823-867)
+ * The callback-pull model becomes arrays: sc n*32, pt_xy n*64, pt_inf n bytes or NULL; g_sc 32 bytes or NULL.
+ * Entries with sc == 0 or an infinite point are skipped (ecmult_impl.h:523).  Output: r_xy 64 bytes, *r_inf. */
+S2K_API int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
+                             const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
+S2K_API int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
+                                 const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
+/* Partial sums for multi-GPU sharding: writes the Jacobian partial result as 3*9 limbs + flag (28 uint32) so that
+ * ranks can all-gather raw limb buffers and finish with s2k_gej_sum (EC addition is not an RCCL op). */
+S2K_API int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
+                                         const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
+S2K_API int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count);
+
+/* ---- BIP-340 batch verification -------------------------------------------------------------------------------
+ * results[i] = secp256k1_schnorrsig_verify(ctx, sig64_i, msg_i, msglen, pubkey_i)
+ *                                       (include/secp256k1_schnorrsig.h, src/modules/schnorrsig/main_impl.h:215-261)
+ * sigs n*64, msgs n*msglen, pubkeys: pk_format 0 = n*32 x-only serialised keys (lifted on the GPU; an invalid key
+ * gives 0, as secp256k1_xonly_pubkey_parse would have failed), 1 = n*64 `secp256k1_xonly_pubkey` opaque objects. */
+S2K_API int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* sigs, const unsigned char* msgs,
+                                              size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n);
+S2K_API int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* sigs,
+                                                  const unsigned char* msgs, size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n);
+
+/* ---- Borromean rangeproof batch verification ---------------------------------------------------------------------
+ * results[i], min_value[i], max_value[i] = secp256k1_rangeproof_verify(ctx, &min, &max, commit_i, proof_i, plen_i,
+ *                                          extra_commit_i, extra_commit_len_i, gen_i)
+ *                                       (include/secp256k1_rangeproof.h:70-80, src/modules/rangeproof/main_impl.h:54-71,
+ *                                        rangeproof_impl.h:541-683, borromean_impl.h:53-104)
+ * Packed form: proofs = all proofs back to back, proof_off[n+1] byte offsets (proof i = [off[i], off[i+1]));
+ * commits n*33 = serialised Pedersen commitments (equivalently the first 33 bytes of each 64-byte
+ * secp256k1_pedersen_commitment object); gens n*64 = secp256k1_generator objects; extra / extra_off likewise or NULL.
+ * min_value / max_value are written exactly when the reference writes them (header parsed), starting from 0. */
+S2K_API int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                              const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                              const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+S2K_API int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                  const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+/* Single-item form with the reference's argument list (ctx is accepted and ignored: the engine is process-global,
+ * lazily created on device $S2K_DEVICE or 0).  commit / gen point at the reference's 64-byte opaque objects. */
+S2K_API int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value, uint64_t* max_value, const void* commit,
+                                            const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
+                                            size_t extra_commit_len, const void* gen);
+
+/* ---- Bulletproofs++ norm-argument batch verification ---------------------------------------------------------------
+ * results[i] = secp256k1_bppp_rangeproof_norm_product_verify(ctx, scratch, proof_i, proof_len, &transcript_i, &rho_i,
+ *                                       g_vec, g_len, c_vec_i, c_vec_len, &commit_i)
+ *                                       (src/modules/bppp/bppp_norm_product_impl.h:425-552)
+ * All items share the generator set (gens33: n_gens compressed points, G_i first then H_i, as
+ * secp256k1_bppp_generators_serialize writes them), g_len, c_vec_len and proof_len.  transcripts: n * 104 bytes, each the
+ * SHA-256 state {uint32 s[8]; uint8 buf[64]; uint64 bytes} of the parent protocol (src/hash.h); rho n*32; c_vec
+ * n*c_vec_len*32; commits n*33 (33 zero bytes = infinity, secp256k1.c:895). */
+S2K_API int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
+                                                     const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
+                                                     size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
+                                                     const unsigned char* commits33, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+"""ctypes binding of the C ABI declared in include/secp256k1_zkp_amd.h.
+
+The shared library is built in-tree (``secp256k1_zkp_amd/libsecp256k1_zkp_amd.so``, see ``__graft_entry__.build``)
+and loaded from there; there is no Python or CPU implementation behind it -- if the library or a HIP device is
+missing the import / engine creation raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsecp256k1_zkp_amd.so")
+
+_c = ctypes
+_vp, _sz, _i32p = _c.c_void_p, _c.c_size_t, _c.c_void_p
+
+# name -> (restype, argtypes); must list every S2K_API symbol of include/secp256k1_zkp_amd.h
+SIGNATURES = {
+    "s2k_engine_create": (_vp, [_c.c_int]),
+    "s2k_engine_destroy": (None, [_vp]),
+    "s2k_last_error": (_c.c_char_p, []),
+    "s2k_engine_reserve": (_c.c_int, [_vp, _sz]),
+    "s2k_engine_sync": (_c.c_int, [_vp]),
+    "s2k_engine_gtable": (_vp, [_vp, _c.POINTER(_sz)]),
+    "s2k_engine_last_ms": (_c.c_float, [_vp, _c.c_int]),
+    "s2k_ecmult_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
+    "s2k_ecmult_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
+    "s2k_ecmult_multi": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
+    "s2k_ecmult_multi_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
+    "s2k_ecmult_multi_partial_dev": (_c.c_int, [_vp, _vp] + [_vp] * 5 + [_sz]),
+    "s2k_gej_sum_dev": (_c.c_int, [_vp, _vp] + [_vp] * 3 + [_sz]),
+    "secp256k1_schnorrsig_verify_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
+    "secp256k1_schnorrsig_verify_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
+    "secp256k1_rangeproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "secp256k1_bppp_norm_product_verify_batch": (_c.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the native library (once) and attach prototypes. Raises OSError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().s2k_last_error().decode()

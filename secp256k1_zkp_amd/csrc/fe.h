@@ -198,8 +198,11 @@ S2K_HD void fe_half(fe& r) {
 
 // ---- multiplication ----------------------------------------------------------------------------
 // fold an 18-limb (29-bit limbs, t[17] < 2^32) product into 9 limbs of magnitude 1
-S2K_HD void fe_reduce18(fe& r, const u32 t[18]) {
+S2K_HD void fe_reduce18(fe& r, const u32 t_in[18]) {
     u64 d = 0;
+    u32 t[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) { t[i] = t_in[i]; S2K_OPAQUE(t[i]); }
 #pragma unroll
     for (int k = 0; k < FE_LIMBS; k++) {
         d += t[k];
@@ -211,16 +214,21 @@ S2K_HD void fe_reduce18(fe& r, const u32 t[18]) {
     d += (u64)t[17] << 8;                                   // weight 2^261
     const u64 hi = (u64)(r.n[8] >> 24) + (d << 5);           // everything >= 2^256, in units of 2^256
     r.n[8] &= FE_TOPM;
-    u64 e = (u64)r.n[0] + hi * 977u;
+    u32 hi_lo = (u32)hi, hi_hi = (u32)(hi >> 32);            // hi < 2^46
+    S2K_OPAQUE(hi_lo); S2K_OPAQUE(hi_hi);
+    u64 e = (u64)r.n[0] + (u64)hi_lo * 977u + ((u64)(hi_hi * 977u) << 32);
     r.n[0] = (u32)e & FE_M; e >>= FE_BITS;
     e += (u64)r.n[1] + (hi << 3);
     r.n[1] = (u32)e & FE_M; e >>= FE_BITS;
     r.n[2] += (u32)e;
 }
 // r = a*b; needs mag(a)*mag(b) <= 7.  (role of secp256k1_fe_mul_inner, field_5x52_int128_impl.h:18-152)
-S2K_HD void fe_mul(fe& r, const fe& a, const fe& b) {
+S2K_HD void fe_mul(fe& r, const fe& a_in, const fe& b_in) {
     u32 t[18];
     u64 c = 0;
+    fe a = a_in, b = b_in;
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { S2K_OPAQUE(a.n[i]); S2K_OPAQUE(b.n[i]); }
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #pragma unroll
@@ -237,11 +245,14 @@ S2K_HD void fe_mul(fe& r, const fe& a, const fe& b) {
     fe_reduce18(r, t);
 }
 // r = a^2; needs mag(a) <= 2.  (role of secp256k1_fe_sqr_inner :154-272)
-S2K_HD void fe_sqr(fe& r, const fe& a) {
+S2K_HD void fe_sqr(fe& r, const fe& a_in) {
     u32 t[18], a2[FE_LIMBS];
     u64 c = 0;
+    fe a = a_in;
 #pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) a2[i] = a.n[i] << 1;
+    for (int i = 0; i < FE_LIMBS; i++) S2K_OPAQUE(a.n[i]);
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { a2[i] = a.n[i] << 1; S2K_OPAQUE(a2[i]); }
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #pragma unroll

@@ -20,6 +20,17 @@
 #define S2K_D static inline
 #endif
 
+// S2K_OPAQUE(x): make the value of a 32-bit register opaque to the optimiser (no instruction is emitted).
+// Needed around every 32x32->64 product: ROCm 7.2's AMDGPU backend, when it can prove both operands of a 64-bit
+// product fit in 24 bits (e.g. the top limb after `& 0xFFFFFF`), first narrows the product to mul24 -- which lets
+// it DROP the mask as "bits not demanded" -- and then re-widens it to a full v_mad_u64_u32 on the unmasked
+// register.  Found on MI355X as wrong top/bottom limbs in chained fe_sqr; see tests/test_gpu_prims.py::test_chained.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define S2K_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define S2K_OPAQUE(x) ((void)0)
+#endif
+
 typedef uint32_t u32;
 typedef uint64_t u64;
 

@@ -110,8 +110,11 @@ S2K_HD int sc_is_high(const scalar& a) {
 }
 
 // 8x8 -> 16 limb schoolbook product
-S2K_HD void sc_mul_wide(u32 l[16], const u32 a[8], const u32 b[8]) {
+S2K_HD void sc_mul_wide(u32 l[16], const u32 a_in[8], const u32 b_in[8]) {
     u64 acc = 0; u32 ex = 0;
+    u32 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = a_in[i]; b[i] = b_in[i]; S2K_OPAQUE(a[i]); S2K_OPAQUE(b[i]); }
 #pragma unroll
     for (int k = 0; k < 15; k++) {
 #pragma unroll
@@ -141,7 +144,8 @@ S2K_HD void sc_reduce_512(scalar& r, const u32 l[16]) {
             for (int i = 0; i < 5; i++) {
                 const int j = k - i;
                 if (j < 0 || j > 7) continue;
-                const u64 p = (u64)sc_nc_limb(i) * l[8 + j];
+                u32 lv = l[8 + j]; S2K_OPAQUE(lv);
+                const u64 p = (u64)sc_nc_limb(i) * lv;
                 acc += p; ex += (acc < p);
             }
             m[k] = (u32)acc; acc = (acc >> 32) | ((u64)ex << 32); ex = 0;
@@ -158,7 +162,8 @@ S2K_HD void sc_reduce_512(scalar& r, const u32 l[16]) {
             for (int i = 0; i < 5; i++) {
                 const int j = k - i;
                 if (j < 0 || j > 4) continue;
-                const u64 p = (u64)sc_nc_limb(i) * m[8 + j];
+                u32 mv = m[8 + j]; S2K_OPAQUE(mv);
+                const u64 p = (u64)sc_nc_limb(i) * mv;
                 acc += p; ex += (acc < p);
             }
             q[k] = (u32)acc; acc = (acc >> 32) | ((u64)ex << 32); ex = 0;
@@ -168,7 +173,8 @@ S2K_HD void sc_reduce_512(scalar& r, const u32 l[16]) {
     u64 t = 0; u32 top;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        t += (u64)q[i] + (u64)sc_nc_limb(i) * q[8];
+        u32 q8 = q[8]; S2K_OPAQUE(q8);
+        t += (u64)q[i] + (u64)sc_nc_limb(i) * q8;
         r.d[i] = (u32)t; t >>= 32;
     }
     top = (u32)t;    // 0 or 1

@@ -1,0 +1,61 @@
+// tests/gpu_prims/prims.hip -- TEST-ONLY kernels that run the per-lane device primitives (fe/scalar/group/sha256)
+// one call per lane so the GPU test-suite can compare each of them with the reference at byte level
+// (role of the reference's per-primitive unit tests, src/tests.c:3375-4213).  Not part of the product library.
+#include "../../secp256k1_zkp_amd/csrc/gtable.h"
+#include "../../secp256k1_zkp_amd/csrc/sha256.h"
+#include <hip/hip_runtime.h>
+
+__global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned char* a, const unsigned char* b, const unsigned char* c, const u32* gtab, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x, y, z;
+    switch (op) {
+    case 0: fe_set_b32_mod(x, a + 32 * i); fe_set_b32_mod(y, b + 32 * i); fe_mul(z, x, y); fe_normalize(z); fe_get_b32(out + 32 * i, z); break;
+    case 1: fe_set_b32_mod(x, a + 32 * i); fe_sqr(z, x); fe_normalize(z); fe_get_b32(out + 32 * i, z); break;
+    case 2: fe_set_b32_mod(x, a + 32 * i); fe_inv(z, x); fe_normalize(z); fe_get_b32(out + 32 * i, z); break;
+    case 3: fe_set_b32_mod(x, a + 32 * i); flag[i] = fe_sqrt(z, x); fe_normalize(z); fe_get_b32(out + 32 * i, z); break;
+    case 4: fe_set_b32_mod(x, a + 32 * i); fe_half(x); fe_normalize(x); fe_get_b32(out + 32 * i, x); break;
+    case 5: {
+        ge p, q; gej j, t; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_set_b32_mod(q.x, b + 64 * i); fe_set_b32_mod(q.y, b + 64 * i + 32);
+        gej_set_ge(j, p); int f = gej_add_ge(t, j, q); if (f == GEJ_ADD_NEEDS_DOUBLE) { gej u; gej_double(u, t); t = u; }
+        flag[i] = t.inf; ge r; ge_set_gej(r, t); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
+    } break;
+    case 6: {
+        ge p; gej j, t; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32);
+        gej_set_ge(j, p); gej_double(t, j); flag[i] = t.inf; ge r; ge_set_gej(r, t); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
+    } break;
+    case 7: {   // Jacobian + Jacobian with random Z's (c holds two 32-byte z values per item)
+        ge p, q; gej ja, jb, r; fe za, zb, z2, z3;
+        fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_set_b32_mod(q.x, b + 64 * i); fe_set_b32_mod(q.y, b + 64 * i + 32);
+        fe_set_b32_mod(za, c + 64 * i); fe_set_b32_mod(zb, c + 64 * i + 32);
+        gej_set_ge(ja, p); gej_set_ge(jb, q);
+        fe_sqr(z2, za); fe_mul(z3, z2, za); fe_mul(ja.x, ja.x, z2); fe_mul(ja.y, ja.y, z3); ja.z = za;
+        fe_sqr(z2, zb); fe_mul(z3, z2, zb); fe_mul(jb.x, jb.x, z2); fe_mul(jb.y, jb.y, z3); jb.z = zb;
+        gej_add_var(r, ja, jb); flag[i] = r.inf; ge o; ge_set_gej(o, r); fe_get_b32(out + 64 * i, o.x); fe_get_b32(out + 64 * i + 32, o.y);
+    } break;
+    case 8: { scalar s, t; sc_set_b32(s, a + 32 * i, nullptr); sc_set_b32(t, b + 32 * i, nullptr); sc_mul(s, s, t); sc_get_b32(out + 32 * i, s); } break;
+    case 9: { scalar s, r1, r2; sc_set_b32(s, a + 32 * i, nullptr); sc_split_lambda(r1, r2, s); sc_get_b32(out + 64 * i, r1); sc_get_b32(out + 64 * i + 32, r2); } break;
+    case 10: { sha256_stream h; sha256_stream_init(h); sha256_stream_write(h, a + 100 * i, 100); sha256_stream_finalize(h, out + 32 * i); } break;
+    case 11: { ge g; gtab_load(g, gtab, (u32)i >> 8, (u32)i & 255u); fe_normalize(g.x); fe_normalize(g.y); fe_get_b32(out + 64 * i, g.x); fe_get_b32(out + 64 * i + 32, g.y); } break;
+    case 20: {   // intermediates of gej_double for debugging: Z3, S, L, T, X3, S2, (X3+T), Y3pre
+        ge p; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32);
+        fe X = p.x, Y = p.y, l, s, t, rx, ry, rz, one; fe_set_int(one, 1);
+        unsigned char* o = out + 256 * i;
+        fe_mul(rz, Y, one); { fe q = rz; fe_normalize(q); fe_get_b32(o, q); }
+        fe_sqr(s, Y); { fe q = s; fe_normalize(q); fe_get_b32(o + 32, q); }
+        fe_sqr(l, X); fe_mul_int(l, 3); fe_half(l); fe_norm_weak(l); { fe q = l; fe_normalize(q); fe_get_b32(o + 64, q); }
+        fe_mul(t, X, s); fe_neg(t, t, 1); { fe q = t; fe_normalize(q); fe_get_b32(o + 96, q); }
+        fe_sqr(rx, l); fe_add(rx, t); fe_add(rx, t); { fe q = rx; fe_normalize(q); fe_get_b32(o + 128, q); }
+        fe_sqr(s, s); { fe q = s; fe_normalize(q); fe_get_b32(o + 160, q); }
+        fe_add(t, rx); { fe q = t; fe_normalize(q); fe_get_b32(o + 192, q); }
+        fe_mul(ry, t, l); { fe q = ry; fe_normalize(q); fe_get_b32(o + 224, q); }
+    } break;
+    case 12: { scalar s; int o; sc_set_b32(s, a + 32 * i, &o); flag[i] = o; sc_negate(s, s); sc_get_b32(out + 32 * i, s); } break;
+    case 13: { scalar s; sc_set_b32(s, a + 32 * i, nullptr); sc_inverse(s, s); sc_get_b32(out + 32 * i, s); } break;
+    }
+}
+extern "C" __attribute__((visibility("default")))
+int s2k_test_prim(int op, unsigned char* out, int* flag, const unsigned char* a, const unsigned char* b, const unsigned char* c, const void* gtab, int n) {
+    hipLaunchKernelGGL(k_prim, dim3((n + 63) / 64), dim3(64), 0, 0, op, out, flag, a, b, c, (const u32*)gtab, n);
+    return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+}

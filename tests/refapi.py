@@ -1,0 +1,107 @@
+"""ctypes view of oracle/_ref/libsecp256k1_ref.so (the unmodified reference + oracle/ref_shim.c). Test-only."""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libsecp256k1_ref.so")
+
+P = 2**256 - 2**32 - 977
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+G_XY = bytes.fromhex("79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798"
+                     "483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8")
+GENERATOR_H = bytes.fromhex("50929b74c1a04954b78b4b6035e97a5e078a5a0f28ec96d547bfee9ace803ac0"
+                            "31d3c6863973926e049e637cb1b5f40a36dac28af1766968c30c2313f3a38904")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Ref:
+    def __init__(self):
+        self.lib = ctypes.CDLL(REF_PATH)
+        L = self.lib
+        L.ref_ecmult_multi.restype = ctypes.c_int
+        L.ref_sha256_state_size.restype = ctypes.c_size_t
+
+    # --- points / scalars helpers
+    def call(self, name, nout, *args):
+        outs = [ctypes.create_string_buffer(n) for n in nout]
+        r = getattr(self.lib, name)(*outs, *args)
+        return r, [o.raw for o in outs]
+
+    def rand_point(self, rng):
+        while True:
+            x = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+            r, o = self.call("ref_ge_set_xquad", [64], x)
+            if r:
+                pt = o[0]
+                if rng.integers(0, 2):
+                    pt = pt[:32] + ((P - int.from_bytes(pt[32:], "big")) % P).to_bytes(32, "big")
+                return pt
+
+    def ecmult_batch(self, a_xy, na, ng=None, a_inf=None):
+        a_xy = np.ascontiguousarray(a_xy, np.uint8); n = a_xy.size // 64
+        na = np.ascontiguousarray(na, np.uint8)
+        ng = None if ng is None else np.ascontiguousarray(ng, np.uint8)
+        a_inf = None if a_inf is None else np.ascontiguousarray(a_inf, np.uint8)
+        r = np.zeros((n, 64), np.uint8); inf = np.zeros(n, np.int32)
+        self.lib.ref_ecmult_batch(_p(r), _p(inf), _p(a_xy), _p(a_inf), _p(na), _p(ng), ctypes.c_size_t(n))
+        return r, inf
+
+    def ecmult_multi(self, sc, pt_xy, g_sc=None, pt_inf=None, algo=0):
+        sc = np.ascontiguousarray(sc, np.uint8); pt_xy = np.ascontiguousarray(pt_xy, np.uint8); n = sc.size // 32
+        g = None if g_sc is None else np.ascontiguousarray(g_sc, np.uint8)
+        pi = None if pt_inf is None else np.ascontiguousarray(pt_inf, np.uint8)
+        r = np.zeros(64, np.uint8)
+        inf = self.lib.ref_ecmult_multi(_p(r), _p(g), _p(sc), _p(pt_xy), _p(pi), ctypes.c_size_t(n), ctypes.c_int(algo))
+        return r, inf
+
+    # --- rangeproofs
+    def make_rangeproofs(self, n, rng, min_bits=64, exp=0, min_value=0, gens64=None, values=None, threads=8):
+        blinds = rng.integers(0, 256, (n, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F
+        if values is None:
+            hi = 2**63 if min_bits >= 64 else 2**max(min_bits, 1)
+            values = rng.integers(0, hi, n, dtype=np.uint64)
+        values = np.ascontiguousarray(values, np.uint64)
+        if gens64 is None:
+            gens64 = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64).copy()
+        stride = 5134
+        commits = np.zeros((n, 33), np.uint8); proofs = np.zeros((n, stride), np.uint8); plens = np.zeros(n, np.uint64)
+        ok = self.lib.ref_rangeproof_make_many(_p(commits), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(blinds), _p(values), _p(gens64),
+                                               ctypes.c_uint64(min_value), ctypes.c_int(exp), ctypes.c_int(min_bits), ctypes.c_size_t(n),
+                                               ctypes.c_int(threads))
+        assert ok == 1
+        plist = [proofs[i, :int(plens[i])].tobytes() for i in range(n)]
+        return commits, plist, gens64, values
+
+    def rangeproof_verify_many(self, commits33, plist, gens64, threads=1):
+        n = len(plist)
+        stride = max(max((len(p) for p in plist), default=1), 1)
+        proofs = np.zeros((n, stride), np.uint8)
+        for i, p in enumerate(plist):
+            proofs[i, :len(p)] = np.frombuffer(p, np.uint8)
+        plens = np.array([len(p) for p in plist], np.uint64)
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        commits33 = np.ascontiguousarray(commits33, np.uint8); gens64 = np.ascontiguousarray(gens64, np.uint8)
+        self.lib.ref_rangeproof_verify_many(_p(res), _p(mn), _p(mx), _p(commits33), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(gens64),
+                                            ctypes.c_size_t(n), ctypes.c_int(threads))
+        return res, mn, mx
+
+    # --- schnorr
+    def make_schnorr(self, n, rng, threads=8):
+        sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); sk[:, 0] &= 0x7F; sk[:, 31] |= 1
+        msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        sigs = np.zeros((n, 64), np.uint8); pks = np.zeros((n, 32), np.uint8)
+        ok = self.lib.ref_schnorrsig_make_many(_p(sigs), _p(pks), _p(sk), _p(msgs), ctypes.c_size_t(n), ctypes.c_int(threads))
+        assert ok == 1
+        return sigs, msgs, pks
+
+    def schnorr_verify_many(self, sigs, msgs, pks, msglen=32, threads=1):
+        n = sigs.size // 64
+        res = np.zeros(n, np.int32)
+        self.lib.ref_schnorrsig_verify_many(_p(res), _p(np.ascontiguousarray(sigs)), _p(np.ascontiguousarray(msgs)), ctypes.c_size_t(msglen),
+                                            _p(np.ascontiguousarray(pks)), ctypes.c_size_t(n), ctypes.c_int(threads))
+        return res

@@ -1,0 +1,160 @@
+"""GPU parity of the per-lane device primitives (fe / scalar / group / sha256 / generator table) against the reference,
+byte-exact.  Mirrors the reference's primitive unit tests (src/tests.c:3375-3437 fe_mul/sqr vs independent mulmod,
+:3468-3582 sqrt, :3584 inverse, :3926-4213 test_ge, :6018-6060 endomorphism split)."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests.refapi import G_XY, N, P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def prims(engine):
+    import torch
+    lib = ctypes.CDLL(os.path.join(HERE, "gpu_prims", "libs2k_gpuprims.so"))
+    gsz = ctypes.c_size_t(0)
+    gtab = engine._lib.s2k_engine_gtable(engine._h, ctypes.byref(gsz))
+
+    def run(op, n, out_bytes, a=None, b=None, c=None):
+        dev = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x, np.uint8).reshape(-1)).cuda()
+        ta, tb, tc = dev(a), dev(b), dev(c)
+        out = torch.zeros(n * out_bytes, dtype=torch.uint8, device="cuda"); flag = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        torch.cuda.synchronize()
+        ok = lib.s2k_test_prim(op, ptr(out), ptr(flag), ptr(ta), ptr(tb), ptr(tc), ctypes.c_void_p(gtab), n)
+        assert ok == 1
+        return out.cpu().numpy().reshape(n, out_bytes), flag.cpu().numpy()
+    return run
+
+
+def _b(v):
+    return int(v).to_bytes(32, "big")
+
+
+def _fe_inputs(rng, n):
+    edge = [0, 1, 2, P - 1, P - 2, P, P + 1, 2**256 - 1, 2**255, 977, 2**32 + 977, N, (P + 1) // 2, 2**256 - 2**32, 2**232, 2**232 - 1]
+    rows = [np.frombuffer(_b(e % 2**256), np.uint8) for e in edge]
+    arr = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        arr[i] = r
+    return arr
+
+
+def _ref_rows(ref, name, nout, *cols):
+    n = cols[0].shape[0]
+    out = np.zeros((n, nout), np.uint8); flags = np.zeros(n, np.int64)
+    for i in range(n):
+        r, o = ref.call(name, [nout], *[c[i].tobytes() for c in cols])
+        out[i] = np.frombuffer(o[0], np.uint8); flags[i] = r if r is not None else 0
+    return out, flags
+
+
+def test_field_ops(prims, ref):
+    rng = np.random.default_rng(11)
+    n = 512
+    a = _fe_inputs(rng, n); b = np.roll(_fe_inputs(rng, n), 5, axis=0)
+    for op, name, cols in ((0, "ref_fe_mul", (a, b)), (1, "ref_fe_sqr", (a,)), (2, "ref_fe_inv", (a,))):
+        got, _ = prims(op, n, 32, *cols)
+        exp, _ = _ref_rows(ref, name, 32, *cols)
+        assert np.array_equal(got, exp), name
+    got, fl = prims(3, n, 32, a)
+    exp, efl = _ref_rows(ref, "ref_fe_sqrt", 32, a)
+    assert np.array_equal(got, exp) and np.array_equal(fl, efl)
+    # half: 2*half(a) == a
+    got, _ = prims(4, n, 32, a)
+    for i in range(n):
+        assert (2 * int.from_bytes(got[i].tobytes(), "big")) % P == int.from_bytes(a[i].tobytes(), "big") % P
+
+
+def test_scalar_ops(prims, ref):
+    rng = np.random.default_rng(12)
+    n = 256
+    a = _fe_inputs(rng, n); b = np.roll(_fe_inputs(rng, n), 3, axis=0)
+    got, _ = prims(8, n, 32, a, b); exp, _ = _ref_rows(ref, "ref_scalar_mul", 32, a, b)
+    assert np.array_equal(got, exp)
+    got, _ = prims(9, n, 64, a)
+    for i in range(n):
+        r, o = ref.call("ref_scalar_split_lambda", [32, 32], a[i].tobytes())
+        assert got[i].tobytes() == o[0] + o[1]
+    got, fl = prims(12, n, 32, a)
+    for i in range(n):
+        v = int.from_bytes(a[i].tobytes(), "big")
+        assert fl[i] == (1 if v >= N else 0)
+        assert int.from_bytes(got[i].tobytes(), "big") == (-v) % N
+    got, _ = prims(13, 64, 32, a[:64]); exp, _ = _ref_rows(ref, "ref_scalar_inverse", 32, a[:64])
+    assert np.array_equal(got, exp)
+
+
+def test_group_ops(prims, ref):
+    rng = np.random.default_rng(13)
+    pts = [ref.rand_point(rng) for _ in range(30)] + [G_XY]
+    neg = lambda p: p[:32] + _b((P - int.from_bytes(p[32:], "big")) % P)
+    A, B = [], []
+    for i, p in enumerate(pts):
+        for q in (pts[(i + 1) % len(pts)], p, neg(p)):
+            A.append(p); B.append(q)
+    n = len(A)
+    a = np.frombuffer(b"".join(A), np.uint8).reshape(n, 64); b = np.frombuffer(b"".join(B), np.uint8).reshape(n, 64)
+    exp = np.zeros((n, 64), np.uint8); einf = np.zeros(n, np.int32)
+    for i in range(n):
+        r, o = ref.call("ref_ge_add", [64], A[i], 0, B[i], 0)
+        exp[i] = np.frombuffer(o[0], np.uint8); einf[i] = r
+    got, inf = prims(5, n, 64, a, b)
+    got[inf != 0] = 0
+    assert np.array_equal(inf, einf) and np.array_equal(got, exp)
+    z = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    got, inf = prims(7, n, 64, a, b, z)
+    got[inf != 0] = 0
+    assert np.array_equal(inf, einf) and np.array_equal(got, exp)
+    got, inf = prims(6, n, 64, a)
+    for i in range(n):
+        r, o = ref.call("ref_ge_double", [64], A[i], 0)
+        assert got[i].tobytes() == o[0] and inf[i] == r
+
+
+def test_sha256(prims):
+    rng = np.random.default_rng(14)
+    n = 64
+    m = rng.integers(0, 256, (n, 100), dtype=np.uint8)
+    got, _ = prims(10, n, 32, m)
+    for i in range(n):
+        assert got[i].tobytes() == hashlib.sha256(m[i].tobytes()).digest()
+
+
+def test_generator_table(prims, ref):
+    """every entry (w,b) of the device-built table equals b*256^w*G computed by the reference's ecmult
+    (role of test_pre_g_table, src/tests.c:4543-4615)."""
+    n = 32 * 256
+    got, _ = prims(11, n, 64)
+    idx = [(w, b) for w in range(32) for b in range(256) if b >= 1]
+    ng = np.stack([np.frombuffer(_b(b << (8 * w)), np.uint8) for (w, b) in idx])
+    zeros = np.zeros((len(idx), 32), np.uint8)
+    g = np.frombuffer(G_XY * len(idx), np.uint8).reshape(-1, 64)
+    exp, inf = ref.ecmult_batch(g, zeros, ng)
+    assert not inf.any()
+    sel = np.array([w * 256 + b for (w, b) in idx])
+    assert np.array_equal(got[sel], exp)
+
+
+def test_chained(prims, ref):
+    """Chained inline field ops (the intermediates of one Jacobian doubling) against big-integer arithmetic.
+    Regression test for the ROCm 7.2 mul24 mis-widening described at S2K_OPAQUE (csrc/s2k_common.h): single
+    fe_mul/fe_sqr calls were right, a product whose operand was the *output* of a previous product was not."""
+    rng = np.random.default_rng(15)
+    pts = [ref.rand_point(rng) for _ in range(64)] + [G_XY]
+    n = len(pts)
+    a = np.frombuffer(b"".join(pts), np.uint8).reshape(n, 64)
+    got, _ = prims(20, n, 256, a)
+    inv2 = pow(2, -1, P)
+    for i in range(n):
+        x = int.from_bytes(pts[i][:32], "big"); y = int.from_bytes(pts[i][32:], "big")
+        S = y * y % P; L = 3 * x * x * inv2 % P; T = (-x * S) % P; X3 = (L * L + 2 * T) % P; S2 = S * S % P; XT = (X3 + T) % P
+        exp = [y, S, L, T, X3, S2, XT, XT * L % P]
+        for k, v in enumerate(exp):
+            assert int.from_bytes(got[i, 32 * k:32 * k + 32].tobytes(), "big") == v, (i, k)
