@@ -6,6 +6,7 @@
 // There is no CPU implementation behind these entry points: without a HIP device every call fails loudly.
 #include "gtable.h"
 #include "sha256.h"
+#include "rangeproof.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -217,6 +218,144 @@ extern "C" int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
     return 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Borromean rangeproof batch verification (rangeproof.h): five kernels on one stream
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_rp_prologue(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* commits33, const unsigned char* proofs,
+              const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t o0 = proof_off[p], o1 = proof_off[p + 1];
+    const unsigned char* ex = nullptr; uint64_t exlen = 0;
+    if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
+    uint64_t mn, mx;
+    rp_prologue(ws.rec[p], ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, &mn, &mx, commits33 + 33 * p, proofs + o0, o1 - o0, ex, exlen, gens64 + 64 * p);
+    min_value[p] = mn; max_value[p] = mx;
+}
+__global__ void __launch_bounds__(256)
+k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t p = t >> 5; const u32 ring = (u32)(t & 31);
+    if (p >= n) return;
+    const rp_rec& rec = ws.rec[p];
+    if (!rec.ok || ring + 1 >= rec.rings) return;
+    rp_lift(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring);
+}
+__global__ void __launch_bounds__(64)
+k_rp_sum(rp_ws ws, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    rp_sum(ws.rec[p], ws.pub0 + p * RP_MAX_RINGS * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS);
+}
+__global__ void __launch_bounds__(256, 2)
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t p = t >> 5; const u32 ring = (u32)(t & 31);
+    int live = p < n;
+    if (!live) p = 0;
+    const rp_rec& rec = ws.rec[p];
+    live &= (ring < rec.rings);
+    rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
+            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab);
+}
+__global__ void __launch_bounds__(64)
+k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    results[p] = rp_final(ws.rec[p], ws.ring_out + p * RP_MAX_RINGS * 36, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
+}
+
+static size_t rp_ws_bytes(size_t n) {
+    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_MAX_RINGS * 36, n * RP_MAX_RINGS});
+}
+static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
+    w.rec = c.take<rp_rec>(n);
+    w.bases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
+    w.pub0 = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
+    w.lift_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
+    w.ring_out = c.take<unsigned char>(n * RP_MAX_RINGS * 36);
+    w.ring_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
+}
+// launches the five stages; `w` must already point into device memory
+static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                     const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
+                     const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    const unsigned b64 = (unsigned)((n + 63) / 64), b256 = (unsigned)((n * 32 + 255) / 256);
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
+    hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, n);
+    hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, n);
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, e->gtab, n);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results, proofs, proof_off, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                     const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                     const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_dev", "null engine");
+    if (n == 0) return 1;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    if (!engine_workspace(e, rp_ws_bytes(n))) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, n);
+    return rp_launch(e, stream ? (hipStream_t)stream : e->stream, w, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
+}
+extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                 const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                 const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch", "null engine");
+    if (n == 0) return 1;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
+    const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n});
+    if (!engine_workspace(e, rp_ws_bytes(n) + io)) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, n);
+    int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
+    unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
+    uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
+    unsigned char* d_gen = c.take<unsigned char>(64 * n);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(d_com, commits33, 33 * n, hipMemcpyHostToDevice, st));
+    if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    if (ebytes) { HIPCHK(hipMemcpyAsync(d_ex, extra, ebytes, hipMemcpyHostToDevice, st)); }
+    if (extra && extra_off) HIPCHK(hipMemcpyAsync(d_eoff, extra_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_gen, gens64, 64 * n, hipMemcpyHostToDevice, st));
+    if (!rp_launch(e, st, w, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n)) return 0;
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+// single-item form with the reference's argument list (include/secp256k1_rangeproof.h:70-80)
+static s2k_engine* g_default_engine = nullptr;
+static std::mutex g_default_mu;
+extern "C" int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value, uint64_t* max_value, const void* commit,
+                                               const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
+                                               size_t extra_commit_len, const void* gen) {
+    (void)ctx;
+    if (!min_value || !max_value || !commit || !proof || !gen || (!extra_commit && extra_commit_len)) return s2k_fail("secp256k1_rangeproof_verify_amd", "illegal argument (ARG_CHECK)");
+    {
+        std::lock_guard<std::mutex> lock(g_default_mu);
+        if (!g_default_engine) {
+            const char* d = getenv("S2K_DEVICE");
+            g_default_engine = s2k_engine_create(d ? atoi(d) : 0);
+            if (!g_default_engine) return 0;
+        }
+    }
+    int32_t res = 0; uint64_t off[2] = {0, plen}, eoff[2] = {0, extra_commit_len};
+    if (!secp256k1_rangeproof_verify_batch(g_default_engine, &res, min_value, max_value, (const unsigned char*)commit, proof, off,
+                                           extra_commit_len ? extra_commit : nullptr, extra_commit_len ? eoff : nullptr, (const unsigned char*)gen, 1)) return 0;
+    return res;
+}
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
@@ -226,7 +365,4 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine*, void*, uint32_t*, const
 extern "C" int s2k_gej_sum_dev(s2k_engine*, void*, unsigned char*, int32_t*, const uint32_t*, size_t) { S2K_TODO("s2k_gej_sum_dev"); }
 extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine*, int32_t*, const unsigned char*, const unsigned char*, size_t, const unsigned char*, int, size_t) { S2K_TODO("secp256k1_schnorrsig_verify_batch"); }
 extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine*, void*, int32_t*, const unsigned char*, const unsigned char*, size_t, const unsigned char*, int, size_t) { S2K_TODO("secp256k1_schnorrsig_verify_batch_dev"); }
-extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine*, int32_t*, uint64_t*, uint64_t*, const unsigned char*, const unsigned char*, const uint64_t*, const unsigned char*, const uint64_t*, const unsigned char*, size_t) { S2K_TODO("secp256k1_rangeproof_verify_batch"); }
-extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine*, void*, int32_t*, uint64_t*, uint64_t*, const unsigned char*, const unsigned char*, const uint64_t*, const unsigned char*, const uint64_t*, const unsigned char*, size_t) { S2K_TODO("secp256k1_rangeproof_verify_batch_dev"); }
-extern "C" int secp256k1_rangeproof_verify_amd(const void*, uint64_t*, uint64_t*, const void*, const unsigned char*, size_t, const unsigned char*, size_t, const void*) { S2K_TODO("secp256k1_rangeproof_verify_amd"); }
 extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine*, int32_t*, const unsigned char*, size_t, const unsigned char*, const unsigned char*, const unsigned char*, size_t, size_t, const unsigned char*, size_t, const unsigned char*, size_t) { S2K_TODO("secp256k1_bppp_norm_product_verify_batch"); }

@@ -1,0 +1,346 @@
+// rangeproof.h -- Borromean rangeproof verification (secp256k1_rangeproof_verify) as five device stages.
+//
+// Reference call stack (src/modules/rangeproof/): main_impl.h:54-71 -> rangeproof_impl.h:541-683
+// (getheader_impl :487-538, pub_expand :20-51) -> borromean_impl.h:53-104.  One proof is 32 rings x 4 steps of
+//      e_{j+1} = SHA256( ser33( s_j G + e_j P_j ) || m || i || j+1 )
+// -- serial inside a ring, independent across rings and proofs.  The mapping chosen for gfx950:
+//
+//   K0  rp_prologue   1 lane / proof : header parse + structural checks, commitment / generator load, the message
+//                                      hash m, min_value*H, and the chain of ring bases  B_i = -(4^i 10^exp H)
+//   K1  rp_lift       1 lane / ring  : C_i = lift_x(proof x_i) (one field sqrt per lane) -> first public key of ring i
+//   K2  rp_sum        1 lane / proof : last ring's key  = commit - min_value*H - sum C_i
+//   K3  rp_rings      1 lane / ring  : the 4-step chain: double multiplication (ecmult.h), to-affine, serialise, SHA-256
+//   K4  rp_final      1 lane / proof : e0 == SHA256(r_0 || ... || r_{rings-1} || m) and all flags
+//
+// K3 is >98% of the work (128 double multiplications per 64-bit proof); K0/K2/K4 run one lane per proof but are
+// two orders of magnitude cheaper, so their low parallelism does not matter.  Stages communicate through a
+// per-proof scratch record in HBM (layout below); nothing is read back by the host between stages.
+#pragma once
+#include "ecmult.h"
+#include "sha256.h"
+
+#define RP_MAX_RINGS 32
+#define RP_GEJ_WORDS 28
+
+struct rp_rec {
+    u32 ok;            // structural checks passed (K0); cleared by later stages on failure
+    u32 rings;         // 1..32
+    u32 last_rsize;    // size of the last ring: 4, 2 (odd mantissa) or 1 (mantissa 0)
+    u32 off_signs;     // byte offsets inside the proof
+    u32 off_pts;
+    u32 off_e0;
+    u32 off_s;
+    u32 pad;
+    u32 m[8];          // message hash, big-endian words
+    u32 commit[18];    // commitment, affine limbs (x, y)
+    u32 accj[RP_GEJ_WORDS];   // min_value * H (infinity when min_value == 0)
+};
+
+struct rp_ws {           // device pointers into the engine workspace
+    rp_rec* rec;         // [n]
+    u32* bases;          // [n][32][28]
+    u32* pub0;           // [n][32][28]
+    unsigned char* lift_ok;   // [n][32]
+    unsigned char* ring_out;  // [n][32][36]
+    unsigned char* ring_ok;   // [n][32]
+};
+
+S2K_HD void gej_store28_h(u32* p, const gej& a) {
+    fe x = a.x, y = a.y, z = a.z;
+    fe_norm_weak(x); fe_norm_weak(y); fe_norm_weak(z);
+    for (int i = 0; i < 9; i++) { p[i] = x.n[i]; p[9 + i] = y.n[i]; p[18 + i] = z.n[i]; }
+    p[27] = (u32)a.inf;
+}
+S2K_HD void gej_load28_h(gej& a, const u32* p) {
+    for (int i = 0; i < 9; i++) { a.x.n[i] = p[i]; a.y.n[i] = p[9 + i]; a.z.n[i] = p[18 + i]; }
+    a.inf = (int)p[27];
+}
+
+// ---- K0 -------------------------------------------------------------------------------------------------
+// cf. secp256k1_rangeproof_getheader_impl (rangeproof_impl.h:487-538).  min/max are written exactly where the
+// reference writes through its pointers, so that a failed parse leaves the same partial values behind.
+S2K_HD int rp_getheader(u32& offset, int& exp, int& mantissa, u64& scale, u64* min_value, u64* max_value, const unsigned char* proof, u64 plen) {
+    offset = 0;
+    if (plen < 65 || ((proof[0] & 128) != 0)) return 0;
+    const int has_nz_range = proof[0] & 64, has_min = proof[0] & 32;
+    exp = -1; mantissa = 0;
+    if (has_nz_range) {
+        exp = proof[0] & 31;
+        offset += 1;
+        if (exp > 18) return 0;
+        mantissa = proof[offset] + 1;
+        if (mantissa > 64) return 0;
+        *max_value = 0xFFFFFFFFFFFFFFFFull >> (64 - mantissa);
+    } else {
+        *max_value = 0;
+    }
+    offset += 1;
+    scale = 1;
+    for (int i = 0; i < exp; i++) {
+        if (*max_value > 0xFFFFFFFFFFFFFFFFull / 10) return 0;
+        *max_value *= 10; scale *= 10;
+    }
+    *min_value = 0;
+    if (has_min) {
+        if (plen - offset < 8) return 0;
+        u64 v = 0;
+        for (int i = 0; i < 8; i++) v = (v << 8) | proof[offset + i];
+        *min_value = v;
+        offset += 8;
+    }
+    if (*max_value > 0xFFFFFFFFFFFFFFFFull - *min_value) return 0;
+    *max_value += *min_value;
+    return 1;
+}
+
+// One lane per proof.  cf. rangeproof_impl.h:541-608 and pub_expand :20-51.
+S2K_HD void rp_prologue(rp_rec& rec, u32* bases /*[32][28]*/, u64* min_value, u64* max_value, const unsigned char* commit33,
+                        const unsigned char* proof, u64 plen, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+    rec.ok = 0; rec.rings = 0; rec.last_rsize = 0;
+    rec.off_signs = 0; rec.off_pts = 0; rec.off_e0 = 0; rec.off_s = 0;
+    *min_value = 0; *max_value = 0;
+    u32 offset; int exp, mantissa; u64 scale;
+    if (!rp_getheader(offset, exp, mantissa, scale, min_value, max_value, proof, plen)) return;
+    const u32 off_hdr = offset;
+    u32 rings = 1, npub = 1, last_rsize = 1;
+    if (mantissa != 0) {
+        rings = (u32)mantissa >> 1; npub = rings * 4; last_rsize = 4;
+        if (mantissa & 1) { npub += 2; rings++; last_rsize = 2; }
+    }
+    if (plen - offset < (u64)32 * (npub + rings - 1) + 32 + ((rings + 6) >> 3)) return;
+    rec.rings = rings; rec.last_rsize = last_rsize;
+    rec.off_signs = offset;
+    offset += (rings + 6) >> 3;
+    if ((rings - 1) & 7) {
+        if ((proof[offset - 1] >> ((rings - 1) & 7)) != 0) return;
+    }
+    rec.off_pts = offset;
+    rec.off_e0 = offset + 32 * (rings - 1);
+    rec.off_s = rec.off_e0 + 32;
+    if ((u64)rec.off_s + (u64)32 * npub != plen) return;        // "Extra data found, reject" (:643-646); too-short was caught above
+
+    // commitment: x = b32 mod p, y = sqrt(x^3+7), negated when bit 0 of the prefix is set (generator/main_impl.h:266-273)
+    ge c;
+    {
+        fe x; fe_set_b32_mod(x, commit33 + 1);
+        ge_set_xquad(c, x);
+        fe_normalize(c.x); fe_normalize(c.y);
+        if (commit33[0] & 1) { fe_neg(c.y, c.y, 1); fe_normalize(c.y); }
+    }
+    for (int i = 0; i < 9; i++) { rec.commit[i] = c.x.n[i]; rec.commit[9 + i] = c.y.n[i]; }
+    // generator (generator/main_impl.h:40-49)
+    ge g;
+    fe_set_b32_mod(g.x, gen64); fe_set_b32_mod(g.y, gen64 + 32);
+    fe_normalize(g.x); fe_normalize(g.y);
+
+    // m = SHA256( ser(commit) || ser(gen) || proof[0..off_hdr) || (sign_i || x_i)_{i<rings-1} || extra )   (:588-651)
+    // ser(point) = [ !is_square(y) ] || x   (rangeproof_serialize_point :53-59)
+    {
+        sha256_stream h; sha256_stream_init(h);
+        unsigned char buf[32];
+        // y of the commitment is the square root (a square) unless negated; y == 0 cannot occur for x^3+7 = 0 has no
+        // solution with a square... keep the exact rule: is_square(0) = 1.
+        int cy_zero = fe_is_zero_normalized(c.y);
+        sha256_stream_put(h, (unsigned char)((commit33[0] & 1) && !cy_zero ? 1 : 0));
+        fe_get_b32(buf, c.x); sha256_stream_write(h, buf, 32);
+        fe r; const int gsq = fe_sqrt(r, g.y);
+        sha256_stream_put(h, (unsigned char)(!gsq));
+        fe_get_b32(buf, g.x); sha256_stream_write(h, buf, 32);
+        sha256_stream_write(h, proof, off_hdr);
+        for (u32 i = 0; i + 1 < rings; i++) {
+            const unsigned char sign = (proof[rec.off_signs + (i >> 3)] & (1u << (i & 7))) != 0;
+            sha256_stream_put(h, sign);
+            sha256_stream_write(h, proof + rec.off_pts + 32 * i, 32);
+        }
+        if (extra) sha256_stream_write(h, extra, (size_t)extra_len);
+        unsigned char m[32];
+        sha256_stream_finalize(h, m);
+        for (int i = 0; i < 8; i++) rec.m[i] = s2k_load_be32(m + 4 * i);
+    }
+    // accj = min_value * H  (pedersen_ecmult_small, generator/pedersen_impl.h:33-38): plain double-and-add, the
+    // result is the same group element as the reference's ecmult_const.
+    {
+        gej acc; gej_set_infinity(acc);
+        const u64 mv = *min_value;
+        if (mv) {
+            for (int bit = 63; bit >= 0; bit--) {
+                gej t; gej_double(t, acc); acc = t;
+                if ((mv >> bit) & 1) {
+                    const int f = gej_add_ge(t, acc, g); acc = t;
+                    if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+                }
+            }
+        }
+        gej_store28_h(rec.accj, acc);
+    }
+    // ring bases: base_0 = -(10^exp) H, base_{i+1} = 4 base_i   (pub_expand, rangeproof_impl.h:20-51)
+    {
+        gej base; ge ng; ng.x = g.x; fe_neg(ng.y, g.y, 1); fe_norm_weak(ng.y);
+        gej_set_ge(base, ng);
+        for (int e = 0; e < exp; e++) {          // multiplication by 10 = 8x + 2x
+            gej t2, t8, s;
+            gej_double(t2, base); gej_double(t8, t2); gej_double(s, t8);
+            gej_add_var(base, s, t2);
+        }
+        for (u32 i = 0; i < rings; i++) {
+            gej_store28_h(bases + RP_GEJ_WORDS * i, base);
+            if (i + 1 < rings) { gej t; gej_double(t, base); gej_double(base, t); }
+        }
+    }
+    rec.ok = 1;
+}
+
+// ---- K1: lift the ring commitments (rangeproof_impl.h:609-626) ------------------------------------------------
+S2K_HD void rp_lift(const rp_rec& rec, u32* pub0_ring, unsigned char* lift_ok, const unsigned char* proof, u32 ring) {
+    fe x; ge c;
+    const unsigned char* px = proof + rec.off_pts + 32 * ring;
+    int ok = fe_set_b32_limit(x, px);
+    ok &= ge_set_xquad(c, x);
+    const int sign = (proof[rec.off_signs + (ring >> 3)] >> (ring & 7)) & 1;
+    fe ny; fe_neg(ny, c.y, 1);
+    fe_select(c.y, ny, c.y, sign);
+    gej j; gej_set_ge(j, c);
+    gej_store28_h(pub0_ring, j);
+    *lift_ok = (unsigned char)ok;
+}
+
+// ---- K2: key of the last ring (rangeproof_impl.h:619-631) ------------------------------------------------------
+S2K_HD void rp_sum(rp_rec& rec, u32* pub0 /*[32][28]*/, const unsigned char* lift_ok /*[32]*/) {
+    if (!rec.ok) return;
+    gej acc; gej_load28_h(acc, rec.accj);
+    int ok = 1;
+    for (u32 i = 0; i + 1 < rec.rings; i++) {
+        ok &= lift_ok[i];
+        gej c; gej_load28_h(c, pub0 + RP_GEJ_WORDS * i);
+        ge ca; ca.x = c.x; ca.y = c.y;                        // lifted points carry Z = 1
+        gej t; const int f = gej_add_ge(t, acc, ca); acc = t;
+        if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+    }
+    // pubs[last] = commit - acc
+    fe ny; fe_neg(ny, acc.y, 3); fe_norm_weak(ny); acc.y = ny;
+    fe_norm_weak(acc.x);
+    ge cm;
+    for (int i = 0; i < 9; i++) { cm.x.n[i] = rec.commit[i]; cm.y.n[i] = rec.commit[9 + i]; }
+    gej last; const int f = gej_add_ge(last, acc, cm);
+    if (f == GEJ_ADD_NEEDS_DOUBLE) { gej t; gej_double(t, last); last = t; }
+    if (last.inf) ok = 0;
+    gej_store28_h(pub0 + RP_GEJ_WORDS * (rec.rings - 1), last);
+    if (!ok) rec.ok = 0;
+}
+
+// ---- K3: one ring (borromean_impl.h:70-98) ------------------------------------------------------------------------
+S2K_HD void rp_words_to_scalar(scalar& s, int& overflow, const u32 w[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.d[i] = w[7 - i];
+    overflow = sc_check_overflow(s.d);
+    sc_reduce_once(s.d, overflow);
+}
+// H(e0 || m || ring || 0)   (secp256k1_borromean_hash with elen = 32, :23-37)
+S2K_HD void rp_hash_e0(u32 out[8], const u32 e0[8], const u32 m[8], u32 ring) {
+    u32 st[8], w[16];
+    sha256_init(st);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w[i] = e0[i]; w[8 + i] = m[i]; }
+    sha256_compress(st, w);
+    w[0] = ring; w[1] = 0; w[2] = 0x80000000u;
+#pragma unroll
+    for (int i = 3; i < 15; i++) w[i] = 0;
+    w[15] = 72 * 8;
+    sha256_compress(st, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+// H(ser33 || m || ring || epos), ser33 = prefix byte || x (8 big-endian words)
+S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8], u32 ring, u32 epos) {
+    u32 st[8], w[16];
+    sha256_init(st);
+    w[0] = (prefix << 24) | (x[0] >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[i] = (x[i - 1] << 24) | (x[i] >> 8);
+    w[8] = (x[7] << 24) | (m[0] >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[8 + i] = (m[i - 1] << 24) | (m[i] >> 8);
+    sha256_compress(st, w);
+    w[0] = (m[7] << 24) | (ring >> 8);
+    w[1] = (ring << 24) | (epos >> 8);
+    w[2] = (epos << 24) | 0x00800000u;
+#pragma unroll
+    for (int i = 3; i < 15; i++) w[i] = 0;
+    w[15] = 73 * 8;
+    sha256_compress(st, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
+S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
+                    const unsigned char* proof, u32 ring, int live, const u32* gtab) {
+    const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
+    int ok = live & (int)rec.ok;
+    u32 m[8], e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+    {
+        u32 e0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {                                   // never touch proof bytes of a proof that failed its structural checks
+            const unsigned char* pe0 = proof + rec.off_e0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) e0[i] = s2k_load_be32(pe0 + 4 * i);
+        }
+        rp_hash_e0(e, e0, m, ring);
+    }
+    gej pub, base;
+    gej_load28_h(pub, pub28);
+    gej_load28_h(base, base28);
+    u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
+#pragma unroll 1
+    for (u32 j = 0; j < 4; j++) {
+        const int step_live = ok & (j < rsize);
+        scalar ens, s; int ov_e, ov_s = 0;
+        rp_words_to_scalar(ens, ov_e, e);
+        sc_set_zero(s);
+        if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);
+        int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens) & !pub.inf;
+        if (!good) { sc_set_zero(ens); sc_set_zero(s); }            // dead lanes ride along with empty work
+        gej R;
+        ecmult_lane(R, pub, ens, s, 1, gtab);
+        good &= !R.inf;
+        ge a; ge_set_gej(a, R);
+        u32 xw[8]; fe_to_words(xw, a.x);
+        u32 xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xb[i] = xw[7 - i];
+        const u32 prefix = 2u | (u32)fe_is_odd(a.y);
+        if (step_live) ok &= good;
+        if (j + 1 < rsize) {
+            rp_hash_step(e, prefix, xb, m, ring, j + 1);
+            gej nxt; gej_add_var(nxt, pub, base); pub = nxt;
+        } else if (j + 1 == rsize) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) outx[i] = xb[i];
+            outp = prefix;
+        }
+    }
+    if (live) {
+        ring_out36[0] = (unsigned char)outp;
+        for (int i = 0; i < 8; i++) s2k_store_be32(ring_out36 + 1 + 4 * i, outx[i]);
+        *ring_ok = (unsigned char)ok;
+    }
+}
+
+// ---- K4: close the loop (borromean_impl.h:100-103) ---------------------------------------------------------------------
+S2K_HD int rp_final(const rp_rec& rec, const unsigned char* ring_out /*[32][36]*/, const unsigned char* ring_ok, const unsigned char* proof) {
+    if (!rec.ok) return 0;
+    int ok = 1;
+    sha256_stream h; sha256_stream_init(h);
+    for (u32 i = 0; i < rec.rings; i++) {
+        ok &= ring_ok[i];
+        sha256_stream_write(h, ring_out + 36 * i, 33);
+    }
+    unsigned char mb[32], d[32];
+    for (int i = 0; i < 8; i++) s2k_store_be32(mb + 4 * i, rec.m[i]);
+    sha256_stream_write(h, mb, 32);
+    sha256_stream_finalize(h, d);
+    int diff = 0;
+    for (int i = 0; i < 32; i++) diff |= d[i] ^ proof[rec.off_e0 + i];
+    return ok & (diff == 0);
+}

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Extract the reference's own known-answer vectors for the hot path into small JSON fixtures.
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+Only *test data* (byte arrays and the expected results the reference's tests assert) is extracted; the fixtures are
+what the GPU box uses, since /root/reference does not exist there.  Sources:
+  rangeproof : src/modules/rangeproof/tests_impl.h:589-812 (3 fixed proofs) and :883-1349 (3 reproducible proofs,
+               incl. the maximal 64-bit / exp=18 / 5126-byte one)
+  bppp       : src/modules/bppp/test_vectors/verify.h (13 norm-argument accept/reject vectors)
+  schnorrsig : src/modules/schnorrsig/tests_impl.h:208-807 (the BIP-340 vectors)
+"""
+import json
+import os
+import re
+import sys
+
+REF = os.environ.get("S2K_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def c_arrays(text):
+    """name -> bytes for every `unsigned char NAME[...] = { 0x.., ... };` in text (in order of appearance, duplicates kept as list)."""
+    out = []
+    for m in re.finditer(r"unsigned char\s+(\w+)\s*\[[^\]]*\]\s*=\s*\{([^;]*?)\}\s*;", text, re.S):
+        body = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+        vals = re.findall(r"0[xX][0-9a-fA-F]{1,2}|\b\d+\b", body)
+        out.append((m.group(1), bytes(int(v, 0) for v in vals), m.start()))
+    return out
+
+
+def rangeproof():
+    path = os.path.join(REF, "src/modules/rangeproof/tests_impl.h")
+    text = open(path).read()
+    a = text.index("static void test_rangeproof_fixed_vectors(void)")
+    b = text.index("static void print_vector_helper")
+    c = text.index("static void test_rangeproof_fixed_vectors_reproducible(void)")
+    fixed = {n: v for n, v, _ in c_arrays(text[a:b])}
+    repro = {n: v for n, v, _ in c_arrays(text[c:])}
+    U64 = 2**64 - 1
+    I64 = 2**63 - 1
+    vecs = [
+        # (proof, commit, expected result, min, max) -- expectations are the CHECK()s at tests_impl.h:663-664,734-735,792-793
+        ("fixed_1", fixed["vector_1"], fixed["commit_1"], 1, 86, 25586),
+        ("fixed_2", fixed["vector_2"], fixed["commit_2"], 1, 0, 15),
+        ("fixed_3", fixed["vector_3"], fixed["commit_3"], 1, U64, U64),
+        # tests_impl.h:1245-1246, 1292-1293, 1343-1344
+        ("repro_0_max64_exp18", repro["vector_0"], repro["commit_0"], 1, 0, U64),
+        ("repro_1_minbits3", repro["vector_1"], repro["commit_1"], 1, 3, 73),
+        ("repro_2_large_min", repro["vector_2"], repro["commit_2"], 1, I64 - 1, I64),
+    ]
+    data = [dict(name=n, proof=p.hex(), commit33=cm.hex(), result=r, min_value=str(mn), max_value=str(mx)) for n, p, cm, r, mn, mx in vecs]
+    json.dump(dict(source="src/modules/rangeproof/tests_impl.h:589-812,883-1349", generator="secp256k1_generator_h", vectors=data),
+              open(os.path.join(OUT, "rangeproof_vectors.json"), "w"), indent=0)
+    print("rangeproof:", [(d["name"], len(d["proof"]) // 2) for d in data])
+
+
+def bppp():
+    path = os.path.join(REF, "src/modules/bppp/test_vectors/verify.h")
+    text = open(path).read()
+    arrs = c_arrays(text)
+    byname = {}
+    for n, v, _ in arrs:
+        byname[n] = v
+    gens = byname["verify_vector_gens"]
+    vecs = []
+    i = 0
+    while f"verify_vector_{i}_commit33" in byname:
+        nlen = int(re.search(rf"verify_vector_{i}_n_vec_len\s*=\s*(\d+)", text).group(1))
+        res = int(re.search(rf"verify_vector_{i}_result\s*=\s*(\d+)", text).group(1))
+        # c_vec32 is a 2-D array: parse rows
+        m = re.search(rf"verify_vector_{i}_c_vec32\[(\d+)\]\[32\]\s*=\s*\{{(.*?)\}}\s*;", text, re.S)
+        rows = re.findall(r"\{([^{}]*)\}", m.group(2))
+        cvec = [bytes(int(v, 0) for v in re.findall(r"0[xX][0-9a-fA-F]{1,2}", r)) for r in rows]
+        assert len(cvec) == int(m.group(1)) and all(len(c) == 32 for c in cvec)
+        vecs.append(dict(index=i, commit33=byname[f"verify_vector_{i}_commit33"].hex(), n_vec_len=nlen, c_vec=[c.hex() for c in cvec],
+                         rho=byname[f"verify_vector_{i}_r32"].hex(), proof=byname[f"verify_vector_{i}_proof"].hex(), result=res))
+        i += 1
+    json.dump(dict(source="src/modules/bppp/test_vectors/verify.h (driver tests_impl.h:540-588: transcript = plain sha256_initialize)",
+                   gens=gens.hex(), vectors=vecs), open(os.path.join(OUT, "bppp_verify_vectors.json"), "w"), indent=0)
+    print("bppp:", len(vecs), "vectors, gens", len(gens) // 33)
+
+
+def bip340():
+    path = os.path.join(REF, "src/modules/schnorrsig/tests_impl.h")
+    text = open(path).read()
+    a = text.index("static void test_schnorrsig_bip_vectors(void)")
+    body = text[a:]
+    end = body.index("\n}\n")
+    body = body[:end]
+    vecs = []
+    # each vector is a { ... } block with pk / msg / sig arrays followed by a check helper call
+    for blk in re.split(r"\n    \{\n", body)[1:]:
+        arrs = {n: v for n, v, _ in c_arrays(blk)}
+        if "pk" not in arrs or "sig" not in arrs:
+            continue
+        msg = arrs.get("msg", b"")
+        m = re.search(r"test_schnorrsig_bip_vectors_check_verify\(pk,\s*msg,\s*(?:sizeof\(msg\)|\d+),\s*sig,\s*(\d)\)", blk)
+        if m is None:
+            if "secp256k1_xonly_pubkey_parse" in blk and "CHECK(!" in blk:
+                vecs.append(dict(pk=arrs["pk"].hex(), msg=msg.hex(), sig=arrs["sig"].hex(), result=0, pk_invalid=1))
+            continue
+        vecs.append(dict(pk=arrs["pk"].hex(), msg=msg.hex(), sig=arrs["sig"].hex(), result=int(m.group(1)), pk_invalid=0))
+    json.dump(dict(source="src/modules/schnorrsig/tests_impl.h:208-807 (BIP-340 test vectors)", vectors=vecs),
+              open(os.path.join(OUT, "bip340_vectors.json"), "w"), indent=0)
+    print("bip340:", len(vecs), "vectors", [v["result"] for v in vecs], "msg lens", sorted(set(len(v["msg"]) // 2 for v in vecs)))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not found at " + REF)
+    rangeproof(); bppp(); bip340()

@@ -6,6 +6,7 @@
 #define S2K_VERIFY 1
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
+#include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
 #include <string.h>
 #include <vector>
 
@@ -93,5 +94,18 @@ int emu_ecmult(unsigned char* r64, const unsigned char* a64, int ainf, const uns
 }
 void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
     sha256_stream c; sha256_stream_init(c); sha256_stream_write(c, msg, len); sha256_stream_finalize(c, out32);
+}
+
+// the five rangeproof stages of rangeproof.h run back to back for one proof
+int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
+                          const unsigned char* extra, size_t extra_len, const unsigned char* gen64) {
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0); unsigned char lift_ok[32] = {0}, ring_out[32 * 36] = {0}, ring_ok[32] = {0};
+    u64 mn, mx;
+    rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, extra_len ? extra : nullptr, extra_len, gen64);
+    *min_value = mn; *max_value = mx;
+    if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
+    rp_sum(rec, pub0.data(), lift_ok);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host());
+    return rp_final(rec, ring_out, ring_ok, proof);
 }
 }

@@ -63,8 +63,8 @@ class Ref:
     def make_rangeproofs(self, n, rng, min_bits=64, exp=0, min_value=0, gens64=None, values=None, threads=8):
         blinds = rng.integers(0, 256, (n, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F
         if values is None:
-            hi = 2**63 if min_bits >= 64 else 2**max(min_bits, 1)
-            values = rng.integers(0, hi, n, dtype=np.uint64)
+            hi = 2**63 if min_bits >= 63 else 2**max(min_bits, 1)
+            values = rng.integers(0, hi, n, dtype=np.uint64) + np.uint64(min_value)
         values = np.ascontiguousarray(values, np.uint64)
         if gens64 is None:
             gens64 = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64).copy()
