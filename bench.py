@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: 64-bit Borromean rangeproof verifies/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the verification hot path (secp256k1_rangeproof_verify semantics, five HIP kernels) over one batch
+of 2^14 synthetic 64-bit proofs per GPU (BASELINE.json configs[2]; the batch the metric is quoted on), inputs already
+resident in HBM.  Independent proofs shard with no exchange step, so N GPUs run N replicas of the batch ("weak" scaling).
+One JSON line is printed by rank 0.  Also reported: the roofline of the dominant kernel (k_rp_rings) and the reference's
+own CPU path timed on the host cores of the same box (oracle/_ref, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 1 << 14                    # proofs per GPU per step
+PROOF_BYTES_ALGO = 5223            # 5126 B proof + 33 B commitment + 64 B generator
+MAC64_PER_PROOF = 6.6e6            # reference schedule, 64x64->128 MACs per 64-bit proof
+MAD32_PEAK = 3.59e13               # measured on MI355X: v_mad_u64_u32 lane-ops/s chip-wide (tools/ubench/valu_rates.hip)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_inputs(n, seed):
+    """n 64-bit proofs (exp 0, min_value 0, generator H), signed with the reference when oracle/_ref is available
+    (as src/bench_rangeproof.c:26-36 does), otherwise tiled from the committed golden 64-bit vector."""
+    rng = np.random.default_rng(seed)
+    try:
+        from tests.refapi import Ref
+        ref = Ref()
+        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=min(os.cpu_count() or 1, 64))
+        return commits, proofs, gens, "synthetic (secp256k1_rangeproof_sign via oracle/_ref, %d unique 64-bit proofs)" % n, ref
+    except OSError:
+        from tests.refapi import GENERATOR_H
+        v = [x for x in json.load(open(os.path.join(ROOT, "tests", "golden", "rangeproof_vectors.json")))["vectors"] if x["name"].startswith("repro_0")][0]
+        commits = np.tile(np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8), (n, 1))
+        proofs = [bytes.fromhex(v["proof"])] * n
+        gens = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64)
+        return commits, proofs, gens, "synthetic (reference golden 64-bit proof tiled; oracle/_ref not present)", None
+
+
+def cpu_baseline(ref, commits, proofs, gens):
+    """the reference's secp256k1_rangeproof_verify on host cores, bounded sample (~10-20 s of CPU work)."""
+    if ref is None:
+        return None
+    cores = os.cpu_count() or 1
+    k1 = min(256, len(proofs))
+    t = time.time(); r, _, _ = ref.rangeproof_verify_many(commits[:k1], proofs[:k1], gens[:k1], threads=1); t1 = time.time() - t
+    assert r.all()
+    kn = min(len(proofs), max(256, 32 * cores))
+    ref.rangeproof_verify_many(commits[:cores], proofs[:cores], gens[:cores], threads=cores)      # spin up the OpenMP team
+    t = time.time(); r, _, _ = ref.rangeproof_verify_many(commits[:kn], proofs[:kn], gens[:kn], threads=cores); tn = time.time() - t
+    assert r.all()
+    return {"value": kn / tn, "unit": "verifies/s", "cores": cores, "kind": "reference",
+            "sample": "%d 64-bit proofs on %d threads (%.2f s); single thread: %d proofs in %.2f s = %.1f verifies/s/core" % (kn, cores, tn, k1, t1, k1 / t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from secp256k1_zkp_amd import Engine
+    eng = Engine(local)
+    torch.cuda.set_device(local)
+    n = args.batch
+    commits, proofs, gens, data_desc, ref = make_inputs(n, seed=1234 + rank)
+    pdata, poff = Engine.pack(proofs)
+    dev = torch.device("cuda", local)
+    d_commits = torch.tensor(commits).to(dev); d_gens = torch.tensor(np.ascontiguousarray(gens)).to(dev)
+    d_proofs = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
+    d_res = torch.zeros(n, dtype=torch.int32, device=dev); d_min = torch.zeros(n, dtype=torch.int64, device=dev); d_max = torch.zeros(n, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_commits, d_proofs, d_off, d_gens, n, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(args.steps):
+        step()
+        torch.cuda.synchronize()          # one batch in flight at a time (a step is one pass over one batch)
+        kern_ms.append(eng.last_ms(1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        ok = torch.tensor([int(d_res.all().item())], device=dev); dist.all_reduce(ok, op=dist.ReduceOp.MIN); all_ok = bool(ok.item())
+    else:
+        all_ok = bool(d_res.all().item())
+    assert all_ok, "a valid proof was rejected"
+    assert int(d_max.min().item()) == -1          # max_value == 2^64-1 for every 64-bit proof
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        kms = float(np.mean(kern_ms))
+        achieved = PROOF_BYTES_ALGO * n / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "64-bit Borromean rangeproof verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit), 32x32->64 integer MAC", "data": data_desc,
+            "config": {"workload": "secp256k1_rangeproof_verify, batch of 2^14 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)",
+                       "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)"},
+            "roofline": {"bound": "hbm", "kernel": "k_rp_rings", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kms,
+                         "note": "path is integer-VALU bound (SURVEY 8d); see valu_roofline"},
+            "valu_roofline": {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": 4 * MAC64_PER_PROOF * n / (kms * 1e-3), "peak": MAD32_PEAK,
+                              "frac": 4 * MAC64_PER_PROOF * n / (kms * 1e-3) / MAD32_PEAK,
+                              "note": "algorithmic 6.6e6 MAC64/proof (reference schedule) x 4 mad_u64_u32; peak measured with tools/ubench"},
+        }
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(ref, commits, proofs, gens)
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
