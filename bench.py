@@ -35,7 +35,7 @@ def make_inputs(n, seed):
     try:
         from tests.refapi import Ref
         ref = Ref()
-        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=min(os.cpu_count() or 1, 64))
+        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=min(usable_cores() * 2, 64))
         return commits, proofs, gens, "synthetic (secp256k1_rangeproof_sign via oracle/_ref, %d unique 64-bit proofs)" % n, ref
     except OSError:
         from tests.refapi import GENERATOR_H
@@ -46,15 +46,28 @@ def make_inputs(n, seed):
         return commits, proofs, gens, "synthetic (reference golden 64-bit proof tiled; oracle/_ref not present)", None
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose
+    256 hardware threads but grant the container 16 CPUs of quota; oversubscribing only slows the OpenMP team down)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(ref, commits, proofs, gens):
     """the reference's secp256k1_rangeproof_verify on host cores, bounded sample (~10-20 s of CPU work)."""
     if ref is None:
         return None
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     k1 = min(256, len(proofs))
     t = time.time(); r, _, _ = ref.rangeproof_verify_many(commits[:k1], proofs[:k1], gens[:k1], threads=1); t1 = time.time() - t
     assert r.all()
-    kn = min(len(proofs), max(256, 32 * cores))
+    kn = min(len(proofs), max(256, 256 * cores))
     ref.rangeproof_verify_many(commits[:cores], proofs[:cores], gens[:cores], threads=cores)      # spin up the OpenMP team
     t = time.time(); r, _, _ = ref.rangeproof_verify_many(commits[:kn], proofs[:kn], gens[:kn], threads=cores); tn = time.time() - t
     assert r.all()

@@ -7,6 +7,7 @@
 #include "gtable.h"
 #include "sha256.h"
 #include "rangeproof.h"
+#include "schnorr.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -40,6 +41,7 @@ struct s2k_engine {
     unsigned char* ws;         // growable HBM workspace
     size_t ws_bytes;
     hipEvent_t ev[4];          // [0],[1] whole call; [2],[3] dominant kernel
+    schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     std::mutex mu;
 };
 
@@ -127,6 +129,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
     e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr;
+    schnorr_tag_midstate(e->bip340);
     HIPCHK_NULL(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK_NULL(hipEventCreate(&e->ev[i]));
     HIPCHK_NULL(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
@@ -356,6 +359,50 @@ extern "C" int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_va
                                            extra_commit_len ? extra_commit : nullptr, extra_commit_len ? eoff : nullptr, (const unsigned char*)gen, 1)) return 0;
     return res;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// BIP-340 batch verification (schnorr.h): one signature per lane
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+k_schnorr_verify(int32_t* __restrict__ results, schnorr_midstate mid, const unsigned char* __restrict__ sigs, const unsigned char* __restrict__ msgs,
+                 size_t msglen, const unsigned char* __restrict__ pks, int pk_format, const u32* __restrict__ gtab, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int live = i < n;
+    const size_t ii = live ? i : 0;
+    const int r = schnorr_verify_lane(mid, sigs + 64 * ii, msgs + msglen * ii, msglen, pks + (pk_format ? 64 : 32) * ii, pk_format, live, gtab);
+    if (live) results[i] = r;
+}
+extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* sigs,
+                                                     const unsigned char* msgs, size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_verify_batch_dev", "null engine");
+    if (n == 0) return 1;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_schnorr_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, e->bip340, sigs, msgs, msglen, pubkeys, pk_format, e->gtab, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* sigs, const unsigned char* msgs,
+                                                 size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_verify_batch", "null engine");
+    if (n == 0) return 1;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pkb = pk_format ? 64 : 32;
+    if (!engine_workspace(e, ws_need({4 * n, 64 * n, msglen * n + 64, pkb * n}))) return 0;
+    ws_carver w{e->ws, 0};
+    int32_t* d_res = w.take<int32_t>(n); unsigned char* d_sig = w.take<unsigned char>(64 * n);
+    unsigned char* d_msg = w.take<unsigned char>(msglen * n + 64); unsigned char* d_pk = w.take<unsigned char>(pkb * n);
+    HIPCHK(hipMemcpyAsync(d_sig, sigs, 64 * n, hipMemcpyHostToDevice, e->stream));
+    if (msglen) HIPCHK(hipMemcpyAsync(d_msg, msgs, msglen * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_pk, pubkeys, pkb * n, hipMemcpyHostToDevice, e->stream));
+    if (!secp256k1_schnorrsig_verify_batch_dev(e, nullptr, d_res, d_sig, d_msg, msglen, d_pk, pk_format, n)) return 0;
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 1;
+}
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
@@ -363,6 +410,4 @@ extern "C" int s2k_ecmult_multi(s2k_engine*, unsigned char*, int32_t*, const uns
 extern "C" int s2k_ecmult_multi_dev(s2k_engine*, void*, unsigned char*, int32_t*, const unsigned char*, const unsigned char*, const unsigned char*, const unsigned char*, size_t) { S2K_TODO("s2k_ecmult_multi_dev"); }
 extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine*, void*, uint32_t*, const unsigned char*, const unsigned char*, const unsigned char*, const unsigned char*, size_t) { S2K_TODO("s2k_ecmult_multi_partial_dev"); }
 extern "C" int s2k_gej_sum_dev(s2k_engine*, void*, unsigned char*, int32_t*, const uint32_t*, size_t) { S2K_TODO("s2k_gej_sum_dev"); }
-extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine*, int32_t*, const unsigned char*, const unsigned char*, size_t, const unsigned char*, int, size_t) { S2K_TODO("secp256k1_schnorrsig_verify_batch"); }
-extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine*, void*, int32_t*, const unsigned char*, const unsigned char*, size_t, const unsigned char*, int, size_t) { S2K_TODO("secp256k1_schnorrsig_verify_batch_dev"); }
 extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine*, int32_t*, const unsigned char*, size_t, const unsigned char*, const unsigned char*, const unsigned char*, size_t, size_t, const unsigned char*, size_t, const unsigned char*, size_t) { S2K_TODO("secp256k1_bppp_norm_product_verify_batch"); }

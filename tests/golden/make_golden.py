@@ -91,10 +91,17 @@ def bip340():
     # each vector is a { ... } block with pk / msg / sig arrays followed by a check helper call
     for blk in re.split(r"\n    \{\n", body)[1:]:
         arrs = {n: v for n, v, _ in c_arrays(blk)}
+        if "pk" in arrs and "sig" not in arrs and re.search(r"CHECK\(!secp256k1_xonly_pubkey_parse", blk):
+            # vectors 5 and 14: the key itself does not parse; any signature must be rejected
+            vecs.append(dict(pk=arrs["pk"].hex(), msg="00" * 32, sig="00" * 64, result=0, pk_invalid=1))
+            continue
         if "pk" not in arrs or "sig" not in arrs:
             continue
         msg = arrs.get("msg", b"")
-        m = re.search(r"test_schnorrsig_bip_vectors_check_verify\(pk,\s*msg,\s*(?:sizeof\(msg\)|\d+),\s*sig,\s*(\d)\)", blk)
+        mm = re.search(r"unsigned char msg\[(\d+)\];\s*memset\(msg,\s*(0x[0-9a-fA-F]+|\d+),\s*sizeof\(msg\)\)", blk)
+        if mm:                                      # vector 18: 100 bytes of 0x99 built with memset (tests_impl.h:761-762)
+            msg = bytes([int(mm.group(2), 0)]) * int(mm.group(1))
+        m = re.search(r"test_schnorrsig_bip_vectors_check_verify\(pk,\s*(?:msg|NULL),\s*(?:sizeof\(msg\)|\d+),\s*sig,\s*(\d)\)", blk)
         if m is None:
             if "secp256k1_xonly_pubkey_parse" in blk and "CHECK(!" in blk:
                 vecs.append(dict(pk=arrs["pk"].hex(), msg=msg.hex(), sig=arrs["sig"].hex(), result=0, pk_invalid=1))

@@ -7,6 +7,7 @@
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
+#include "../../secp256k1_zkp_amd/csrc/schnorr.h"
 #include <string.h>
 #include <vector>
 
@@ -107,5 +108,10 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
     rp_sum(rec, pub0.data(), lift_ok);
     for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host());
     return rp_final(rec, ring_out, ring_ok, proof);
+}
+
+int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, size_t msglen, const unsigned char* pk, int pk_format) {
+    schnorr_midstate mid; schnorr_tag_midstate(mid);
+    return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host());
 }
 }
