@@ -17,6 +17,8 @@ class S2KError(RuntimeError):
 
 
 def _u8(a, shape=None):
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
     a = np.ascontiguousarray(a, dtype=np.uint8)
     if shape is not None:
         a = a.reshape(shape)

@@ -8,6 +8,7 @@
 #include "sha256.h"
 #include "rangeproof.h"
 #include "schnorr.h"
+#include "msm.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -403,11 +404,277 @@ extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipStreamSynchronize(e->stream));
     return 1;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// multi-scalar multiplication (msm.h)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_msm_prep(u32* term, u32* keys, u32* hist, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
+           size_t n, size_t nt, msm_plan pl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const int isg = (i == n);       // only when g_sc != NULL (nt == n + 1)
+    msm_prep(term + i * MSM_TERM_WORDS, keys + i * 2 * pl.windows, hist, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
+             isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg, pl);
+}
+// exclusive scan of hist[0..nk) into off[0..nk] and cur (copy), one workgroup
+__global__ void __launch_bounds__(1024)
+k_scan_u32(u32* off, u32* cur, const u32* hist, u32 nk) {
+    __shared__ u32 part[1024];
+    const u32 t = threadIdx.x, per = (nk + 1023) / 1024, lo = t * per, hi = min(lo + per, nk);
+    u32 s = 0;
+    for (u32 k = lo; k < hi; k++) s += hist[k];
+    part[t] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        u32 v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - s;
+    for (u32 k = lo; k < hi; k++) { off[k] = run; cur[k] = run; run += hist[k]; }
+    if (t == 1023) off[nk] = part[1023];
+}
+__global__ void __launch_bounds__(256)
+k_msm_scatter(u32* refs, u32* cur, const u32* keys, size_t nt, msm_plan pl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    for (u32 h = 0; h < 2; h++) for (u32 w = 0; w < pl.windows; w++) {
+        const u32 key = keys[i * 2 * pl.windows + h * pl.windows + w];
+        if (key) { const u32 pos = atomicAdd(&cur[key >> 1], 1u); refs[pos] = (u32)(i << 2) | (h << 1) | (key & 1u); }
+    }
+}
+__global__ void k_msm_counts(u32* cnt_out, const u32* cnt_in, u32 nk, u32 T) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nk) cnt_out[k] = (cnt_in[k] + T - 1) / T;
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* off_out, const u32* term, u32 nk, u32 T) {
+    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= off_out[nk]) return;
+    const u32 k = msm_find_key(off_out, nk, m), j = m - off_out[k];
+    const u32 start = off_in[k] + j * T, end = min(start + T, off_in[k + 1]);
+    gej o; msm_sum_refs(o, refs, start, end, term);
+    gej_store28(out28 + (size_t)m * 28, o);
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_roundN(u32* out28, const u32* in28, const u32* off_in, const u32* off_out, u32 nk, u32 T) {
+    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= off_out[nk]) return;
+    const u32 k = msm_find_key(off_out, nk, m), j = m - off_out[k];
+    const u32 start = off_in[k] + j * T, end = min(start + T, off_in[k + 1]);
+    gej acc; gej_set_infinity(acc);
+    for (u32 i = start; i < end; i++) { gej v, s; gej_load28(v, in28 + (size_t)i * 28); gej_add_var(s, acc, v); acc = s; }
+    gej_store28(out28 + (size_t)m * 28, acc);
+}
+__global__ void __launch_bounds__(256, 2)
+k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, msm_plan pl) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    const u32 b = k % pl.nb;
+    gej v, o; gej_set_infinity(v);
+    if (b != 0 && off_last[k + 1] > off_last[k]) gej_load28(v, in28 + (size_t)off_last[k] * 28);
+    msm_scale(o, v, b);
+    gej_store28(bucket_out28 + (size_t)k * 28, o);
+}
+// segmented tree sum: block (seg, chunk) adds up items [chunk*per_block, ...) of segment `seg` (seg_len items each)
+__global__ void __launch_bounds__(256)
+k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunks) {
+    __shared__ u32 sh[256 * 28];
+    const u32 seg = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, t = threadIdx.x;
+    const u32 lo = chunk * per_block, hi = min(lo + per_block, seg_len);
+    gej acc; gej_set_infinity(acc);
+    for (u32 k = lo + t; k < hi; k += 256) {
+        gej v; gej_load28(v, in28 + ((size_t)seg * seg_len + k) * 28);
+        gej s; gej_add_var(s, acc, v); acc = s;
+    }
+    gej_store28(sh + t * 28, acc);
+    __syncthreads();
+    for (u32 d = 128; d >= 1; d >>= 1) {
+        if (t < d) {
+            gej a, b, s; gej_load28(a, sh + t * 28); gej_load28(b, sh + (t + d) * 28);
+            gej_add_var(s, a, b);
+            gej_store28(sh + t * 28, s);
+        }
+        __syncthreads();
+    }
+    if (t == 0) for (int i = 0; i < 28; i++) out28[(size_t)blockIdx.x * 28 + i] = sh[i];
+}
+__global__ void k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
+    if (threadIdx.x || blockIdx.x) return;
+    gej r; msm_combine(r, wsum28, pl);
+    gej_store28(out28, r);
+}
+// small inputs: one full double-and-add per lane; lane n carries g_sc*G
+__global__ void __launch_bounds__(256, 2)
+k_msm_small(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
+            const u32* gtab, size_t n, size_t nt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int live = i < nt, isg = live && (i == n);
+    gej A; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
+    if (live && !isg) {
+        ge a; ge_load_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a);
+        A.inf = pt_inf ? (pt_inf[i] != 0) : 0;
+        sc_set_b32(k, sc + 32 * i, nullptr);
+    }
+    if (isg) sc_set_b32(g, g_sc, nullptr);
+    gej R; ecmult_lane(R, A, k, g, 1, gtab);
+    if (live) gej_store28(out28 + i * 28, R);
+}
+__global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in28) {
+    if (threadIdx.x || blockIdx.x) return;
+    gej r; gej_load28(r, in28);
+    ge a; ge_set_gej(a, r);
+    if (r.inf) { for (int k = 0; k < 64; k++) r_xy[k] = 0; } else ge_store_b64(r_xy, a);
+    *r_inf = r.inf;
+}
+
+// reduce `count` gej28 (one segment) down to one, ping-ponging between two scratch buffers; returns pointer to the result
+static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u32* bufB, u32 nseg, u32 seg_len) {
+    const u32* cur = in; u32* dst = bufA;
+    while (seg_len > 1) {
+        const u32 per_block = 1024, nchunks = (seg_len + per_block - 1) / per_block;
+        hipLaunchKernelGGL(k_gej_reduce, dim3(nseg * nchunks), dim3(256), 0, st, dst, cur, seg_len, per_block, nchunks);
+        cur = dst; dst = (dst == bufA) ? bufB : bufA; seg_len = nchunks;
+    }
+    return cur;
+}
+static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
+    const size_t nk = (size_t)pl.windows * pl.nb;
+    const size_t E = nt * 2 * pl.windows;
+    return ws_need({nt * MSM_TERM_WORDS * 4, E * 4, (nk + 1) * 4 * 7, E * 4, (nk + nt + 64) * 28 * 4, (nk + E / 8 + 2) * 28 * 4, (nk * 2 + E / 64 + 64) * 28 * 4,
+                    (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2, 64 * 28 * 4}) + 16 * 256;
+}
+// core: leaves the Jacobian result (28 words) at *result28 (device).  Workspace must already be large enough.
+static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
+                      const unsigned char* pt, const unsigned char* pt_inf, size_t n) {
+    const size_t nt = n + (g_sc ? 1 : 0);
+    u32* final28 = c.take<u32>(28);
+    *result28 = final28;
+    if (nt < MSM_SMALL_N) {
+        u32* lanes = c.take<u32>((nt + 1) * 28); u32* bufA = c.take<u32>(64 * 28); u32* bufB = c.take<u32>(64 * 28);
+        if (nt == 0) { HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st)); const u32 one = 1; HIPCHK(hipMemcpyAsync(final28 + 27, &one, 4, hipMemcpyHostToDevice, st)); return 1; }
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, lanes, g_sc, sc, pt, pt_inf, e->gtab, n, nt);
+        HIPCHK(hipEventRecord(e->ev[3], st));
+        const u32* r = launch_gej_reduce(st, lanes, bufA, bufB, 1, (u32)nt);
+        HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipGetLastError());
+        return 1;
+    }
+    const msm_plan pl = msm_make_plan(nt);
+    const u32 nk = pl.windows * pl.nb;
+    const size_t E = nt * 2 * pl.windows;                      // upper bound on bucket references
+    u32 T = (u32)(E / 262144); if (T < 8) T = 8; if (T > 64) T = 64;
+    int rounds = 1; { size_t cap = T; while (cap < E) { cap *= T; rounds++; } }
+    const size_t bound1 = (size_t)nk + E / T + 2;
+    u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* keys = c.take<u32>(E);
+    u32* hist = c.take<u32>(nk + 1); u32* off0 = c.take<u32>(nk + 1); u32* cur = c.take<u32>(nk + 1);
+    u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
+    u32* refs = c.take<u32>(E); u32* buckets = c.take<u32>((size_t)nk * 28);
+    u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / T + 64) * 28);
+    u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
+    HIPCHK(hipMemsetAsync(hist, 0, (nk + 1) * 4, st));
+    const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
+    hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, keys, hist, g_sc, sc, pt, pt_inf, n, nt, pl);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, off0, cur, hist, nk);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(bt), dim3(256), 0, st, refs, cur, keys, nt, pl);
+    // round 1: references -> partial sums (at most T references each)
+    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, hist, nk, T);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, offA, cur, cntA, nk);
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs, off0, offA, term, nk, T);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    // rounds 2..R: partial sums of partial sums until every bucket holds at most one
+    u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
+    size_t bound = bound1;
+    for (int r = 2; r <= rounds; r++) {
+        bound = (size_t)nk + bound / T + 2;
+        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, oout, cur, cout, nk);
+        hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T);
+        u32* t;
+        t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
+    }
+    hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl);
+    const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.windows, pl.nb);
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
+    HIPCHK(hipGetLastError());
+    return 1;
+}
+extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
+                                            const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    if (!e) return s2k_fail("s2k_ecmult_multi_partial_dev", "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t nt = n + (g_sc ? 1 : 0);
+    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    ws_carver c{e->ws, 0}; u32* res = nullptr;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
+    HIPCHK(hipMemcpyAsync(r_gej28, res, 28 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
+                                    const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    if (!e) return s2k_fail("s2k_ecmult_multi_dev", "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t nt = n + (g_sc ? 1 : 0);
+    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    ws_carver c{e->ws, 0}; u32* res = nullptr;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
+    hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, r_xy, r_inf, res);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count) {
+    if (!e) return s2k_fail("s2k_gej_sum_dev", "null engine");
+    if (count == 0) return s2k_fail("s2k_gej_sum_dev", "count == 0");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if (!engine_workspace(e, ws_need({(count / 1024 + 64) * 28 * 4, (count / 1024 + 64) * 28 * 4}))) return 0;
+    ws_carver c{e->ws, 0};
+    u32* bufA = c.take<u32>((count / 1024 + 64) * 28); u32* bufB = c.take<u32>((count / 1024 + 64) * 28);
+    const u32* r = launch_gej_reduce(st, gej28, bufA, bufB, 1, (u32)count);
+    hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, r_xy, r_inf, r);
+    HIPCHK(hipGetLastError());
+    return 1;
+}
+extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
+                                const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    if (!e) return s2k_fail("s2k_ecmult_multi", "null engine");
+    unsigned char *d_g = nullptr, *d_sc = nullptr, *d_pt = nullptr, *d_inf = nullptr, *d_r = nullptr; int32_t* d_ri = nullptr;
+    HIPCHK(hipSetDevice(e->device));
+    // inputs live outside the engine workspace (which the MSM passes re-carve)
+    HIPCHK(hipMalloc((void**)&d_sc, 32 * n + 64)); HIPCHK(hipMalloc((void**)&d_pt, 64 * n + 64)); HIPCHK(hipMalloc((void**)&d_inf, n + 64));
+    HIPCHK(hipMalloc((void**)&d_g, 64)); HIPCHK(hipMalloc((void**)&d_r, 64)); HIPCHK(hipMalloc((void**)&d_ri, 16));
+    int ok = 0;
+    do {
+        if (n && hipMemcpy(d_sc, sc, 32 * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (n && hipMemcpy(d_pt, pt_xy, 64 * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (n && pt_inf && hipMemcpy(d_inf, pt_inf, n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (g_sc && hipMemcpy(d_g, g_sc, 32, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (!s2k_ecmult_multi_dev(e, nullptr, d_r, d_ri, g_sc ? d_g : nullptr, d_sc, d_pt, pt_inf ? d_inf : nullptr, n)) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) break;
+        if (hipMemcpy(r_xy, d_r, 64, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(r_inf, d_ri, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
+        ok = 1;
+    } while (0);
+    hipFree(d_sc); hipFree(d_pt); hipFree(d_inf); hipFree(d_g); hipFree(d_r); hipFree(d_ri);
+    if (!ok && g_last_error.empty()) s2k_fail("s2k_ecmult_multi", "HIP copy failed");
+    return ok;
+}
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
-extern "C" int s2k_ecmult_multi(s2k_engine*, unsigned char*, int32_t*, const unsigned char*, const unsigned char*, const unsigned char*, const unsigned char*, size_t) { S2K_TODO("s2k_ecmult_multi"); }
-extern "C" int s2k_ecmult_multi_dev(s2k_engine*, void*, unsigned char*, int32_t*, const unsigned char*, const unsigned char*, const unsigned char*, const unsigned char*, size_t) { S2K_TODO("s2k_ecmult_multi_dev"); }
-extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine*, void*, uint32_t*, const unsigned char*, const unsigned char*, const unsigned char*, const unsigned char*, size_t) { S2K_TODO("s2k_ecmult_multi_partial_dev"); }
-extern "C" int s2k_gej_sum_dev(s2k_engine*, void*, unsigned char*, int32_t*, const uint32_t*, size_t) { S2K_TODO("s2k_gej_sum_dev"); }
 extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine*, int32_t*, const unsigned char*, size_t, const unsigned char*, const unsigned char*, const unsigned char*, size_t, size_t, const unsigned char*, size_t, const unsigned char*, size_t) { S2K_TODO("secp256k1_bppp_norm_product_verify_batch"); }

@@ -8,6 +8,7 @@
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
 #include "../../secp256k1_zkp_amd/csrc/schnorr.h"
+#include "../../secp256k1_zkp_amd/csrc/msm.h"
 #include <string.h>
 #include <vector>
 
@@ -113,5 +114,36 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
 int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, size_t msglen, const unsigned char* pk, int pk_format) {
     schnorr_midstate mid; schnorr_tag_midstate(mid);
     return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host());
+}
+
+// the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width)
+int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n, int force_c) {
+    const size_t nt = n + (g_sc ? 1 : 0);
+    msm_plan pl = msm_make_plan(nt ? nt : 1);
+    if (force_c > 0) { pl.c = force_c; pl.windows = (129 + pl.c - 1) / pl.c; pl.nb = (1u << (pl.c - 1)) + 1u; }
+    const size_t nk = (size_t)pl.windows * pl.nb;
+    std::vector<u32> term(nt * MSM_TERM_WORDS + 1), keys(nt * 2 * pl.windows + 1), hist(nk + 1, 0), off(nk + 1, 0), cur(nk + 1, 0), refs(nt * 2 * pl.windows + 1);
+    for (size_t i = 0; i < nt; i++) {
+        const int isg = (g_sc && i == n);
+        msm_prep(term.data() + i * MSM_TERM_WORDS, keys.data() + i * 2 * pl.windows, hist.data(), isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
+                 isg ? 0 : (inf ? inf[i] : 0), isg, pl);
+    }
+    for (size_t k = 0; k < nk; k++) off[k + 1] = off[k] + hist[k];
+    cur = off;
+    for (size_t i = 0; i < nt; i++) for (int half = 0; half < 2; half++) for (u32 w = 0; w < pl.windows; w++) {
+        const u32 key = keys[i * 2 * pl.windows + half * pl.windows + w];
+        if (key) refs[cur[key >> 1]++] = (u32)(i << 2) | (half << 1) | (key & 1);
+    }
+    std::vector<u32> wsum(pl.windows * 28);
+    for (u32 w = 0; w < pl.windows; w++) {
+        gej s; gej_set_infinity(s);
+        for (u32 b = 1; b < pl.nb; b++) {
+            gej v, o; msm_sum_refs(v, refs.data(), off[w * pl.nb + b], off[w * pl.nb + b + 1], term.data()); msm_scale(o, v, b);
+            gej t; gej_add_var(t, s, o); s = t;
+        }
+        gej_store28_h(wsum.data() + 28 * w, s);
+    }
+    gej r; msm_combine(r, wsum.data(), pl);
+    return gej_to_b64(r64, r);
 }
 }

@@ -53,7 +53,7 @@ class Ref:
 
     def ecmult_multi(self, sc, pt_xy, g_sc=None, pt_inf=None, algo=0):
         sc = np.ascontiguousarray(sc, np.uint8); pt_xy = np.ascontiguousarray(pt_xy, np.uint8); n = sc.size // 32
-        g = None if g_sc is None else np.ascontiguousarray(g_sc, np.uint8)
+        g = None if g_sc is None else (np.frombuffer(g_sc, np.uint8).copy() if isinstance(g_sc, (bytes, bytearray)) else np.ascontiguousarray(g_sc, np.uint8))
         pi = None if pt_inf is None else np.ascontiguousarray(pt_inf, np.uint8)
         r = np.zeros(64, np.uint8)
         inf = self.lib.ref_ecmult_multi(_p(r), _p(g), _p(sc), _p(pt_xy), _p(pi), ctypes.c_size_t(n), ctypes.c_int(algo))
