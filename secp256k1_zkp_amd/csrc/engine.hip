@@ -9,6 +9,7 @@
 #include "rangeproof.h"
 #include "schnorr.h"
 #include "msm.h"
+#include "bppp.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -674,7 +675,88 @@ extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
     if (!ok && g_last_error.empty()) s2k_fail("s2k_ecmult_multi", "HIP copy failed");
     return ok;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Bulletproofs++ norm-argument batch verification (bppp.h)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_bp_gens(u32* gens18, int* gens_ok, const unsigned char* gens33, u32 n_gens) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_gens) return;
+    ge p; const int ok = bp_parse33(p, gens33 + 33 * i);
+    fe_norm_weak(p.x); fe_norm_weak(p.y);
+    for (int k = 0; k < 9; k++) { gens18[18 * i + k] = p.x.n[k]; gens18[18 * i + 9 + k] = p.y.n[k]; }
+    if (!ok) atomicAnd(gens_ok, 0);
+}
+__global__ void __launch_bounds__(64)
+k_bp_prologue(u32* term_sc, int* proof_ok, bp_shape sh, const unsigned char* proofs, size_t proof_len, const unsigned char* transcripts,
+              const unsigned char* rho, const unsigned char* c_vec, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    proof_ok[p] = bp_prologue(term_sc + p * sh.n_terms * 8, sh, proofs + p * proof_len, transcripts + p * 104, rho + 32 * p, c_vec + p * sh.h_len * 32);
+}
+__global__ void __launch_bounds__(256, 2)
+k_bp_terms(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* gens18, const unsigned char* proofs,
+           size_t proof_len, const unsigned char* commits33, const u32* gtab, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t p = t / sh.n_terms; const u32 ti = (u32)(t % sh.n_terms);
+    int live = p < n;
+    if (!live) p = 0;
+    live &= proof_ok[p];
+    gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab);
+    if (t < n * sh.n_terms) { gej_store28(out28 + t * 28, o); term_ok[t] = (unsigned char)ok; }
+}
+__global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int ok = proof_ok[p] & *gens_ok;
+    for (u32 t = 0; t < n_terms; t++) ok &= term_ok[p * n_terms + t];
+    ok &= (int)sums28[p * 28 + 27];            // res2 - res1 must be the point at infinity (gej_eq_var, :551)
+    results[p] = ok;
+}
+extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
+                                                        const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
+                                                        size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
+                                                        const unsigned char* commits33, size_t n) {
+    if (!e) return s2k_fail("secp256k1_bppp_norm_product_verify_batch", "null engine");
+    if (n == 0) return 1;
+    bp_shape sh;
+    if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { for (size_t i = 0; i < n; i++) results[i] = 0; return 1; }   // :446-461
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t T = sh.n_terms, nt = n * T;
+    const size_t need = ws_need({4 * n, n * proof_len + 64, 104 * n, 32 * n, 33 * n_gens, 32 * c_vec_len * n, 33 * n, n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n,
+                                 nt * 28 * 4, nt + 64, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4});
+    if (!engine_workspace(e, need)) return 0;
+    ws_carver c{e->ws, 0};
+    int32_t* d_res = c.take<int32_t>(n); unsigned char* d_pr = c.take<unsigned char>(n * proof_len + 64); unsigned char* d_tr = c.take<unsigned char>(104 * n);
+    unsigned char* d_rho = c.take<unsigned char>(32 * n); unsigned char* d_g33 = c.take<unsigned char>(33 * n_gens);
+    unsigned char* d_cv = c.take<unsigned char>(32 * c_vec_len * n); unsigned char* d_cm = c.take<unsigned char>(33 * n);
+    u32* gens18 = c.take<u32>(n_gens * 18); int* gens_ok = c.take<int>(16); u32* term_sc = c.take<u32>(nt * 8); int* proof_ok = c.take<int>(n);
+    u32* out28 = c.take<u32>(nt * 28); unsigned char* term_ok = c.take<unsigned char>(nt + 64);
+    u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(d_pr, proofs, n * proof_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_tr, transcripts, 104 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rho, rho, 32 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_g33, gens33, 33 * n_gens, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cv, c_vec, 32 * c_vec_len * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cm, commits33, 33 * n, hipMemcpyHostToDevice, st));
+    const int one = 1;
+    HIPCHK(hipMemcpyAsync(gens_ok, &one, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
+    hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm, e->gtab, n);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);
+    hipLaunchKernelGGL(k_bp_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_res, sums, proof_ok, term_ok, gens_ok, (u32)T, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
-extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine*, int32_t*, const unsigned char*, size_t, const unsigned char*, const unsigned char*, const unsigned char*, size_t, size_t, const unsigned char*, size_t, const unsigned char*, size_t) { S2K_TODO("secp256k1_bppp_norm_product_verify_batch"); }

@@ -9,6 +9,7 @@
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
 #include "../../secp256k1_zkp_amd/csrc/schnorr.h"
 #include "../../secp256k1_zkp_amd/csrc/msm.h"
+#include "../../secp256k1_zkp_amd/csrc/bppp.h"
 #include <string.h>
 #include <vector>
 
@@ -145,5 +146,23 @@ int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* 
     }
     gej r; msm_combine(r, wsum.data(), pl);
     return gej_to_b64(r64, r);
+}
+
+int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned char* transcript104, const unsigned char* rho32, const unsigned char* gens33,
+                    size_t n_gens, size_t g_len, const unsigned char* c_vec32, size_t c_len, const unsigned char* commit33) {
+    bp_shape sh;
+    if (!bp_make_shape(sh, g_len, c_len, n_gens, proof_len)) return 0;
+    std::vector<u32> gens18(n_gens * 18), term_sc(sh.n_terms * 8);
+    int ok = 1;
+    for (size_t i = 0; i < n_gens; i++) { ge p; ok &= bp_parse33(p, gens33 + 33 * i); fe_norm_weak(p.x); fe_norm_weak(p.y);
+        for (int k = 0; k < 9; k++) { gens18[18 * i + k] = p.x.n[k]; gens18[18 * i + 9 + k] = p.y.n[k]; } }
+    ok &= bp_prologue(term_sc.data(), sh, proof, transcript104, rho32, c_vec32);
+    if (!ok) return 0;
+    gej sum; gej_set_infinity(sum);
+    for (u32 t = 0; t < sh.n_terms; t++) {
+        gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host());
+        gej s; gej_add_var(s, sum, o); sum = s;
+    }
+    return ok & sum.inf;
 }
 }

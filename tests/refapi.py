@@ -105,3 +105,42 @@ class Ref:
         self.lib.ref_schnorrsig_verify_many(_p(res), _p(np.ascontiguousarray(sigs)), _p(np.ascontiguousarray(msgs)), ctypes.c_size_t(msglen),
                                             _p(np.ascontiguousarray(pks)), ctypes.c_size_t(n), ctypes.c_int(threads))
         return res
+
+    # --- bppp norm argument (test-side flow of modules/bppp/tests_impl.h:385-435)
+    def bppp_generators(self, n):
+        out = np.zeros((n, 33), np.uint8)
+        assert self.lib.ref_bppp_generators(_p(out), ctypes.c_size_t(n)) == 1
+        return out
+
+    def make_bppp(self, n, rng, g_len, h_len):
+        """n norm-argument proofs over the deterministic generator set; returns the batch-API argument tuple."""
+        gens = self.bppp_generators(g_len + h_len)
+        sc = lambda k: (rng.integers(0, 256, (k, 32), dtype=np.uint8) & np.array([0x7F] + [0xFF] * 31, np.uint8))
+        nr = max(int(np.log2(g_len)), int(np.log2(h_len)))
+        plen = 65 * nr + 64
+        proofs = np.zeros((n, plen), np.uint8); trs = np.zeros((n, 104), np.uint8); rhos = sc(n)
+        cvs = np.zeros((n, h_len, 32), np.uint8); commits = np.zeros((n, 33), np.uint8)
+        for i in range(n):
+            nv, lv, cv = sc(g_len), sc(h_len), sc(h_len)
+            mu = np.zeros(32, np.uint8)
+            self.lib.ref_scalar_mul(_p(mu), _p(rhos[i]), _p(rhos[i]))
+            cm = np.zeros(33, np.uint8)
+            assert self.lib.ref_bppp_commit(_p(cm), _p(gens), ctypes.c_size_t(g_len + h_len), _p(nv), ctypes.c_size_t(g_len), _p(lv), _p(cv),
+                                            ctypes.c_size_t(h_len), _p(mu)) == 1
+            tr = np.zeros(104, np.uint8)
+            self.lib.ref_bppp_transcript_init(_p(tr), _p(rhos[i]), _p(gens), ctypes.c_size_t(g_len + h_len), ctypes.c_size_t(g_len), _p(cv),
+                                              ctypes.c_size_t(h_len), _p(cm))
+            pl = ctypes.c_size_t(plen); pr = np.zeros(plen, np.uint8)
+            assert self.lib.ref_bppp_norm_prove(_p(pr), ctypes.byref(pl), _p(tr), _p(rhos[i]), _p(gens), ctypes.c_size_t(g_len + h_len), _p(nv),
+                                                ctypes.c_size_t(g_len), _p(lv), _p(cv), ctypes.c_size_t(h_len)) == 1
+            assert pl.value == plen
+            proofs[i] = pr; trs[i] = tr; cvs[i] = cv; commits[i] = cm
+        return proofs, trs, rhos, gens, g_len, cvs, commits
+
+    def bppp_verify_many(self, proofs, trs, rhos, gens, g_len, cvs, commits):
+        n = rhos.shape[0]; h_len = cvs.shape[1]; res = np.zeros(n, np.int32)
+        for i in range(n):
+            res[i] = self.lib.ref_bppp_norm_verify(_p(np.ascontiguousarray(proofs[i])), ctypes.c_size_t(proofs.shape[1]), _p(np.ascontiguousarray(trs[i])),
+                                                   _p(np.ascontiguousarray(rhos[i])), _p(gens), ctypes.c_size_t(gens.shape[0]), ctypes.c_size_t(g_len),
+                                                   _p(np.ascontiguousarray(cvs[i])), ctypes.c_size_t(h_len), _p(np.ascontiguousarray(commits[i])))
+        return res

@@ -1,0 +1,47 @@
+"""GPU parity: secp256k1_bppp_norm_product_verify_batch vs the reference's (static) secp256k1_bppp_rangeproof_norm_product_verify:
+the 13 accept/reject vectors of src/modules/bppp/test_vectors/verify.h, and freshly proven arguments (reference prover) of the
+sizes BASELINE config 4 names (g_len 64, h_len 8) and the tested maximum (64/64), with mutations."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SHA256_INIT_STATE = (np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], "<u4").tobytes()
+                     + b"\0" * 64 + b"\0" * 8)      # secp256k1_sha256_initialize(): the transcript the vector driver uses (tests_impl.h:550)
+
+
+def test_verify_vectors(engine):
+    g = json.load(open(os.path.join(HERE, "golden", "bppp_verify_vectors.json")))
+    gens = np.frombuffer(bytes.fromhex(g["gens"]), np.uint8)
+    tr = np.frombuffer(SHA256_INIT_STATE, np.uint8)
+    for v in g["vectors"]:
+        proof = np.frombuffer(bytes.fromhex(v["proof"]), np.uint8)
+        cvec = np.frombuffer(b"".join(bytes.fromhex(c) for c in v["c_vec"]), np.uint8)
+        nlen, clen = v["n_vec_len"], len(v["c_vec"])
+        res = engine.bppp_norm_product_verify_batch(proof, tr, np.frombuffer(bytes.fromhex(v["rho"]), np.uint8), gens[:33 * (nlen + clen)], nlen, cvec,
+                                                    np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8))
+        assert res[0] == v["result"], v["index"]
+
+
+@pytest.mark.parametrize("g_len,h_len,n", [(64, 8, 24), (64, 64, 8), (1, 1, 4), (2, 16, 4), (8, 1, 4)])
+def test_random_proofs(engine, ref, g_len, h_len, n):
+    rng = np.random.default_rng(g_len * 100 + h_len)
+    proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(n, rng, g_len, h_len)
+    # mutate a third: proof bytes, rho, c_vec, commitment
+    proofs = proofs.copy(); rhos = rhos.copy(); cvs = cvs.copy(); commits = commits.copy()
+    for i in range(n):
+        if i % 3 == 1:
+            k = i // 3 % 4
+            if k == 0: proofs[i, int(rng.integers(0, proofs.shape[1]))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 1: rhos[i, 31] ^= 1
+            elif k == 2: cvs[i, 0, 31] ^= 1
+            else: commits[i, 5] ^= 1
+    exp = ref.bppp_verify_many(proofs, trs, rhos, gens, gl, cvs, commits)
+    res = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits)
+    assert np.array_equal(res, exp)
+    assert exp[0] == 1 and exp.sum() < n
