@@ -1,0 +1,80 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+Two shapes, as SURVEY.md section 8e lays out:
+  * batches of independent proofs / signatures: replicas -- `shard_range` splits the item index range, no exchange step,
+    the caller concatenates per-rank result arrays (`gather_results`);
+  * one large multi-scalar multiplication: term sharding -- every rank runs a complete bucket MSM on its slice of the terms
+    and emits ONE Jacobian partial (28 uint32: x, y, z limbs + infinity flag).  EC addition is not an RCCL reduction
+    operator, so the collective is an all-gather of the raw limb buffers followed by a local tree sum
+    (`s2k_gej_sum_dev`).  Payload: world_size x 112 bytes -- latency, not bandwidth, is what it costs.
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """contiguous [lo, hi) slice of n items for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
+    """r = g_sc*G + sum sc_i*pt_i with the terms sharded over the ranks of `group`.
+
+    `backend` provides  msm_partial(sc, pt_xy, g_sc, pt_inf) -> torch uint32[28] (on its device)  and
+    gej_sum(parts uint32[world,28]) -> (xy bytes[64], inf).  On a GPU rank that is `EngineBackend(engine)`.
+    Every rank passes the full input (already resident); each computes only its slice.  Returns (xy, inf) on all ranks."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
+    lo, hi = shard_range(n, rank, world)
+    part = backend.msm_partial(sc[lo:hi], pt_xy[lo:hi], g_sc if rank == 0 else None, None if pt_inf is None else pt_inf[lo:hi])
+    if world == 1:
+        parts = part.reshape(1, 28)
+    else:
+        bufs = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(bufs, part, group=group)
+        parts = torch.stack(bufs)
+    return backend.gej_sum(parts)
+
+
+def gather_results(local, n_total, group=None):
+    """concatenate per-rank result arrays of a replica-sharded batch (rank order = index order)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    maxlen = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(maxlen, dtype=local.dtype, device=local.device); pad[: local.numel()] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)])
+
+
+class EngineBackend:
+    """adapter: Engine (HIP) -> the backend interface of msm_sharded; tensors live in HBM of the engine's GPU."""
+
+    def __init__(self, engine):
+        import torch
+        self.engine = engine
+        self.dev = torch.device("cuda", engine.device)
+
+    def msm_partial(self, sc, pt_xy, g_sc, pt_inf):
+        import torch
+        out = torch.zeros(28, dtype=torch.int32, device=self.dev)
+        if sc.numel() == 0 and g_sc is None:
+            out[27] = 1
+            return out
+        self.engine.ecmult_multi_partial_dev(out, sc.contiguous(), pt_xy.contiguous(), g_sc, pt_inf, stream=torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def gej_sum(self, parts):
+        import torch
+        r = torch.zeros(64, dtype=torch.uint8, device=self.dev); inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.engine.gej_sum_dev(r, inf, parts.contiguous(), parts.shape[0], stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return r.cpu().numpy(), int(inf.item())

@@ -165,4 +165,22 @@ int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned
     }
     return ok & sum.inf;
 }
+
+// multi-GPU path pieces for the gloo test: a shard's Jacobian partial (28 words) and the final sum of gathered partials
+void emu_msm_partial(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n) {
+    gej acc; gej_set_infinity(acc);
+    for (size_t i = 0; i < n + (g_sc ? 1 : 0); i++) {
+        gej A, R; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
+        if (i < n) { ge a; ge_from_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a); A.inf = inf ? inf[i] : 0; sc_set_b32(k, sc + 32 * i, 0); }
+        else sc_set_b32(g, g_sc, 0);
+        ecmult_lane(R, A, k, g, 1, gtab_host());
+        gej s; gej_add_var(s, acc, R); acc = s;
+    }
+    gej_store28_h(out28, acc);
+}
+int emu_gej_sum(unsigned char* r64, const u32* gej28, size_t count) {
+    gej acc; gej_set_infinity(acc);
+    for (size_t i = 0; i < count; i++) { gej v, s; gej_load28_h(v, gej28 + 28 * i); gej_add_var(s, acc, v); acc = s; }
+    return gej_to_b64(r64, acc);
+}
 }

@@ -1,0 +1,212 @@
+"""CPU tier (-m "not gpu").  (1) pins the oracle: oracle/_ref (the unmodified reference) must reproduce every golden vector
+extracted from the reference's own tests; (2) runs the per-lane *device* arithmetic compiled for the host with S2K_VERIFY on
+(tests/host_emul) against the oracle: field / scalar / group / ecmult primitives, the five rangeproof stages, BIP-340, the
+bucket MSM and the BP++ norm argument; (3) checks the C ABI: the product library loads and exports every symbol declared in
+include/secp256k1_zkp_amd.h, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.refapi import GENERATOR_H, G_XY, N, P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    path = os.path.join(HERE, "host_emul", "libs2k_hostemu.so")
+    if not os.path.exists(path):
+        pytest.skip("host emulation library not built (run __graft_entry__.build())")
+    return ctypes.CDLL(path)
+
+
+def _b(v):
+    return int(v).to_bytes(32, "big")
+
+
+def _golden(name):
+    return json.load(open(os.path.join(HERE, "golden", name)))
+
+
+# ---- (1) the oracle reproduces the reference's own known answers ------------------------------------------------------
+def test_ref_rangeproof_golden(ref):
+    vecs = _golden("rangeproof_vectors.json")["vectors"]
+    n = len(vecs)
+    commits = np.stack([np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8) for v in vecs])
+    gens = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64)
+    res, mn, mx = ref.rangeproof_verify_many(commits, [bytes.fromhex(v["proof"]) for v in vecs], gens)
+    for i, v in enumerate(vecs):
+        assert res[i] == v["result"] and int(mn[i]) == int(v["min_value"]) and int(mx[i]) == int(v["max_value"]), v["name"]
+
+
+def test_ref_bip340_golden(ref):
+    vecs = _golden("bip340_vectors.json")["vectors"]
+    for v in vecs:
+        msg = bytes.fromhex(v["msg"])
+        r = ref.schnorr_verify_many(np.frombuffer(bytes.fromhex(v["sig"]), np.uint8), np.frombuffer(msg, np.uint8) if msg else np.zeros(1, np.uint8),
+                                    np.frombuffer(bytes.fromhex(v["pk"]), np.uint8), msglen=len(msg))
+        assert r[0] == v["result"]
+
+
+def test_ref_bppp_golden(ref):
+    g = _golden("bppp_verify_vectors.json")
+    gens = bytes.fromhex(g["gens"])
+    st = ctypes.create_string_buffer(104)
+    assert ref.lib.ref_sha256_state_size() == 104
+    ref.lib.ref_sha256_state_from_prefix(st, b"", ctypes.c_size_t(0))
+    for v in g["vectors"]:
+        proof = bytes.fromhex(v["proof"]); cvec = b"".join(bytes.fromhex(c) for c in v["c_vec"]); nlen = v["n_vec_len"]; clen = len(v["c_vec"])
+        r = ref.lib.ref_bppp_norm_verify(proof, ctypes.c_size_t(len(proof)), st.raw, bytes.fromhex(v["rho"]), gens[:33 * (nlen + clen)],
+                                         ctypes.c_size_t(nlen + clen), ctypes.c_size_t(nlen), cvec, ctypes.c_size_t(clen), bytes.fromhex(v["commit33"]))
+        assert r == v["result"], v["index"]
+
+
+# ---- (2) device arithmetic, host-compiled with magnitude checks, vs the oracle -----------------------------------------------
+def _call(lib, name, nout, *args):
+    outs = [ctypes.create_string_buffer(n) for n in nout]
+    r = getattr(lib, name)(*outs, *args)
+    return r, [o.raw for o in outs]
+
+
+def test_emu_field_scalar(emu, ref):
+    rng = np.random.default_rng(7)
+    edge = [0, 1, 2, P - 1, P - 2, P, P + 1, 2**256 - 1, 2**255, 977, 2**32 + 977, N, N - 1, N + 1, (P + 1) // 2, 2**232, 2**256 - 2**32]
+    cs = [_b(e % 2**256) for e in edge] + [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(200)]
+    for i in range(len(cs)):
+        a, c = cs[i], cs[(i * 7 + 3) % len(cs)]
+        for name, args in (("fe_mul", (a, c)), ("fe_sqr", (a,)), ("fe_add", (a, c)), ("fe_negate", (a,)), ("fe_inv", (a,)), ("fe_sqrt", (a,)),
+                           ("scalar_mul", (a, c)), ("scalar_add", (a, c)), ("scalar_negate", (a,)), ("scalar_set_b32", (a,))):
+            r1, o1 = _call(ref.lib, "ref_" + name, [32], *args); r2, o2 = _call(emu, "emu_" + name, [32], *args)
+            assert o1 == o2, name
+            if name in ("fe_sqrt", "scalar_set_b32"):
+                assert r1 == r2, name
+        assert _call(ref.lib, "ref_scalar_split_lambda", [32, 32], a)[1] == _call(emu, "emu_scalar_split_lambda", [32, 32], a)[1]
+        if i < 30:
+            assert _call(ref.lib, "ref_scalar_inverse", [32], a)[1] == _call(emu, "emu_scalar_inverse", [32], a)[1]
+
+
+def test_emu_group_ecmult(emu, ref):
+    rng = np.random.default_rng(8)
+    pts = [ref.rand_point(rng) for _ in range(12)] + [G_XY]
+    neg = lambda p: p[:32] + _b((P - int.from_bytes(p[32:], "big")) % P)
+    for i, a in enumerate(pts):
+        for c in (pts[(i + 1) % len(pts)], a, neg(a)):
+            for ai in (0, 1):
+                for bi in (0, 1):
+                    e1 = _call(ref.lib, "ref_ge_add", [64], a, ai, c, bi)
+                    assert e1 == _call(emu, "emu_ge_add", [64], a, ai, c, bi)
+                    za, zb = bytes(rng.integers(0, 256, 32, dtype=np.uint8)), bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+                    assert e1 == _call(emu, "emu_gej_add_var", [64], a, ai, c, bi, za, zb)
+        assert _call(ref.lib, "ref_ge_double", [64], a, 0) == _call(emu, "emu_ge_double", [64], a, 0)
+    sc_edge = [_b(v) for v in (0, 1, 2, 3, N - 1, N - 2, 255, 256, 257, 2**128, 2**128 - 1, N // 2, N // 2 + 1)]
+    cases = []
+    for i in range(40):
+        na = bytes(rng.integers(0, 256, 32, dtype=np.uint8)) if i % 3 else sc_edge[i % len(sc_edge)]
+        ng = bytes(rng.integers(0, 256, 32, dtype=np.uint8)) if i % 4 else sc_edge[(i * 5) % len(sc_edge)]
+        cases.append((pts[i % len(pts)], 0, na, ng))
+    for sa in (1, 2, 3, 255, 256):          # accumulator meets table points: P+P / P-P inside the loop
+        for sg in (1, 2, 255, 256, N - 1, N - 2):
+            cases.append((G_XY, 0, _b(sa), _b(sg))); cases.append((neg(G_XY), 0, _b(sa), _b(sg)))
+    cases += [(G_XY, 1, _b(5), _b(7)), (G_XY, 0, _b(0), _b(0)), (G_XY, 0, _b(5), None), (pts[0], 0, sc_edge[4], None)]
+    for (a, ai, na, ng) in cases:
+        e1 = _call(ref.lib, "ref_ecmult", [64], a, ai, na, ng)
+        for z in (None, bytes(rng.integers(0, 256, 32, dtype=np.uint8))):
+            assert e1 == _call(emu, "emu_ecmult", [64], a, ai, na, ng, z)
+
+
+def _emu_rp(emu, c, p, g, extra=b""):
+    mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0)
+    r = emu.emu_rangeproof_verify(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)), g.tobytes())
+    return r, mn.value, mx.value
+
+
+def test_emu_rangeproof(emu, ref):
+    rng = np.random.default_rng(3)
+    vecs = _golden("rangeproof_vectors.json")["vectors"]
+    gh = np.frombuffer(GENERATOR_H, np.uint8)
+    for v in vecs:
+        r = _emu_rp(emu, np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8), bytes.fromhex(v["proof"]), gh)
+        assert r == (v["result"], int(v["min_value"]), int(v["max_value"])), v["name"]
+    for (mb, exp, minv, n) in ((64, 0, 0, 1), (5, 2, 17, 1), (1, 0, 0, 1), (13, 3, 1000, 1)):
+        commits, plist, gens, _ = ref.make_rangeproofs(n, rng, min_bits=mb, exp=exp, min_value=minv)
+        res, mn, mx = ref.rangeproof_verify_many(commits, plist, gens)
+        assert _emu_rp(emu, commits[0], plist[0], gens[0]) == (res[0], mn[0], mx[0]) and res[0] == 1
+        for k in range(4):
+            p = bytearray(plist[0]); p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8)); p = bytes(p)
+            if k == 2: p = plist[0] + b"\x00"
+            if k == 3: p = plist[0][:-1]
+            rr, rmn, rmx = ref.rangeproof_verify_many(commits[:1], [p], gens[:1])
+            assert _emu_rp(emu, commits[0], p, gens[0]) == (rr[0], rmn[0], rmx[0])
+
+
+def test_emu_schnorr(emu, ref):
+    for v in _golden("bip340_vectors.json")["vectors"]:
+        msg = bytes.fromhex(v["msg"])
+        assert emu.emu_schnorr_verify(bytes.fromhex(v["sig"]), msg, ctypes.c_size_t(len(msg)), bytes.fromhex(v["pk"]), 0) == v["result"]
+    rng = np.random.default_rng(5)
+    sigs, msgs, pks = ref.make_schnorr(24, rng, threads=4)
+    sigs[::5, 40] ^= 1; sigs[1::7, 3] ^= 0x80; pks[2::9, 5] ^= 1
+    exp = ref.schnorr_verify_many(sigs, msgs, pks)
+    got = [emu.emu_schnorr_verify(sigs[i].tobytes(), msgs[i].tobytes(), ctypes.c_size_t(32), pks[i].tobytes(), 0) for i in range(24)]
+    assert list(exp) == got
+
+
+def test_emu_msm(emu, ref):
+    rng = np.random.default_rng(9)
+    pts = [ref.rand_point(rng) for _ in range(32)]
+    for (n, g, c) in ((1, 0, 0), (1, 1, 0), (2, 1, 0), (5, 0, 4), (17, 1, 5), (100, 1, 0), (300, 1, 6), (600, 0, 0)):
+        Pn = np.frombuffer(b"".join(pts[i % 32] for i in range(n)), np.uint8).reshape(n, 64)
+        S = rng.integers(0, 256, (n, 32), dtype=np.uint8); inf = np.zeros(n, np.uint8)
+        if n > 3:
+            S[1] = 0; inf[2] = 1
+        gs = bytes(rng.integers(0, 256, 32, dtype=np.uint8)) if g else None
+        r1, i1 = ref.ecmult_multi(S, Pn, gs, inf)
+        out = ctypes.create_string_buffer(64)
+        i2 = emu.emu_msm(out, gs, S.tobytes(), Pn.tobytes(), inf.tobytes(), ctypes.c_size_t(n), c)
+        assert i1 == i2 and r1.tobytes() == out.raw, (n, g, c)
+
+
+def test_emu_bppp(emu, ref):
+    g = _golden("bppp_verify_vectors.json")
+    gens = bytes.fromhex(g["gens"])
+    st = ctypes.create_string_buffer(104); ref.lib.ref_sha256_state_from_prefix(st, b"", ctypes.c_size_t(0))
+    for v in g["vectors"]:
+        proof = bytes.fromhex(v["proof"]); cvec = b"".join(bytes.fromhex(c) for c in v["c_vec"]); nlen = v["n_vec_len"]; clen = len(v["c_vec"])
+        r = emu.emu_bppp_verify(proof, ctypes.c_size_t(len(proof)), st.raw, bytes.fromhex(v["rho"]), gens[:33 * (nlen + clen)], ctypes.c_size_t(nlen + clen),
+                                ctypes.c_size_t(nlen), cvec, ctypes.c_size_t(clen), bytes.fromhex(v["commit33"]))
+        assert r == v["result"], v["index"]
+    rng = np.random.default_rng(10)
+    proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(3, rng, 8, 2)
+    proofs = proofs.copy(); proofs[1, 7] ^= 4
+    exp = ref.bppp_verify_many(proofs, trs, rhos, gens, gl, cvs, commits)
+    for i in range(3):
+        r = emu.emu_bppp_verify(proofs[i].tobytes(), ctypes.c_size_t(proofs.shape[1]), trs[i].tobytes(), rhos[i].tobytes(), gens.tobytes(), ctypes.c_size_t(gens.shape[0]),
+                                ctypes.c_size_t(gl), cvs[i].tobytes(), ctypes.c_size_t(cvs.shape[1]), commits[i].tobytes())
+        assert r == exp[i]
+    assert list(exp) == [1, 0, 1]
+
+
+# ---- (3) the C ABI ---------------------------------------------------------------------------------------------------------
+def test_abi_symbols_and_loud_failure():
+    from secp256k1_zkp_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        pytest.skip("product library not built")
+    lib = _native.load()
+    hdr = open(os.path.join(ROOT, "include", "secp256k1_zkp_amd.h")).read()
+    declared = set(re.findall(r"S2K_API\s+[\w\s\*]+?\b(\w+)\s*\(", hdr))
+    assert declared, "no S2K_API declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    import torch
+    if not torch.cuda.is_available():
+        # no device: creating an engine must fail with a message, and nothing may silently compute on the CPU
+        from secp256k1_zkp_amd import Engine, S2KError
+        with pytest.raises(S2KError):
+            Engine(0)
+        assert "HIP" in _native.last_error() or "device" in _native.last_error()

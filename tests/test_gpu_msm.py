@@ -68,3 +68,22 @@ def test_bench_ecmult_config1(engine, ref):
     exp, einf = ref.ecmult_multi(sc, pts, gsc, None, algo=2)       # reference's pippenger_batch_single
     got, ginf = engine.ecmult_multi(sc, pts, gsc, None)
     assert ginf == einf and np.array_equal(got, exp)
+
+
+def test_sharded_path_single_rank(engine, ref):
+    """parallel.msm_sharded with world_size 1 on the GPU (partial -> gej_sum) equals the direct call and the reference."""
+    import torch
+    from secp256k1_zkp_amd import parallel
+    rng = np.random.default_rng(4)
+    n = 3000
+    pts = _points(engine, rng, n); sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); g = rng.integers(0, 256, 32, dtype=np.uint8)
+    exp, einf = ref.ecmult_multi(sc, pts, g.tobytes(), None)
+    be = parallel.EngineBackend(engine)
+    xy, inf = parallel.msm_sharded(be, torch.tensor(sc).cuda(), torch.tensor(pts).cuda(), torch.tensor(g).cuda())
+    assert inf == einf and np.array_equal(xy, exp)
+    # two "ranks" by hand: partials of the two halves, gathered and summed
+    h = n // 2
+    p0 = be.msm_partial(torch.tensor(sc[:h]).cuda(), torch.tensor(pts[:h]).cuda(), torch.tensor(g).cuda(), None)
+    p1 = be.msm_partial(torch.tensor(sc[h:]).cuda(), torch.tensor(pts[h:]).cuda(), None, None)
+    xy, inf = be.gej_sum(torch.stack([p0, p1]))
+    assert inf == einf and np.array_equal(xy, exp)
