@@ -59,10 +59,34 @@ def usable_cores():
     return n
 
 
+def cpu_baseline_port(commits, proofs, gens):
+    """fallback when oracle/_ref did not travel: the plain-C restatement (oracle/zkp_oracle.c), kind = "port"."""
+    import ctypes
+    path = os.path.join(ROOT, "oracle", "libzkp_oracle.so")
+    if not os.path.exists(path):
+        return None
+    zo = ctypes.CDLL(path)
+    cores = usable_cores()
+    kn = min(len(proofs), 64 * cores)
+    stride = max(len(p) for p in proofs[:kn])
+    buf = np.zeros((kn, stride), np.uint8)
+    for i in range(kn):
+        buf[i, :len(proofs[i])] = np.frombuffer(proofs[i], np.uint8)
+    plens = np.array([len(p) for p in proofs[:kn]], np.uint64)
+    res = np.zeros(kn, np.int32); mn = np.zeros(kn, np.uint64); mx = np.zeros(kn, np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    c = np.ascontiguousarray(commits[:kn]); g = np.ascontiguousarray(gens[:kn])
+    t = time.time()
+    zo.zo_rangeproof_verify_many(vp(res), vp(mn), vp(mx), vp(c), vp(buf), ctypes.c_size_t(stride), vp(plens), vp(g), ctypes.c_size_t(kn), ctypes.c_int(cores))
+    dt = time.time() - t
+    assert res.all()
+    return {"value": kn / dt, "unit": "verifies/s", "cores": cores, "kind": "port", "sample": "%d 64-bit proofs on %d threads (%.2f s), oracle/zkp_oracle.c" % (kn, cores, dt)}
+
+
 def cpu_baseline(ref, commits, proofs, gens):
     """the reference's secp256k1_rangeproof_verify on host cores, bounded sample (~10-20 s of CPU work)."""
     if ref is None:
-        return None
+        return cpu_baseline_port(commits, proofs, gens)
     cores = usable_cores()
     k1 = min(256, len(proofs))
     t = time.time(); r, _, _ = ref.rangeproof_verify_many(commits[:k1], proofs[:k1], gens[:k1], threads=1); t1 = time.time() - t

@@ -41,4 +41,18 @@ def run():
         r2, inf2 = ref.ecmult_batch(a, na, ng)
         assert np.array_equal(r, r2) and np.array_equal(inf, inf2)
         print("smoke: 64 double multiplications bit-exact vs oracle/_ref")
+    else:
+        import ctypes
+        zpath = os.path.join(os.path.dirname(HERE), "oracle", "libzkp_oracle.so")
+        if os.path.exists(zpath):
+            zo = ctypes.CDLL(zpath)
+            rng = np.random.default_rng(1)
+            k = 16
+            a = np.frombuffer(G_XY * k, np.uint8).reshape(k, 64)
+            na = rng.integers(0, 256, (k, 32), dtype=np.uint8); ng = rng.integers(0, 256, (k, 32), dtype=np.uint8)
+            r, inf = eng.ecmult_batch(a, na, ng)
+            for i in range(k):
+                out = ctypes.create_string_buffer(64)
+                assert zo.zo_ecmult(out, a[i].tobytes(), 0, na[i].tobytes(), ng[i].tobytes()) == inf[i] and out.raw == r[i].tobytes()
+            print("smoke: 16 double multiplications bit-exact vs oracle/zkp_oracle.c")
     eng.close()
