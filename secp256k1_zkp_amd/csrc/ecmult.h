@@ -1,21 +1,23 @@
 // ecmult.h -- per-lane double multiplication  R = na*A + ng*G  (the reference's secp256k1_ecmult,
 // src/ecmult_impl.h:365-375 -> strauss_wnaf :252-363) re-designed for a 64-wide SIMT machine.
 //
-// The reference interleaves wNAF(5) of the GLV halves of na with wNAF(15) of ng and walks 129 doublings; its
-// per-call table (8 odd multiples + lambda copies) lives on the CPU stack.  On gfx950 a per-lane table cannot be
-// indexed in registers and a sparse wNAF wastes lanes (an add slot costs the whole wavefront whenever *any* lane
-// has a digit), so the schedule here is:
+// The reference interleaves wNAF(5) of the GLV halves of na with wNAF(15) of ng and walks 129 doublings; its per-call
+// table (8 odd multiples + lambda copies) lives on the CPU stack.  On gfx950 a sparse wNAF wastes lanes -- an add slot
+// costs the whole wavefront whenever ANY lane has a digit -- so every slot is made useful for every lane:
 //
-//   variable point:  GLV split (scalar.h) -> joint sparse form of (k1, k2)  -> 4-entry co-Z table
-//                    {P, Q=lambda P, P+Q, P-Q} held in VGPRs and selected with v_cndmask (no memory, no LDS);
-//                    the table shares one Z, so the loop runs on the isomorphic curve exactly like the
-//                    reference's global-Z trick (ecmult_impl.h:289-320) and fixes Z once at the end;
-//   generator:       no doublings at all: ng is cut into 32 bytes and each byte indexes a precomputed
-//                    (window, byte) -> affine multiple table in HBM/L2 (gtable.h), 32 mixed adds;
+//   variable point:  GLV split (scalar.h); each 129-bit half is recoded into 33 signed ODD 4-bit digits (never zero;
+//                    digit i is read straight off the bits of the scalar, no carry chain), so the loop is exactly
+//                    4 doublings + 2 additions per digit position for all 64 lanes.  The 8 odd multiples {1..15}P
+//                    (+ their beta*x for lambda*P) are built once per multiplication with one common Z -- the reference's
+//                    isomorphic-curve / global-Z trick (ecmult_impl.h:73-115, group_impl.h:289-320) -- and parked in a
+//                    per-lane 896-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
+//                    addition ahead so the ~1-2 us of latency hides under the previous ~4 us of arithmetic.
+//   generator:       no doublings at all: ng is cut into 16 x 16-bit windows, each indexing a precomputed
+//                    (window, value) -> affine multiple table (gtable.h, 75 MB in HBM), 16 mixed additions.
 //   control:         one loop whose body contains exactly ONE doubling site and ONE mixed-add site, driven by a
-//                    per-lane state machine.  The only data-dependent *arithmetic* case (P + P inside an add)
-//                    is turned into "take the operand and double it on the next trip", so exceptional inputs
-//                    cost one extra iteration for that lane instead of a second copy of the doubling code.
+//                    per-lane micro-program counter.  The only data-dependent *arithmetic* case (P + P inside an add)
+//                    becomes "take the operand and double it on the next trip", so exceptional inputs cost one extra
+//                    trip for that lane instead of a second copy of the doubling code.
 //
 // Results are identical to the reference as group elements (and therefore as serialised bytes).
 #pragma once
@@ -23,131 +25,73 @@
 #include "scalar.h"
 
 // ---- generator table ---------------------------------------------------------------------------------
-// gtab[(w*256 + b)*18 .. +18) = affine (x limbs[9], y limbs[9]) of  b * 256^w * G ,  b = 1..255, w = 0..31.
-#define S2K_GTAB_WINDOWS 32
+// gtab[((w << 16) + v) * 18 .. +18) = affine (x limbs[9], y limbs[9]) of  v * 65536^w * G ,  v = 1..65535, w = 0..15.
+#define S2K_GTAB_BITS 16
+#define S2K_GTAB_WINDOWS 16
 #define S2K_GTAB_ENTRY_WORDS 18
-#define S2K_GTAB_WORDS (S2K_GTAB_WINDOWS * 256 * S2K_GTAB_ENTRY_WORDS)
+#define S2K_GTAB_WORDS ((size_t)S2K_GTAB_WINDOWS * 65536 * S2K_GTAB_ENTRY_WORDS)
 
-S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 byte) {
-    const u32* p = gtab + (size_t)(window * 256u + byte) * S2K_GTAB_ENTRY_WORDS;
+S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
+    const u32* p = gtab + ((size_t)(window << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
 #pragma unroll
     for (int i = 0; i < 9; i++) { r.x.n[i] = p[i]; r.y.n[i] = p[9 + i]; }
 }
 
-// ---- joint sparse form ---------------------------------------------------------------------------------
-// Digits (u1,u2) in {-1,0,1}^2 of two 129-bit magnitudes, least significant first (Solinas 2001).  Each digit pair
-// is packed in a nibble  [bit0: u1 != 0, bit1: u1 < 0, bit2: u2 != 0, bit3: u2 < 0]  and pushed in at the TOP of a
-// 17-word shift register, so that after S2K_JSF_LEN steps the most significant digit sits in the top nibble and
-// the main loop can pop digits MSB-first with the same (wave-uniform) shift -- no indexed register access.
-#define S2K_JSF_LEN 130
-#define S2K_JSF_WORDS 17
+// ---- per-lane table of odd multiples ----------------------------------------------------------------------
+// ptab (this lane's slice): entry e = 0..7 holds (2e+1)*P on the isomorphic curve: x[9] | y[9] | beta*x[9] | pad
+#define S2K_PTAB_ENTRIES 8
+#define S2K_PTAB_ENTRY_WORDS 28
+#define S2K_PTAB_WORDS (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)
 
-struct jsf_digits { u32 w[S2K_JSF_WORDS]; };
-
-S2K_HD void jsf_push_top(jsf_digits& d, u32 nib) {
+S2K_HD void ptab_store(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
-    for (int i = 0; i < S2K_JSF_WORDS - 1; i++) d.w[i] = (d.w[i] >> 4) | (d.w[i + 1] << 28);
-    d.w[S2K_JSF_WORDS - 1] = (d.w[S2K_JSF_WORDS - 1] >> 4) | (nib << 28);
+    for (int i = 0; i < 9; i++) { e[i] = x.n[i]; e[9 + i] = y.n[i]; e[18 + i] = third.n[i]; }
 }
-S2K_HD u32 jsf_pop_top(jsf_digits& d) {
-    const u32 nib = d.w[S2K_JSF_WORDS - 1] >> 28;
+// Builds the table for a finite Jacobian A (magnitudes <= (5,3,1)); returns the factor that takes the accumulator's Z
+// from the isomorphic curve back to the real one.  ~138 field multiplications.
+S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
+    gej d; gej_double(d, A);
+    fe c2, c3, beta; fe_set_beta(beta);
+    fe_sqr(c2, d.z); fe_mul(c3, c2, d.z);
+    gej cur;
+    { fe x = A.x, y = A.y; fe_norm_weak(x); fe_norm_weak(y); fe_mul(cur.x, x, c2); fe_mul(cur.y, y, c3); }
+    cur.z = A.z; cur.inf = 0;
+    ge dd; dd.x = d.x; dd.y = d.y; fe_norm_weak(dd.x); fe_norm_weak(dd.y);
+    { fe one; fe_set_int(one, 1); ptab_store(ptab, cur.x, cur.y, one); }
+    for (int i = 1; i < S2K_PTAB_ENTRIES; i++) {
+        gej nxt; fe h;
+        gej_add_ge(nxt, cur, dd, &h);
+        fe_norm_weak(nxt.y);
+        ptab_store(ptab + i * S2K_PTAB_ENTRY_WORDS, nxt.x, nxt.y, h);     // third slot: z ratio, replaced by beta*x below
+        cur = nxt;
+    }
+    fe_mul(ziso, cur.z, d.z);
+    // bring every entry to the Z of the last one (secp256k1_ge_table_set_globalz, group_impl.h:289-320), then beta*x
+    fe zs; fe_set_int(zs, 1);
+    for (int i = S2K_PTAB_ENTRIES - 1; i >= 0; i--) {
+        u32* e = ptab + i * S2K_PTAB_ENTRY_WORDS;
+        fe x, y, h, bx;
 #pragma unroll
-    for (int i = S2K_JSF_WORDS - 1; i > 0; i--) d.w[i] = (d.w[i] << 4) | (d.w[i - 1] >> 28);
-    d.w[0] <<= 4;
-    return nib;
-}
-S2K_HD void hs_shr1(u32 w[5]) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
-    w[4] >>= 1;
-}
-S2K_HD void jsf_recode(jsf_digits& d, const half_scalar& k1, const half_scalar& k2) {
-    u32 a[5], b[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) { a[i] = k1.w[i]; b[i] = k2.w[i]; }
-#pragma unroll
-    for (int i = 0; i < S2K_JSF_WORDS; i++) d.w[i] = 0;
-    u32 da = 0, db = 0;
-    for (int j = 0; j < S2K_JSF_LEN; j++) {
-        const u32 la = (a[0] + da) & 7u, lb = (b[0] + db) & 7u;
-        int ua = 0, ub = 0;
-        if (la & 1u) { ua = 2 - (int)(la & 3u); if ((la == 3u || la == 5u) && (lb & 3u) == 2u) ua = -ua; }
-        if (lb & 1u) { ub = 2 - (int)(lb & 3u); if ((lb == 3u || lb == 5u) && (la & 3u) == 2u) ub = -ub; }
-        if ((int)(2 * da) == 1 + ua) da = 1 - da;
-        if ((int)(2 * db) == 1 + ub) db = 1 - db;
-        hs_shr1(a); hs_shr1(b);
-        const u32 nib = (ua != 0 ? 1u : 0u) | (ua < 0 ? 2u : 0u) | (ub != 0 ? 4u : 0u) | (ub < 0 ? 8u : 0u);
-        jsf_push_top(d, nib);
+        for (int k = 0; k < 9; k++) { x.n[k] = e[k]; y.n[k] = e[9 + k]; h.n[k] = e[18 + k]; }
+        if (i != S2K_PTAB_ENTRIES - 1) {
+            fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
+            fe_mul(x, x, zs2); fe_mul(y, y, zs3);
+        }
+        fe_mul(bx, x, beta);
+        ptab_store(e, x, y, bx);
+        fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
     }
 }
-
-// ---- co-Z table {P, Q, P+Q, P-Q} ------------------------------------------------------------------------
-// P = (X1,Y1,Z), Q = (X2,Y2,Z) with X1 != X2.  ZADDU + conjugate addition (Meloni 2007; Goundar, Joye, Miyaji 2010):
-// all four points leave with the common  Z' = Z (X1 - X2).  7M + 3S.  Q is always lambda*P up to sign here, so
-// only the sign of Y2 relative to Y1 is kept (q_ysign) instead of a ninth field element.
-struct jsf_table {
-    fe px, py;        // P  on the isomorphic curve (Z' implicit)
-    fe qx;            // Q.x ;  Q.y = q_neg ? -py : py
-    fe sx, sy;        // P + Q
-    fe dx, dy;        // P - Q
-    fe ziso;          // Z' : multiply the accumulator's Z by this when leaving the isomorphic curve
-    int q_neg;
-};
-
-// Inputs: P finite Jacobian with magnitudes (<=1,<=1,1) after the normalisations below; negp/negq pick -P / -Q.
-S2K_HD void jsf_table_build(jsf_table& t, const gej& P, int negp, int negq) {
-    fe beta, x1 = P.x, y1 = P.y, x2, y2, d, c, w1, w2, a1, e, f, g;
-    fe_norm_weak(x1); fe_norm_weak(y1);
-    if (negp) { fe_neg(y1, y1, 1); fe_norm_weak(y1); }
-    fe_set_beta(beta);
-    fe_mul(x2, x1, beta);
-    t.q_neg = (negp != negq);                 // sign of Q.y relative to (possibly negated) P.y
-    fe_neg(y2, y1, 1); fe_norm_weak(y2);      // -y1
-    fe_select(y2, y2, y1, t.q_neg);           // y2 = q_neg ? -y1 : y1
-    fe_neg(d, x2, 1); fe_add(d, x1); fe_norm_weak(d);      // d = X1 - X2
-    fe_sqr(c, d);
-    fe_mul(w1, x1, c); fe_mul(w2, x2, c);
-    fe_neg(e, w2, 1); fe_add(e, w1);                       // W1 - W2  (3)
-    fe_mul(a1, y1, e);                                     // A1 = Y1 (W1 - W2) = P.y'
-    fe_mul(t.ziso, P.z, d);
-    // P + Q
-    fe_neg(f, y2, 1); fe_add(f, y1); fe_norm_weak(f);      // Y1 - Y2
-    fe_sqr(g, f);
-    fe nw; fe_add2(nw, w1, w2); fe_neg(nw, nw, 2);         // -(W1 + W2)  (3)
-    fe_add2(t.sx, g, nw); fe_norm_weak(t.sx);              // X3 = D - W1 - W2
-    fe_neg(g, t.sx, 1); fe_add(g, w1);                     // W1 - X3  (3)
-    fe_mul(t.sy, f, g);
-    fe na1; fe_neg(na1, a1, 1);                            // -A1 (2)
-    fe_add(t.sy, na1); fe_norm_weak(t.sy);
-    // P - Q
-    fe_add2(f, y1, y2); fe_norm_weak(f);                   // Y1 + Y2
-    fe_sqr(g, f);
-    fe_add2(t.dx, g, nw); fe_norm_weak(t.dx);
-    fe_neg(g, t.dx, 1); fe_add(g, w1);
-    fe_mul(t.dy, f, g);
-    fe_add(t.dy, na1); fe_norm_weak(t.dy);
-    t.px = w1; t.py = a1; t.qx = w2;
-}
-
-// operand for JSF nibble (nonzero): x from {px,qx,sx,dx}, y from {py,sy,dy} with sign.  Output magnitudes (1,2).
-S2K_HD void jsf_select(ge& o, const jsf_table& t, u32 nib) {
-    const int u1nz = nib & 1u, u1neg = (nib >> 1) & 1u, u2nz = (nib >> 2) & 1u, u2neg = (nib >> 3) & 1u;
-    const int both = u1nz & u2nz;
-    const int same = both & (u1neg == u2neg);      // +-(P+Q)
-    const int diff = both & (u1neg != u2neg);      // +-(P-Q)
-    const int only_q = u2nz & !u1nz;
-    fe x, y;
-    fe_select(x, t.qx, t.px, only_q);
-    fe_cmov(x, t.sx, same);
-    fe_cmov(x, t.dx, diff);
-    y = t.py;
-    fe_cmov(y, t.sy, same);
-    fe_cmov(y, t.dy, diff);
-    // sign: single P: u1neg; single Q: u2neg ^ q_neg; P+Q / P-Q: sign of u1
-    const int neg = only_q ? (u2neg ^ t.q_neg) : u1neg;
+// operand for digit value v (4 bits: d = 2v - 15) of half `half`; sign_flip = the half's own sign.  Magnitudes (1, <=2).
+S2K_HD void ptab_fetch(ge& o, const u32* ptab, u32 v, int half, int sign_flip) {
+    const int neg = (v < 8u) ^ sign_flip;
+    const u32 idx = (v < 8u) ? (7u - v) : (v - 8u);
+    const u32* e = ptab + idx * S2K_PTAB_ENTRY_WORDS;
+    fe y;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { o.x.n[k] = half ? e[18 + k] : e[k]; y.n[k] = e[9 + k]; }
     fe yn; fe_neg(yn, y, 1);
     fe_select(o.y, yn, y, neg);
-    o.x = x;
 }
 
 // ---- wave-level predicates ------------------------------------------------------------------------------
@@ -157,65 +101,113 @@ S2K_HD void jsf_select(ge& o, const jsf_table& t, u32 nib) {
 #define S2K_WAVE_ANY(p) (p)
 #endif
 
+// 160-bit shift register holding a 129-bit magnitude: the next 4-bit digit window is always the top nibble
+struct digit_reg { u32 w[5]; };
+S2K_HD void digit_reg_init(digit_reg& r, const u32 k[5]) {          // k' << 31 : window of digit 31 (bits 125..128) at the top
+    r.w[4] = (k[4] << 31) | (k[3] >> 1);
+    r.w[3] = (k[3] << 31) | (k[2] >> 1);
+    r.w[2] = (k[2] << 31) | (k[1] >> 1);
+    r.w[1] = (k[1] << 31) | (k[0] >> 1);
+    r.w[0] = (k[0] << 31);
+}
+S2K_HD u32 digit_reg_pop(digit_reg& r) {
+    const u32 v = r.w[4] >> 28;
+#pragma unroll
+    for (int i = 4; i > 0; i--) r.w[i] = (r.w[i] << 4) | (r.w[i - 1] >> 28);
+    r.w[0] <<= 4;
+    return v;
+}
+
+#define S2K_ADDS_P 66            // 33 digit positions x 2 halves
+#define S2K_ADDS_SKEW 2
+#define S2K_ADD_G0 (S2K_ADDS_P + S2K_ADDS_SKEW)
+#define S2K_ADDS_TOTAL (S2K_ADD_G0 + S2K_GTAB_WINDOWS)
+
 // R = na*A + ng*G for this lane.  A is Jacobian (A.inf allowed), ng may be absent (has_ng = 0).
-// gtab: generator table (see above).  R is returned on the real curve, magnitudes (<=6,<=3,1).
-S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng, int has_ng, const u32* gtab) {
-    jsf_digits dig;
-    jsf_table tab;
+// gtab: generator table; ptab: this lane's private S2K_PTAB_WORDS-word slice of scratch memory.
+// R is returned on the real curve, magnitudes (<=5,<=3,1).
+S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng, int has_ng, const u32* gtab, u32* ptab) {
     const int p_active = (!A.inf) & (!sc_is_zero(na));
     const int g_active = has_ng & (!sc_is_zero(ng));
+    digit_reg dr0, dr1; int hneg0, hneg1, skew0, skew1;
+    fe ziso;
     {
-        scalar k1s, k2s; half_scalar k1, k2;
+        scalar k1s, k2s; half_scalar h0, h1;
         sc_split_lambda(k1s, k2s, na);
-        sc_to_half(k1, k1s); sc_to_half(k2, k2s);
-        jsf_recode(dig, k1, k2);
-        jsf_table_build(tab, A, k1.neg, k2.neg);
+        sc_to_half(h0, k1s); sc_to_half(h1, k2s);
+        hneg0 = h0.neg; hneg1 = h1.neg;
+        skew0 = !(h0.w[0] & 1u); skew1 = !(h1.w[0] & 1u);       // make the magnitudes odd: k' = k + skew, corrected by -P at the end
+        u32 c = (u32)skew0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const u32 t = h0.w[i] + c; c = (t < c); h0.w[i] = t; }
+        c = (u32)skew1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const u32 t = h1.w[i] + c; c = (t < c); h1.w[i] = t; }
+        digit_reg_init(dr0, h0.w); digit_reg_init(dr1, h1.w);
+        if (S2K_WAVE_ANY(p_active)) ptab_build(ziso, ptab, A);
     }
-    gej_set_infinity(R);
-    int phase = p_active ? 0 : (g_active ? 1 : 2);
-    int pending = 0;          // the previous add hit P + P: R holds P (Z = 1), double it next
-    int left = S2K_JSF_LEN;   // digits left in phase 0
-    u32 win = 0;              // next generator window in phase 1
-    u32 gw[8];                // ng, rotated right one byte per window (no indexed register access)
+    u32 gw[8];                // ng, shifted right one 16-bit window per generator addition
 #pragma unroll
     for (int i = 0; i < 8; i++) gw[i] = ng.d[i];
-    while (S2K_WAVE_ANY(phase != 2)) {
+
+    // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
+    int a = p_active ? 0 : S2K_ADD_G0;
+    int zfixed = !p_active;
+    int dbl_left = 0, pending = 0;
+    const int a_end = g_active ? S2K_ADDS_TOTAL : S2K_ADD_G0;
+    ge cur, nxt; int cur_valid = 0, nxt_valid = 0;
+    fe_set_zero(cur.x); fe_set_zero(cur.y); fe_set_zero(nxt.x); fe_set_zero(nxt.y);
+    // operand of addition `idx` (called once per idx, in increasing order: the digit registers are consumed as we go)
+#define S2K_FETCH(dst, dst_valid, idx)                                                                              \
+    do {                                                                                                            \
+        const int _i = (idx);                                                                                       \
+        dst_valid = 0;                                                                                              \
+        if (_i < S2K_ADD_G0) {                                                                                      \
+            const int _h = _i & 1;                                                                                  \
+            const int _hn = _h ? hneg1 : hneg0;                                                                     \
+            u32 _v = 8u; int _flip = _hn; dst_valid = 1;                       /* top digit (a = 0, 1) is always +1 */ \
+            if (_i >= 2 && _i < S2K_ADDS_P) { if (_h) _v = digit_reg_pop(dr1); else _v = digit_reg_pop(dr0); }      \
+            if (_i >= S2K_ADDS_P) { _flip = !_hn; dst_valid = _h ? skew1 : skew0; }      /* skew correction: -(+-P) */ \
+            ptab_fetch(dst, ptab, _v, _h, _flip);                                                                   \
+        }                                                                                                           \
+        else if (_i < S2K_ADDS_TOTAL) {                                                                             \
+            const u32 _v = gw[0] & 0xFFFFu;                                                                         \
+            _Pragma("unroll") for (int _k = 0; _k < 7; _k++) gw[_k] = (gw[_k] >> 16) | (gw[_k + 1] << 16);          \
+            gw[7] >>= 16;                                                                                           \
+            if (_v) { gtab_load(dst, gtab, (u32)(_i - S2K_ADD_G0), _v); dst_valid = 1; }                            \
+        }                                                                                                           \
+    } while (0)
+    if (a < a_end) S2K_FETCH(cur, cur_valid, a);
+    gej_set_infinity(R);
+    int done = !(a < a_end);
+    while (S2K_WAVE_ANY(!done)) {
         int do_dbl = 0, do_add = 0;
-        ge opnd;
-        fe_set_zero(opnd.x); fe_set_zero(opnd.y);
-        if (phase == 0) {
+        if (!done) {
             if (pending) { do_dbl = 1; pending = 0; }
-            else {
-                do_dbl = !R.inf;
-                const u32 nib = jsf_pop_top(dig);
-                left--;
-                if (nib) { do_add = 1; jsf_select(opnd, tab, nib); }
-            }
-        } else if (phase == 1) {
-            if (pending) { do_dbl = 1; pending = 0; }
-            else {
-                const u32 byte = gw[0] & 0xFFu;
-#pragma unroll
-                for (int i = 0; i < 7; i++) gw[i] = (gw[i] >> 8) | (gw[i + 1] << 24);
-                gw[7] >>= 8;
-                if (byte) { do_add = 1; gtab_load(opnd, gtab, win, byte); }
-                win++;
-            }
+            else if (dbl_left > 0) { do_dbl = !R.inf; dbl_left--; }
+            else do_add = 1;
         }
         if (S2K_WAVE_ANY(do_dbl)) {
             gej t; gej_double(t, R);
             if (do_dbl) R = t;
         }
         if (S2K_WAVE_ANY(do_add)) {
-            gej t; const int f = gej_add_ge(t, R, opnd);
-            if (do_add) { R = t; pending = (f == GEJ_ADD_NEEDS_DOUBLE); }
+            if (do_add && a + 1 < a_end) S2K_FETCH(nxt, nxt_valid, a + 1);      // issue the next gather before the arithmetic
+            gej t; const int f = gej_add_ge(t, R, cur);
+            if (do_add) {
+                if (cur_valid) { R = t; pending = (f == GEJ_ADD_NEEDS_DOUBLE); }
+                a++;
+                cur = nxt; cur_valid = nxt_valid;
+                dbl_left = (a >= 2 && a < S2K_ADDS_P && !(a & 1)) ? 4 : 0;
+            }
         }
-        // phase transitions
-        const int leave0 = (phase == 0) & (left == 0) & (!pending);
-        if (S2K_WAVE_ANY(leave0)) {
-            fe z; fe_mul(z, R.z, tab.ziso);
-            if (leave0) { R.z = z; phase = g_active ? 1 : 2; }
+        // leaving the isomorphic curve: after the skew corrections, before the generator additions
+        const int fix = (!done) & (!zfixed) & (a == S2K_ADD_G0) & (!pending);
+        if (S2K_WAVE_ANY(fix)) {
+            fe z; fe_mul(z, R.z, ziso);
+            if (fix) { R.z = z; zfixed = 1; }
         }
-        if ((phase == 1) & (win == S2K_GTAB_WINDOWS) & (!pending)) phase = 2;
+        if ((a >= a_end) & (!pending) & zfixed) done = 1;
     }
+#undef S2K_FETCH
 }

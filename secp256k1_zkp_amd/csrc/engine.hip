@@ -42,11 +42,24 @@ struct s2k_engine {
     u32* gtab;                 // generator table (S2K_GTAB_WORDS words)
     unsigned char* ws;         // growable HBM workspace
     size_t ws_bytes;
+    u32* ptab;                 // per-lane odd-multiples tables (S2K_PTAB_WORDS words per lane), grown on demand
+    size_t ptab_lanes;
     hipEvent_t ev[4];          // [0],[1] whole call; [2],[3] dominant kernel
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     std::mutex mu;
 };
 
+// per-lane table scratch for `lanes` concurrent ecmult_lane callers (lane = global thread index of the launch)
+static int engine_ptab(s2k_engine* e, size_t lanes) {
+    lanes = (lanes + 255) & ~size_t(255);
+    if (lanes <= e->ptab_lanes) return 1;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->ptab) HIPCHK(hipFree(e->ptab));
+    e->ptab = nullptr; e->ptab_lanes = 0;
+    HIPCHK(hipMalloc((void**)&e->ptab, lanes * S2K_PTAB_WORDS * sizeof(u32)));
+    e->ptab_lanes = lanes;
+    return 1;
+}
 static int engine_workspace(s2k_engine* e, size_t bytes) {
     if (bytes <= e->ws_bytes) return 1;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -83,10 +96,11 @@ __global__ void k_gtab_base(u32* gtab) {
     const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < S2K_GTAB_WINDOWS) gtab_build_base(gtab, w);
 }
-__global__ void k_gtab_entries(u32* gtab) {
+__global__ void __launch_bounds__(256)
+k_gtab_entries(u32* gtab) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 w = t >> 8, b = t & 255u;
-    if (w < S2K_GTAB_WINDOWS && b >= 2) gtab_build_entry(gtab, w, b);
+    const u32 w = t >> S2K_GTAB_BITS, v = t & 0xFFFFu;
+    if (w < S2K_GTAB_WINDOWS && v >= 2) gtab_build_entry(gtab, w, v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -97,7 +111,7 @@ __global__ void k_gtab_entries(u32* gtab) {
 __global__ void __launch_bounds__(256, 2)
 k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, const unsigned char* __restrict__ a_xy,
                const unsigned char* __restrict__ a_inf, const unsigned char* __restrict__ na, const unsigned char* __restrict__ ng,
-               const u32* __restrict__ gtab, size_t n) {
+               const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int live = i < n;
     const size_t ii = live ? i : 0;
@@ -111,7 +125,7 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
     if (ng) sc_set_b32(sg, ng + 32 * ii, nullptr); else sc_set_zero(sg);
     if (!live) { sc_set_zero(sa); sc_set_zero(sg); }
     gej R;
-    ecmult_lane(R, A, sa, sg, ng != nullptr, gtab);
+    ecmult_lane(R, A, sa, sg, ng != nullptr, gtab, ptab + i * S2K_PTAB_WORDS);
     ge out;
     ge_set_gej(out, R);
     if (live) {
@@ -130,14 +144,14 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0;
     schnorr_tag_midstate(e->bip340);
     HIPCHK_NULL(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK_NULL(hipEventCreate(&e->ev[i]));
     HIPCHK_NULL(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
     HIPCHK_NULL(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
-    hipLaunchKernelGGL(k_gtab_entries, dim3(S2K_GTAB_WINDOWS * 256 / 64), dim3(64), 0, e->stream, e->gtab);
+    hipLaunchKernelGGL(k_gtab_entries, dim3(S2K_GTAB_WINDOWS * 65536 / 256), dim3(256), 0, e->stream, e->gtab);
     HIPCHK_NULL(hipGetLastError());
     HIPCHK_NULL(hipStreamSynchronize(e->stream));
     return e;
@@ -147,6 +161,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     if (e->ws) hipFree(e->ws);
+    if (e->ptab) hipFree(e->ptab);
     if (e->gtab) hipFree(e->gtab);
     for (int i = 0; i < 4; i++) hipEventDestroy(e->ev[i]);
     hipStreamDestroy(e->stream);
@@ -193,9 +208,10 @@ extern "C" int s2k_ecmult_batch_dev(s2k_engine* e, void* stream, unsigned char* 
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (!engine_ptab(e, (size_t)blocks * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_ecmult_batch, dim3(blocks), dim3(256), 0, st, r_xy, r_inf, a_xy, a_inf, na, ng, e->gtab, n);
+    hipLaunchKernelGGL(k_ecmult_batch, dim3(blocks), dim3(256), 0, st, r_xy, r_inf, a_xy, a_inf, na, ng, e->gtab, e->ptab, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipEventRecord(e->ev[1], st));
@@ -255,7 +271,7 @@ k_rp_sum(rp_ws ws, size_t n) {
     rp_sum(ws.rec[p], ws.pub0 + p * RP_MAX_RINGS * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS);
 }
 __global__ void __launch_bounds__(256, 2)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, size_t n) {
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     int live = p < n;
@@ -263,7 +279,7 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     const rp_rec& rec = ws.rec[p];
     live &= (ring < rec.rings);
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab);
+            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, ptab + t * S2K_PTAB_WORDS);
 }
 __global__ void __launch_bounds__(64)
 k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
@@ -288,12 +304,13 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
                      const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
     const unsigned b64 = (unsigned)((n + 63) / 64), b256 = (unsigned)((n * 32 + 255) / 256);
+    if (!engine_ptab(e, (size_t)b256 * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
     hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, n);
     hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, e->gtab, n);
+    hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, e->gtab, e->ptab, n);
     HIPCHK(hipEventRecord(e->ev[3], st));
     hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results, proofs, proof_off, n);
     HIPCHK(hipGetLastError());
@@ -367,11 +384,11 @@ extern "C" int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_va
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 k_schnorr_verify(int32_t* __restrict__ results, schnorr_midstate mid, const unsigned char* __restrict__ sigs, const unsigned char* __restrict__ msgs,
-                 size_t msglen, const unsigned char* __restrict__ pks, int pk_format, const u32* __restrict__ gtab, size_t n) {
+                 size_t msglen, const unsigned char* __restrict__ pks, int pk_format, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int live = i < n;
     const size_t ii = live ? i : 0;
-    const int r = schnorr_verify_lane(mid, sigs + 64 * ii, msgs + msglen * ii, msglen, pks + (pk_format ? 64 : 32) * ii, pk_format, live, gtab);
+    const int r = schnorr_verify_lane(mid, sigs + 64 * ii, msgs + msglen * ii, msglen, pks + (pk_format ? 64 : 32) * ii, pk_format, live, gtab, ptab + i * S2K_PTAB_WORDS);
     if (live) results[i] = r;
 }
 extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* sigs,
@@ -380,8 +397,9 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
     if (n == 0) return 1;
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if (!engine_ptab(e, ((n + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_schnorr_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, e->bip340, sigs, msgs, msglen, pubkeys, pk_format, e->gtab, n);
+    hipLaunchKernelGGL(k_schnorr_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, e->bip340, sigs, msgs, msglen, pubkeys, pk_format, e->gtab, e->ptab, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
@@ -510,7 +528,7 @@ __global__ void k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
 // small inputs: one full double-and-add per lane; lane n carries g_sc*G
 __global__ void __launch_bounds__(256, 2)
 k_msm_small(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
-            const u32* gtab, size_t n, size_t nt) {
+            const u32* gtab, u32* ptab, size_t n, size_t nt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int live = i < nt, isg = live && (i == n);
     gej A; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
@@ -520,7 +538,7 @@ k_msm_small(u32* out28, const unsigned char* g_sc, const unsigned char* sc, cons
         sc_set_b32(k, sc + 32 * i, nullptr);
     }
     if (isg) sc_set_b32(g, g_sc, nullptr);
-    gej R; ecmult_lane(R, A, k, g, 1, gtab);
+    gej R; ecmult_lane(R, A, k, g, 1, gtab, ptab + i * S2K_PTAB_WORDS);
     if (live) gej_store28(out28 + i * 28, R);
 }
 __global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in28) {
@@ -557,7 +575,8 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
         u32* lanes = c.take<u32>((nt + 1) * 28); u32* bufA = c.take<u32>(64 * 28); u32* bufB = c.take<u32>(64 * 28);
         if (nt == 0) { HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st)); const u32 one = 1; HIPCHK(hipMemcpyAsync(final28 + 27, &one, 4, hipMemcpyHostToDevice, st)); return 1; }
         HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, lanes, g_sc, sc, pt, pt_inf, e->gtab, n, nt);
+        if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
+        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, lanes, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt);
         HIPCHK(hipEventRecord(e->ev[3], st));
         const u32* r = launch_gej_reduce(st, lanes, bufA, bufB, 1, (u32)nt);
         HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
@@ -696,13 +715,13 @@ k_bp_prologue(u32* term_sc, int* proof_ok, bp_shape sh, const unsigned char* pro
 }
 __global__ void __launch_bounds__(256, 2)
 k_bp_terms(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* gens18, const unsigned char* proofs,
-           size_t proof_len, const unsigned char* commits33, const u32* gtab, size_t n) {
+           size_t proof_len, const unsigned char* commits33, const u32* gtab, u32* ptab, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t / sh.n_terms; const u32 ti = (u32)(t % sh.n_terms);
     int live = p < n;
     if (!live) p = 0;
     live &= proof_ok[p];
-    gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab);
+    gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab, ptab + t * S2K_PTAB_WORDS);
     if (t < n * sh.n_terms) { gej_store28(out28 + t * 28, o); term_ok[t] = (unsigned char)ok; }
 }
 __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
@@ -735,6 +754,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     u32* out28 = c.take<u32>(nt * 28); unsigned char* term_ok = c.take<unsigned char>(nt + 64);
     u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
     hipStream_t st = e->stream;
+    if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemcpyAsync(d_pr, proofs, n * proof_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_tr, transcripts, 104 * n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_rho, rho, 32 * n, hipMemcpyHostToDevice, st));
@@ -747,7 +767,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
     hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm, e->gtab, n);
+    hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm, e->gtab, e->ptab, n);
     HIPCHK(hipEventRecord(e->ev[3], st));
     const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);
     hipLaunchKernelGGL(k_bp_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_res, sums, proof_ok, term_ok, gens_ok, (u32)T, n);

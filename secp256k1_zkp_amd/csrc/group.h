@@ -54,7 +54,7 @@ S2K_HD void gej_double(gej& r, const gej& a) {
 // r = a + b, b affine and finite.  8M + 3S (cf. secp256k1_gej_add_ge_var, group_impl.h:598-659).
 // Returns GEJ_ADD_NEEDS_DOUBLE when a == b (then r is set to b with Z = 1 and the caller must double it);
 // a == -b gives r.inf = 1; a.inf gives r = b.  Inputs: a magnitudes up to (5,3,1), b up to (1,2).  Output (1,3,1).
-S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b) {
+S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
     fe z12, u2, s2, h, i, h2, h3, t, i2;
     fe_sqr(z12, a.z);
     fe_mul(u2, b.x, z12);
@@ -68,6 +68,7 @@ S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b) {
     fe_mul(h3, h, h2);
     fe_mul(t, a.x, h2);                        // t = X1*h2           (6*1)
     fe zz; fe_mul(zz, a.z, h);                 // Z3 = Z1*h
+    if (zr) *zr = h;                           // Z3 / Z1, for global-Z table construction
     fe x3, y3, tn;
     fe_neg(x3, h3, 1);                         // -h3                 (2)
     fe_neg(tn, t, 1);                          // -t                  (2)

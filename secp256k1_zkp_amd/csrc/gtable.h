@@ -1,11 +1,11 @@
 // gtable.h -- device-resident fixed-base table for the generator G.
 //
 // Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
-// src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine
-// that would rather gather 72 bytes than execute 8 doublings: entry (w, b) = b * 256^w * G for every byte value of
-// every one of the 32 byte-windows of a scalar, in the engine's own 9x29 limb format (18 words, affine), so
-// ng*G is 32 mixed additions and zero doublings.  8160 useful entries * 72 B = 574 KiB: resident in every XCD's L2.
-// The table is *computed on the device* when an engine is created (two tiny kernels), never shipped as data.
+// src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine with
+// 288 GB of HBM that would rather gather 72 bytes than execute 16 doublings: entry (w, v) = v * 65536^w * G for every
+// 16-bit value of every one of the 16 windows of a scalar, in the engine's own 9x29 limb format (18 words, affine), so
+// ng*G is 16 mixed additions and zero doublings.  16 x 65535 entries x 72 B = 75.5 MB (Infinity-Cache resident).
+// The table is *computed on the device* when an engine is created (two kernels, a few ms), never shipped as data.
 #pragma once
 #include "ecmult.h"
 
@@ -15,29 +15,30 @@ S2K_HD void ge_set_generator(ge& g) {
 #pragma unroll
     for (int i = 0; i < 9; i++) { g.x.n[i] = gx[i]; g.y.n[i] = gy[i]; }
 }
-
-// step 1 (one thread per window w): base[w] = 256^w * G, affine, stored as entry (w, 1).
+S2K_HD void gtab_store(u32* gtab, u32 w, u32 v, const ge& a) {
+    u32* p = gtab + ((size_t)(w << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
+    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+}
+// step 1 (one thread per window w): base[w] = 65536^w * G, affine, stored as entry (w, 1).
 S2K_HD void gtab_build_base(u32* gtab, u32 w) {
     ge g; ge_set_generator(g);
     gej j; gej_set_ge(j, g);
-    for (u32 i = 0; i < 8 * w; i++) { gej t; gej_double(t, j); j = t; }
+    for (u32 i = 0; i < S2K_GTAB_BITS * w; i++) { gej t; gej_double(t, j); j = t; }
     ge a; ge_set_gej(a, j);
-    u32* p = gtab + (size_t)(w * 256u + 1u) * S2K_GTAB_ENTRY_WORDS;
-    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+    gtab_store(gtab, w, 1, a);
 }
-// step 2 (one thread per (w, b), b = 2..255): entry = b * base[w] by left-to-right double-and-add.
-S2K_HD void gtab_build_entry(u32* gtab, u32 w, u32 b) {
+// step 2 (one thread per (w, v), v = 2..65535): entry = v * base[w] by left-to-right double-and-add.
+S2K_HD void gtab_build_entry(u32* gtab, u32 w, u32 v) {
     ge base; gtab_load(base, gtab, w, 1);
     gej acc; gej_set_infinity(acc);
-    for (int bit = 7; bit >= 0; bit--) {
+    for (int bit = S2K_GTAB_BITS - 1; bit >= 0; bit--) {
         gej t; gej_double(t, acc); acc = t;
-        if ((b >> bit) & 1u) {
+        if ((v >> bit) & 1u) {
             const int f = gej_add_ge(t, acc, base);
             acc = t;
             if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
         }
     }
     ge a; ge_set_gej(a, acc);
-    u32* p = gtab + (size_t)(w * 256u + b) * S2K_GTAB_ENTRY_WORDS;
-    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+    gtab_store(gtab, w, v, a);
 }

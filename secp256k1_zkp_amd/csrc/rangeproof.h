@@ -273,7 +273,7 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
 }
 
 S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
-                    const unsigned char* proof, u32 ring, int live, const u32* gtab) {
+                    const unsigned char* proof, u32 ring, int live, const u32* gtab, u32* ptab) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
     u32 m[8], e[8];
@@ -302,7 +302,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsi
         int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens) & !pub.inf;
         if (!good) { sc_set_zero(ens); sc_set_zero(s); }            // dead lanes ride along with empty work
         gej R;
-        ecmult_lane(R, pub, ens, s, 1, gtab);
+        ecmult_lane(R, pub, ens, s, 1, gtab, ptab);
         good &= !R.inf;
         ge a; ge_set_gej(a, R);
         u32 xw[8]; fe_to_words(xw, a.x);

@@ -77,13 +77,39 @@ int emu_ge_set_xquad(unsigned char* r64, const unsigned char* x32) {
 }
 
 static std::vector<u32> g_gtab;
+static u32 g_ptab[S2K_PTAB_WORDS];
+// Host-only construction of the 16-bit window table: same entries as gtable.h's device kernels, but built by running
+// sums + Montgomery batch inversion so that a CPU test does not spend a minute on a million inversions.
 static const u32* gtab_host() {
     if (g_gtab.empty()) {
         g_gtab.assign(S2K_GTAB_WORDS, 0);
-        for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) gtab_build_base(g_gtab.data(), w);
-        for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) for (u32 b = 2; b < 256; b++) gtab_build_entry(g_gtab.data(), w, b);
+        std::vector<gej> acc(65536); std::vector<fe> pre(65536);
+        for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
+            gtab_build_base(g_gtab.data(), w);
+            ge base; gtab_load(base, g_gtab.data(), w, 1);
+            gej_set_ge(acc[1], base);
+            for (u32 v = 2; v < 65536; v++) {
+                gej t; int f = gej_add_ge(t, acc[v - 1], base);
+                if (f == GEJ_ADD_NEEDS_DOUBLE) { gej u; gej_double(u, t); t = u; }
+                fe_norm_weak(t.y); acc[v] = t;
+            }
+            fe run; fe_set_int(run, 1);
+            for (u32 v = 1; v < 65536; v++) { pre[v] = run; fe_mul(run, run, acc[v].z); }
+            fe inv; fe_inv(inv, run);
+            for (u32 v = 65535; v >= 2; v--) {
+                fe zi, zi2, zi3; fe_mul(zi, inv, pre[v]); fe_mul(inv, inv, acc[v].z);
+                fe_sqr(zi2, zi); fe_mul(zi3, zi2, zi);
+                ge a; fe_mul(a.x, acc[v].x, zi2); fe_mul(a.y, acc[v].y, zi3); fe_normalize(a.x); fe_normalize(a.y);
+                gtab_store(g_gtab.data(), w, v, a);
+            }
+        }
     }
     return g_gtab.data();
+}
+// spot-check entry (w, v) of the host table against the device construction path
+int emu_gtab_entry(unsigned char* r64, unsigned w, unsigned v) {
+    std::vector<u32> t(S2K_GTAB_WORDS / S2K_GTAB_WINDOWS * 0 + 1);
+    ge g; gtab_load(g, gtab_host(), w, v); fe_normalize(g.x); fe_normalize(g.y); fe_get_b32(r64, g.x); fe_get_b32(r64 + 32, g.y); return 0;
 }
 // z32 != NULL: present A in Jacobian form with that Z
 int emu_ecmult(unsigned char* r64, const unsigned char* a64, int ainf, const unsigned char* na32, const unsigned char* ng32, const unsigned char* z32) {
@@ -92,7 +118,7 @@ int emu_ecmult(unsigned char* r64, const unsigned char* a64, int ainf, const uns
     if (z32 && !ainf) { fe z, z2, z3; fe_from_b32(z, z32); fe_norm_weak(z); fe_sqr(z2, z); fe_mul(z3, z2, z); fe_mul(A.x, A.x, z2); fe_mul(A.y, A.y, z3); A.z = z; }
     sc_set_b32(na, na32, 0);
     if (ng32) sc_set_b32(ng, ng32, 0); else sc_set_zero(ng);
-    ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host());
+    ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host(), g_ptab);
     return gej_to_b64(r64, R);
 }
 void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
@@ -108,13 +134,13 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
     *min_value = mn; *max_value = mx;
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
-    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host());
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_ptab);
     return rp_final(rec, ring_out, ring_ok, proof);
 }
 
 int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, size_t msglen, const unsigned char* pk, int pk_format) {
     schnorr_midstate mid; schnorr_tag_midstate(mid);
-    return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host());
+    return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host(), g_ptab);
 }
 
 // the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width)
@@ -160,7 +186,7 @@ int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned
     if (!ok) return 0;
     gej sum; gej_set_infinity(sum);
     for (u32 t = 0; t < sh.n_terms; t++) {
-        gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host());
+        gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host(), g_ptab);
         gej s; gej_add_var(s, sum, o); sum = s;
     }
     return ok & sum.inf;
@@ -173,7 +199,7 @@ void emu_msm_partial(u32* out28, const unsigned char* g_sc, const unsigned char*
         gej A, R; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
         if (i < n) { ge a; ge_from_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a); A.inf = inf ? inf[i] : 0; sc_set_b32(k, sc + 32 * i, 0); }
         else sc_set_b32(g, g_sc, 0);
-        ecmult_lane(R, A, k, g, 1, gtab_host());
+        ecmult_lane(R, A, k, g, 1, gtab_host(), g_ptab);
         gej s; gej_add_var(s, acc, R); acc = s;
     }
     gej_store28_h(out28, acc);

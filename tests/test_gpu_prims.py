@@ -128,18 +128,19 @@ def test_sha256(prims):
 
 
 def test_generator_table(prims, ref):
-    """every entry (w,b) of the device-built table equals b*256^w*G computed by the reference's ecmult
-    (role of test_pre_g_table, src/tests.c:4543-4615)."""
-    n = 32 * 256
-    got, _ = prims(11, n, 64)
-    idx = [(w, b) for w in range(32) for b in range(256) if b >= 1]
-    ng = np.stack([np.frombuffer(_b(b << (8 * w)), np.uint8) for (w, b) in idx])
-    zeros = np.zeros((len(idx), 32), np.uint8)
-    g = np.frombuffer(G_XY * len(idx), np.uint8).reshape(-1, 64)
-    exp, inf = ref.ecmult_batch(g, zeros, ng)
+    """entries (w, v) of the device-built 16-bit window table equal v*65536^w*G computed by the reference's ecmult
+    (role of test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample."""
+    rng = np.random.default_rng(16)
+    idx = [(w, v) for w in range(16) for v in (1, 2, 3, 255, 256, 257, 32767, 32768, 65534, 65535)]
+    idx += [(int(rng.integers(0, 16)), int(rng.integers(1, 65536))) for _ in range(4000)]
+    n = len(idx)
+    sel = np.array([(w << 16) | v for (w, v) in idx], np.uint32)
+    got, _ = prims(11, n, 64, sel.view(np.uint8))
+    ng = np.stack([np.frombuffer(_b(v << (16 * w)), np.uint8) for (w, v) in idx])
+    g = np.frombuffer(G_XY * n, np.uint8).reshape(-1, 64)
+    exp, inf = ref.ecmult_batch(g, np.zeros((n, 32), np.uint8), ng)
     assert not inf.any()
-    sel = np.array([w * 256 + b for (w, b) in idx])
-    assert np.array_equal(got[sel], exp)
+    assert np.array_equal(got, exp)
 
 
 def test_chained(prims, ref):
