@@ -270,7 +270,10 @@ k_rp_sum(rp_ws ws, size_t n) {
     if (p >= n) return;
     rp_sum(ws.rec[p], ws.pub0 + p * RP_MAX_RINGS * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS);
 }
-__global__ void __launch_bounds__(256, 2)
+#ifndef S2K_RINGS_WAVES
+#define S2K_RINGS_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
 k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);

@@ -196,79 +196,107 @@ S2K_HD void fe_half(fe& r) {
     r.n[8] >>= 1;
 }
 
-// ---- multiplication ----------------------------------------------------------------------------
-// fold an 18-limb (29-bit limbs, t[17] < 2^32) product into 9 limbs of magnitude 1
-S2K_HD void fe_reduce18(fe& r, const u32 t_in[18]) {
-    u64 d = 0;
-    u32 t[18];
-#pragma unroll
-    for (int i = 0; i < 18; i++) { t[i] = t_in[i]; S2K_OPAQUE(t[i]); }
-#pragma unroll
-    for (int k = 0; k < FE_LIMBS; k++) {
-        d += t[k];
-        d += (u64)t[k + 9] * 31264u;
-        if (k > 0) d += (u64)t[k + 8] << 8;
-        r.n[k] = (u32)d & FE_M;
-        d >>= FE_BITS;
-    }
-    d += (u64)t[17] << 8;                                   // weight 2^261
-    const u64 hi = (u64)(r.n[8] >> 24) + (d << 5);           // everything >= 2^256, in units of 2^256
+// ---- multiplication ----------------------------------------------------------------------------------------
+// Product scanning with the reduction folded in, two interleaved carry chains (the structure of the reference's
+// fe_mul_inner, field_5x52_int128_impl.h:18-152, re-derived for 9x29):
+//     T = sum_{k<17} col_k 2^(29k),  col_k = sum_{i+j=k} a_i b_j
+//     high chain d walks columns 9..16 and emits clean limbs u_0..u_8 of  H = T >> 261;
+//     low chain c walks columns 0..8 and, since 2^261 == 31264 + 2^8 * 2^29 (mod p), absorbs 31264*u_k + 256*u_{k-1}
+//     in the same step -- two extra multiply-accumulates per limb instead of separate shifts and 64-bit adds.
+// Every partial sum fits a u64 for mag(a)*mag(b) <= 7:  9 products <= 63.3*2^58, fold terms < 2^48, carry < 2^35.
+// Instruction budget per product: 81 + 18 v_mad_u64_u32, 18 v_and, 18 v_lshrrev_b64 and a ~10-instruction tail.
+S2K_HD void fe_mul_tail(fe& r, u64 c, u32 u8) {
+    u32 k256 = 256u; S2K_OPAQUE(k256);
+    c += (u64)u8 * k256;                                     // everything of weight 2^261
+    const u64 hi = (u64)(r.n[8] >> 24) + (c << 5);           // everything >= 2^256, in units of 2^256 (< 2^46)
     r.n[8] &= FE_TOPM;
-    u32 hi_lo = (u32)hi, hi_hi = (u32)(hi >> 32);            // hi < 2^46
+    u32 hi_lo = (u32)hi, hi_hi = (u32)(hi >> 32);
     S2K_OPAQUE(hi_lo); S2K_OPAQUE(hi_hi);
-    u64 e = (u64)r.n[0] + (u64)hi_lo * 977u + ((u64)(hi_hi * 977u) << 32);
+    u64 e = (u64)r.n[0] + (u64)hi_lo * 977u + ((u64)(hi_hi * 977u) << 32);     // 2^256 == 2^32 + 977
     r.n[0] = (u32)e & FE_M; e >>= FE_BITS;
     e += (u64)r.n[1] + (hi << 3);
     r.n[1] = (u32)e & FE_M; e >>= FE_BITS;
     r.n[2] += (u32)e;
 }
-// r = a*b; needs mag(a)*mag(b) <= 7.  (role of secp256k1_fe_mul_inner, field_5x52_int128_impl.h:18-152)
+// r = a*b; needs mag(a)*mag(b) <= 7.
 S2K_HD void fe_mul(fe& r, const fe& a_in, const fe& b_in) {
-    u32 t[18];
-    u64 c = 0;
-    fe a = a_in, b = b_in;
+    u32 a[FE_LIMBS], b[FE_LIMBS];
 #pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) { S2K_OPAQUE(a.n[i]); S2K_OPAQUE(b.n[i]); }
+    for (int i = 0; i < FE_LIMBS; i++) { a[i] = a_in.n[i]; b[i] = b_in.n[i]; }
+    S2K_OPAQUE(a[8]); S2K_OPAQUE(b[8]);          // the only limbs whose range (< 2^24) the optimiser can prove: see S2K_OPAQUE
+    u32 k256 = 256u; S2K_OPAQUE(k256);           // keeps "x * 256 + acc" one v_mad_u64_u32 instead of a 64-bit shift and add
+    u64 c = 0, d = 0; u32 u = 0, uprev = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 0; k < FE_LIMBS; k++) {
+        if (k < 8) {
+#pragma unroll
+            for (int i = 0; i < FE_LIMBS; i++) {
+                const int j = 9 + k - i;
+                if (j < 0 || j >= FE_LIMBS) continue;
+                S2K_CHECK(d + (u64)a[i] * b[j] >= d);
+                d += (u64)a[i] * b[j];
+            }
+            u = (u32)d & FE_M; d >>= FE_BITS;
+        } else {
+            S2K_CHECK((d >> 32) == 0);
+            u = (u32)d;                           // what is left of the high chain (< 7*2^29)
+        }
 #pragma unroll
         for (int i = 0; i < FE_LIMBS; i++) {
             const int j = k - i;
             if (j < 0 || j >= FE_LIMBS) continue;
-            S2K_CHECK(c + (u64)a.n[i] * b.n[j] >= c);
-            c += (u64)a.n[i] * b.n[j];
+            S2K_CHECK(c + (u64)a[i] * b[j] >= c);
+            c += (u64)a[i] * b[j];
         }
-        t[k] = (u32)c & FE_M;
-        c >>= FE_BITS;
+        S2K_CHECK(c + (u64)u * 31264u >= c);
+        c += (u64)u * 31264u;
+        if (k > 0) c += (u64)uprev * k256;
+        uprev = u;
+        r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
     }
-    t[17] = (u32)c;
-    fe_reduce18(r, t);
+    fe_mul_tail(r, c, u);                         // c: carry of weight 2^261; 256*u_8 has that weight too
 }
-// r = a^2; needs mag(a) <= 2.  (role of secp256k1_fe_sqr_inner :154-272)
+// r = a^2; needs mag(a) <= 2.
 S2K_HD void fe_sqr(fe& r, const fe& a_in) {
-    u32 t[18], a2[FE_LIMBS];
-    u64 c = 0;
-    fe a = a_in;
+    u32 a[FE_LIMBS], a2[FE_LIMBS];
 #pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) S2K_OPAQUE(a.n[i]);
+    for (int i = 0; i < FE_LIMBS; i++) a[i] = a_in.n[i];
+    S2K_OPAQUE(a[8]);
 #pragma unroll
-    for (int i = 0; i < FE_LIMBS; i++) { a2[i] = a.n[i] << 1; S2K_OPAQUE(a2[i]); }
+    for (int i = 0; i < FE_LIMBS; i++) { S2K_CHECK(a[i] < (1u << 31)); a2[i] = a[i] << 1; }
+    S2K_OPAQUE(a2[8]);
+    u32 k256 = 256u; S2K_OPAQUE(k256);
+    u64 c = 0, d = 0; u32 u = 0, uprev = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 0; k < FE_LIMBS; k++) {
+        if (k < 8) {
+#pragma unroll
+            for (int i = 0; i < FE_LIMBS; i++) {
+                const int j = 9 + k - i;
+                if (j < 0 || j >= FE_LIMBS || i > j) continue;
+                const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
+                S2K_CHECK(d + pr >= d);
+                d += pr;
+            }
+            u = (u32)d & FE_M; d >>= FE_BITS;
+        } else {
+            S2K_CHECK((d >> 32) == 0);
+            u = (u32)d;
+        }
 #pragma unroll
         for (int i = 0; i < FE_LIMBS; i++) {
             const int j = k - i;
             if (j < 0 || j >= FE_LIMBS || i > j) continue;
-            S2K_CHECK(a.n[i] < (1u << 31));
-            const u64 pr = (i == j) ? (u64)a.n[i] * a.n[i] : (u64)a2[i] * a.n[j];
+            const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
             S2K_CHECK(c + pr >= c);
             c += pr;
         }
-        t[k] = (u32)c & FE_M;
-        c >>= FE_BITS;
+        c += (u64)u * 31264u;
+        if (k > 0) c += (u64)uprev * k256;
+        uprev = u;
+        r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
     }
-    t[17] = (u32)c;
-    fe_reduce18(r, t);
+    fe_mul_tail(r, c, u);
 }
 
 // ---- exponentiation chains ------------------------------------------------------------------------
