@@ -41,7 +41,9 @@ S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
 // ptab (this lane's slice): entry e = 0..7 holds (2e+1)*P on the isomorphic curve: x[9] | y[9] | beta*x[9] | pad
 #define S2K_PTAB_ENTRIES 8
 #define S2K_PTAB_ENTRY_WORDS 28
-#define S2K_PTAB_WORDS (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)
+#define S2K_PTAB_ZISO (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)      // parked while the main loop runs, to keep VGPRs for arithmetic
+#define S2K_PTAB_NG (S2K_PTAB_ZISO + 9)
+#define S2K_PTAB_WORDS 256
 
 S2K_HD void ptab_store(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
@@ -144,11 +146,17 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
 #pragma unroll
         for (int i = 0; i < 5; i++) { const u32 t = h1.w[i] + c; c = (t < c); h1.w[i] = t; }
         digit_reg_init(dr0, h0.w); digit_reg_init(dr1, h1.w);
-        if (S2K_WAVE_ANY(p_active)) ptab_build(ziso, ptab, A);
-    }
-    u32 gw[8];                // ng, shifted right one 16-bit window per generator addition
+        if (S2K_WAVE_ANY(p_active)) {
+            ptab_build(ziso, ptab, A);
 #pragma unroll
-    for (int i = 0; i < 8; i++) gw[i] = ng.d[i];
+            for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) ptab[S2K_PTAB_NG + i] = ng.d[i];
+    u32 gw[8];                // ng, shifted right one 16-bit window per generator addition; loaded when the G phase starts
+#pragma unroll
+    for (int i = 0; i < 8; i++) gw[i] = 0;
 
     // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
     int a = p_active ? 0 : S2K_ADD_G0;
@@ -171,6 +179,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             ptab_fetch(dst, ptab, _v, _h, _flip);                                                                   \
         }                                                                                                           \
         else if (_i < S2K_ADDS_TOTAL) {                                                                             \
+            if (_i == S2K_ADD_G0) { _Pragma("unroll") for (int _k = 0; _k < 8; _k++) gw[_k] = ptab[S2K_PTAB_NG + _k]; } \
             const u32 _v = gw[0] & 0xFFFFu;                                                                         \
             _Pragma("unroll") for (int _k = 0; _k < 7; _k++) gw[_k] = (gw[_k] >> 16) | (gw[_k + 1] << 16);          \
             gw[7] >>= 16;                                                                                           \
@@ -204,7 +213,10 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         // leaving the isomorphic curve: after the skew corrections, before the generator additions
         const int fix = (!done) & (!zfixed) & (a == S2K_ADD_G0) & (!pending);
         if (S2K_WAVE_ANY(fix)) {
-            fe z; fe_mul(z, R.z, ziso);
+            fe zi;
+#pragma unroll
+            for (int i = 0; i < 9; i++) zi.n[i] = ptab[S2K_PTAB_ZISO + i];
+            fe z; fe_mul(z, R.z, zi);
             if (fix) { R.z = z; zfixed = 1; }
         }
         if ((a >= a_end) & (!pending) & zfixed) done = 1;

@@ -272,14 +272,15 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
     for (int i = 0; i < 8; i++) out[i] = st[i];
 }
 
-S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
+S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
                     const unsigned char* proof, u32 ring, int live, const u32* gtab, u32* ptab) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
-    u32 m[8], e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+    u32 e[8];
     {
+        u32 m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] = rec.m[i];
         u32 e0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ok) {                                   // never touch proof bytes of a proof that failed its structural checks
             const unsigned char* pe0 = proof + rec.off_e0;
@@ -288,9 +289,8 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsi
         }
         rp_hash_e0(e, e0, m, ring);
     }
-    gej pub, base;
-    gej_load28_h(pub, pub28);
-    gej_load28_h(base, base28);
+    // Nothing but flags and pointers stays live across ecmult_lane: the ring key is re-read from its scratch record and the
+    // next key (key + base, pub_expand :43-45) is written back there before the multiplication starts.
     u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
 #pragma unroll 1
     for (u32 j = 0; j < 4; j++) {
@@ -299,8 +299,14 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsi
         rp_words_to_scalar(ens, ov_e, e);
         sc_set_zero(s);
         if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);
+        gej pub; gej_load28_h(pub, pub28);
         int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens) & !pub.inf;
         if (!good) { sc_set_zero(ens); sc_set_zero(s); }            // dead lanes ride along with empty work
+        if (j + 1 < rsize) {
+            gej base, nxt; gej_load28_h(base, base28);
+            gej_add_var(nxt, pub, base);
+            if (live) gej_store28_h(pub28, nxt);
+        }
         gej R;
         ecmult_lane(R, pub, ens, s, 1, gtab, ptab);
         good &= !R.inf;
@@ -312,8 +318,10 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, const u32* pub28, unsi
         const u32 prefix = 2u | (u32)fe_is_odd(a.y);
         if (step_live) ok &= good;
         if (j + 1 < rsize) {
+            u32 m[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] = rec.m[i];
             rp_hash_step(e, prefix, xb, m, ring, j + 1);
-            gej nxt; gej_add_var(nxt, pub, base); pub = nxt;
         } else if (j + 1 == rsize) {
 #pragma unroll
             for (int i = 0; i < 8; i++) outx[i] = xb[i];
