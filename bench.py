@@ -113,9 +113,16 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # one process per GPU over RCCL ("nccl"); S2K_DIST_BACKEND=gloo lets the N>1 code path be exercised on a box with
+    # fewer GPUs than ranks (ranks then share devices) -- for testing only, never for reported numbers
+    backend = os.environ.get("S2K_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from secp256k1_zkp_amd import Engine
     eng = Engine(local)
     torch.cuda.set_device(local)
@@ -194,7 +201,7 @@ def main():
             "metric": "64-bit Borromean rangeproof verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit), 32x32->64 integer MAC", "data": data_desc,
-            "config": {"workload": "secp256k1_rangeproof_verify, batch of 2^14 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)",
+            "config": {"workload": "secp256k1_rangeproof_verify, batch of %d 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)" % n,
                        "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)"},
             "roofline": {"bound": "hbm", "kernel": "k_rp_rings", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kms,

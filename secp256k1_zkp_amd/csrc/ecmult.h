@@ -188,6 +188,11 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
     } while (0)
     if (a < a_end) S2K_FETCH(cur, cur_valid, a);
     gej_set_infinity(R);
+    if (p_active) {                                 // addition 0 would add the top digit of half 0 to infinity: just take it
+        gej_set_ge(R, cur);
+        a = 1;
+        S2K_FETCH(cur, cur_valid, a);
+    }
     int done = !(a < a_end);
     while (S2K_WAVE_ANY(!done)) {
         int do_dbl = 0, do_add = 0;
