@@ -38,14 +38,18 @@ S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
 }
 
 // ---- per-lane table of odd multiples ----------------------------------------------------------------------
-// ptab (this lane's slice): entry e = 0..7 holds (2e+1)*P on the isomorphic curve: x[9] | y[9] | beta*x[9] | pad
+// ptab (this lane's slice of HBM, 128-byte aligned): entry e = 0..7 holds (2e+1)*P on the isomorphic curve as two
+// 64-byte sectors of canonical 8x32-bit words,  [ x | y ]  and  [ beta*x | y ] , so that an operand for either GLV half
+// is exactly ONE aligned 64-byte gather (the per-lane tables of all resident waves live in the Infinity Cache, not L2:
+// every gather crosses the fabric, so sectors are what is paid for).  During construction the same 128 bytes hold the
+// 27 limbs (x, y, z-ratio) of the not-yet-rescaled entry.
 #define S2K_PTAB_ENTRIES 8
-#define S2K_PTAB_ENTRY_WORDS 28
+#define S2K_PTAB_ENTRY_WORDS 32
 #define S2K_PTAB_ZISO (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)      // parked while the main loop runs, to keep VGPRs for arithmetic
 #define S2K_PTAB_NG (S2K_PTAB_ZISO + 9)
-#define S2K_PTAB_WORDS 256
+#define S2K_PTAB_WORDS 288
 
-S2K_HD void ptab_store(u32* e, const fe& x, const fe& y, const fe& third) {
+S2K_HD void ptab_store_raw(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
     for (int i = 0; i < 9; i++) { e[i] = x.n[i]; e[9 + i] = y.n[i]; e[18 + i] = third.n[i]; }
 }
@@ -59,16 +63,16 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
     { fe x = A.x, y = A.y; fe_norm_weak(x); fe_norm_weak(y); fe_mul(cur.x, x, c2); fe_mul(cur.y, y, c3); }
     cur.z = A.z; cur.inf = 0;
     ge dd; dd.x = d.x; dd.y = d.y; fe_norm_weak(dd.x); fe_norm_weak(dd.y);
-    { fe one; fe_set_int(one, 1); ptab_store(ptab, cur.x, cur.y, one); }
+    { fe one; fe_set_int(one, 1); ptab_store_raw(ptab, cur.x, cur.y, one); }
     for (int i = 1; i < S2K_PTAB_ENTRIES; i++) {
         gej nxt; fe h;
         gej_add_ge(nxt, cur, dd, &h);
         fe_norm_weak(nxt.y);
-        ptab_store(ptab + i * S2K_PTAB_ENTRY_WORDS, nxt.x, nxt.y, h);     // third slot: z ratio, replaced by beta*x below
+        ptab_store_raw(ptab + i * S2K_PTAB_ENTRY_WORDS, nxt.x, nxt.y, h);     // third slot: z ratio of this step
         cur = nxt;
     }
     fe_mul(ziso, cur.z, d.z);
-    // bring every entry to the Z of the last one (secp256k1_ge_table_set_globalz, group_impl.h:289-320), then beta*x
+    // bring every entry to the Z of the last one (secp256k1_ge_table_set_globalz, group_impl.h:289-320), then pack
     fe zs; fe_set_int(zs, 1);
     for (int i = S2K_PTAB_ENTRIES - 1; i >= 0; i--) {
         u32* e = ptab + i * S2K_PTAB_ENTRY_WORDS;
@@ -80,7 +84,11 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
             fe_mul(x, x, zs2); fe_mul(y, y, zs3);
         }
         fe_mul(bx, x, beta);
-        ptab_store(e, x, y, bx);
+        fe_normalize(x); fe_normalize(y); fe_normalize(bx);
+        u32 wx[8], wy[8], wb[8];
+        fe_to_words(wx, x); fe_to_words(wy, y); fe_to_words(wb, bx);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { e[k] = wx[k]; e[8 + k] = wy[k]; e[16 + k] = wb[k]; e[24 + k] = wy[k]; }
         fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
     }
 }
@@ -88,10 +96,12 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
 S2K_HD void ptab_fetch(ge& o, const u32* ptab, u32 v, int half, int sign_flip) {
     const int neg = (v < 8u) ^ sign_flip;
     const u32 idx = (v < 8u) ? (7u - v) : (v - 8u);
-    const u32* e = ptab + idx * S2K_PTAB_ENTRY_WORDS;
-    fe y;
+    const u32* e = ptab + idx * S2K_PTAB_ENTRY_WORDS + (half ? 16 : 0);
+    u32 w[16];
 #pragma unroll
-    for (int k = 0; k < 9; k++) { o.x.n[k] = half ? e[18 + k] : e[k]; y.n[k] = e[9 + k]; }
+    for (int k = 0; k < 16; k++) w[k] = e[k];
+    fe y;
+    fe_from_words(o.x, w); fe_from_words(y, w + 8);
     fe yn; fe_neg(yn, y, 1);
     fe_select(o.y, yn, y, neg);
 }
