@@ -104,6 +104,18 @@ S2K_API int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value
                                             const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
                                             size_t extra_commit_len, const void* gen);
 
+/* ---- surjection-proof batch verification -----------------------------------------------------------------------------
+ * results[i] = secp256k1_surjectionproof_parse(ctx, &proof, ser_i, len_i) &&
+ *              secp256k1_surjectionproof_verify(ctx, &proof, ephemeral_input_tags_i, n_i, &ephemeral_output_tag_i)
+ *                                       (include/secp256k1_surjectionproof.h, src/modules/surjection/main_impl.h:45-82,360-402)
+ * proofs: serialised proofs back to back with proof_off[n+1]; input_tags64: all items' input generators (64-byte
+ * secp256k1_generator objects) back to back with tag_off[n+1] counted in tags; output_tags64: n*64. */
+S2K_API int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off,
+                                                   const unsigned char* input_tags64, const uint64_t* tag_off, const unsigned char* output_tags64, size_t n);
+S2K_API int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* proofs,
+                                                       const uint64_t* proof_off, const unsigned char* input_tags64, const uint64_t* tag_off,
+                                                       const unsigned char* output_tags64, size_t n);
+
 /* ---- Bulletproofs++ norm-argument batch verification ---------------------------------------------------------------
  * results[i] = secp256k1_bppp_rangeproof_norm_product_verify(ctx, scratch, proof_i, proof_len, &transcript_i, &rho_i,
  *                                       g_vec, g_len, c_vec_i, c_vec_len, &commit_i)

@@ -344,3 +344,46 @@ REF_EXPORT int ref_schnorrsig_make_many(unsigned char *sigs64, unsigned char *pk
     secp256k1_context_destroy(ctx);
     return ok;
 }
+
+/* ---------- surjection proofs (src/modules/surjection/main_impl.h) ---------- */
+#include "../include/secp256k1_surjectionproof.h"
+/* parse + verify on the wire format; tags are 64-byte secp256k1_generator objects */
+REF_EXPORT int ref_surjectionproof_verify_ser(const unsigned char *proof_ser, size_t len, const unsigned char *in_tags64, size_t n_tags, const unsigned char *out_tag64) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    secp256k1_surjectionproof proof; secp256k1_generator *tags = (secp256k1_generator *)malloc((n_tags ? n_tags : 1) * sizeof(secp256k1_generator)), out; size_t i; int ret = 0;
+    for (i = 0; i < n_tags; i++) memcpy(tags[i].data, in_tags64 + 64 * i, 64);
+    memcpy(out.data, out_tag64, 64);
+    if (secp256k1_surjectionproof_parse(ctx, &proof, proof_ser, len)) ret = secp256k1_surjectionproof_verify(ctx, &proof, tags, n_tags, &out);
+    free(tags); secp256k1_context_destroy(ctx);
+    return ret;
+}
+/* synthesise one proof the way the reference's tests do (tests_impl.h:300-340): n_inputs blinded asset tags, the output
+ * re-blinds input `which`; returns serialised proof length (0 on failure) and the ephemeral tags (64 bytes each) */
+REF_EXPORT size_t ref_surjection_make(unsigned char *proof_ser, size_t max_len, unsigned char *in_tags64, unsigned char *out_tag64,
+                                      const unsigned char *seed32, size_t n_inputs, size_t n_used, size_t which) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    secp256k1_fixed_asset_tag *fixed = (secp256k1_fixed_asset_tag *)malloc(n_inputs * sizeof(*fixed)), fixed_out;
+    secp256k1_generator *eph = (secp256k1_generator *)malloc(n_inputs * sizeof(*eph)), eph_out;
+    unsigned char *blinds = (unsigned char *)malloc(32 * n_inputs), out_blind[32], h[32];
+    secp256k1_surjectionproof proof; size_t i, input_index, len = max_len; int ok = 1;
+    for (i = 0; i < n_inputs; i++) {
+        secp256k1_sha256 s; unsigned char t[40]; memcpy(t, seed32, 32); t[32] = (unsigned char)i; t[33] = (unsigned char)(i >> 8); t[34] = 1;
+        secp256k1_sha256_initialize(&s); secp256k1_sha256_write(secp256k1_get_hash_context(ctx), &s, t, 35); secp256k1_sha256_finalize(secp256k1_get_hash_context(ctx), &s, fixed[i].data);
+        t[34] = 2;
+        secp256k1_sha256_initialize(&s); secp256k1_sha256_write(secp256k1_get_hash_context(ctx), &s, t, 35); secp256k1_sha256_finalize(secp256k1_get_hash_context(ctx), &s, blinds + 32 * i);
+        blinds[32 * i] &= 0x7F;
+        ok &= secp256k1_generator_generate_blinded(ctx, &eph[i], fixed[i].data, blinds + 32 * i);
+    }
+    { secp256k1_sha256 s; unsigned char t[40]; memcpy(t, seed32, 32); t[32] = 0xFF; t[33] = 0xFF; t[34] = 3;
+      secp256k1_sha256_initialize(&s); secp256k1_sha256_write(secp256k1_get_hash_context(ctx), &s, t, 35); secp256k1_sha256_finalize(secp256k1_get_hash_context(ctx), &s, out_blind); out_blind[0] &= 0x7F; }
+    fixed_out = fixed[which];
+    ok &= secp256k1_generator_generate_blinded(ctx, &eph_out, fixed_out.data, out_blind);
+    memcpy(h, seed32, 32);
+    ok = ok && secp256k1_surjectionproof_initialize(ctx, &proof, &input_index, fixed, n_inputs, n_used, &fixed_out, 1000000, h);
+    ok = ok && secp256k1_surjectionproof_generate(ctx, &proof, eph, n_inputs, &eph_out, input_index, blinds + 32 * input_index, out_blind);
+    ok = ok && secp256k1_surjectionproof_serialize(ctx, proof_ser, &len, &proof);
+    for (i = 0; i < n_inputs; i++) memcpy(in_tags64 + 64 * i, eph[i].data, 64);
+    memcpy(out_tag64, eph_out.data, 64);
+    free(fixed); free(eph); free(blinds); secp256k1_context_destroy(ctx);
+    return ok ? len : 0;
+}

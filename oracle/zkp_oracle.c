@@ -600,6 +600,34 @@ int zo_bppp_norm_verify(const unsigned char *proof, size_t proof_len, const unsi
     return ok;
 }
 
+/* ========================================================== surjection =================================================== */
+/* secp256k1_surjectionproof_parse + _verify on the wire format (modules/surjection/main_impl.h:45-82,360-402;
+ * surjection_impl.h:19-37 message, :66-95 public keys); tags are 64-byte generators x||y */
+int zo_surjectionproof_verify(const unsigned char *proof, size_t plen, const unsigned char *in_tags64, size_t n_tags, const unsigned char *out_tag64) {
+    size_t n_inputs, bm, n_used = 0, i, j = 0, rsizes[1]; const unsigned char *data; sha256 h; unsigned char m[32], t33[33];
+    static gej pubs[256]; static sc s[256]; ge out; int overflow;
+    if (plen < 2) return 0;
+    n_inputs = ((size_t)proof[1] << 8) + proof[0];
+    if (n_inputs > 256) return 0;
+    bm = (n_inputs + 7) / 8;
+    if (plen < 2 + bm) return 0;
+    if (n_inputs % 8 != 0 && (proof[2 + bm - 1] & (unsigned char)(0xFFu << (n_inputs % 8)))) return 0;
+    for (i = 0; i < bm; i++) { unsigned b = proof[2 + i]; while (b) { n_used += b & 1; b >>= 1; } }
+    if (plen != 2 + bm + 32 * (1 + n_used)) return 0;
+    if (n_used == 0 || n_used > n_inputs || n_inputs != n_tags) return 0;
+    data = proof + 2 + bm;
+    ge_from_b64(&out, out_tag64, 0);
+    for (i = 0; i < n_inputs; i++) {
+        if (proof[2 + i / 8] & (1 << (i % 8))) { ge tin; ge_from_b64(&tin, in_tags64 + 64 * i, 0); ge_neg(&tin, &tin); gej_set_ge(&pubs[j], &tin); gej_add_ge(&pubs[j], &pubs[j], &out); j++; }
+    }
+    for (i = 0; i < n_used; i++) { sc_set_b32(&s[i], data + 32 + 32 * i, &overflow); if (overflow) return 0; }
+    sha256_init(&h);
+    for (i = 0; i <= n_tags; i++) { const unsigned char *t = i < n_tags ? in_tags64 + 64 * i : out_tag64; t33[0] = 2 + (t[63] & 1); memcpy(t33 + 1, t, 32); sha256_write(&h, t33, 33); }
+    sha256_final(&h, m);
+    rsizes[0] = n_used;
+    return borromean_verify(data, s, pubs, rsizes, 1, m);
+}
+
 /* ======================================================= byte-level exports ============================================= */
 void zo_fe_mul(unsigned char *r, const unsigned char *a, const unsigned char *b) { fe x, y; fe_set_b32_mod(&x, a); fe_set_b32_mod(&y, b); fe_mul(&x, &x, &y); fe_get_b32(r, &x); }
 void zo_fe_inv(unsigned char *r, const unsigned char *a) { fe x; fe_set_b32_mod(&x, a); fe_inv(&x, &x); fe_get_b32(r, &x); }

@@ -22,4 +22,5 @@ ZO_API void zo_rangeproof_verify_many(int *results, uint64_t *min_v, uint64_t *m
 ZO_API int zo_schnorrsig_verify(const unsigned char *sig64, const unsigned char *msg, size_t msglen, const unsigned char *pk32);
 ZO_API int zo_bppp_norm_verify(const unsigned char *proof, size_t proof_len, const unsigned char *transcript104, const unsigned char *rho32,
                                const unsigned char *gens33, size_t n_gens, size_t g_len, const unsigned char *c_vec32, size_t c_len, const unsigned char *commit33);
+ZO_API int zo_surjectionproof_verify(const unsigned char *proof, size_t plen, const unsigned char *in_tags64, size_t n_tags, const unsigned char *out_tag64);
 #endif

@@ -33,6 +33,8 @@ SIGNATURES = {
     "secp256k1_rangeproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "secp256k1_surjectionproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
+    "secp256k1_surjectionproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "secp256k1_bppp_norm_product_verify_batch": (_c.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),
 }
 

@@ -141,6 +141,19 @@ class Engine:
                                                                      _dp(proofs), _dp(proof_off), _dp(extra), _dp(extra_off), _dp(gens64), n),
                     "secp256k1_rangeproof_verify_batch_dev")
 
+    # ---- secp256k1_surjectionproof_verify (modules/surjection/main_impl.h:360-402), batched ---------------------
+    def surjectionproof_verify_batch(self, proofs, input_tags, output_tags64):
+        """proofs: list of serialised proofs; input_tags: list of (k_i,64) uint8 arrays; output_tags64: (n,64)."""
+        data, off = self.pack(list(proofs))
+        n = off.size - 1
+        toff = np.zeros(n + 1, np.uint64)
+        toff[1:] = np.cumsum([np.asarray(t).size // 64 for t in input_tags], dtype=np.uint64)
+        tags = np.concatenate([_u8(t).reshape(-1) for t in input_tags] + [np.zeros(64, np.uint8)])
+        res = np.zeros(n, np.int32)
+        self._check(self._lib.secp256k1_surjectionproof_verify_batch(self._h, _p(res), _p(data), _p(off), _p(tags), _p(toff), _p(_u8(output_tags64)), n),
+                    "secp256k1_surjectionproof_verify_batch")
+        return res
+
     # ---- secp256k1_bppp_rangeproof_norm_product_verify (modules/bppp/bppp_norm_product_impl.h:425-552), batched --
     def bppp_norm_product_verify_batch(self, proofs, transcripts, rho, gens33, g_len, c_vec, commits33):
         proofs = _u8(proofs); n = _u8(rho).size // 32

@@ -10,6 +10,7 @@
 #include "schnorr.h"
 #include "msm.h"
 #include "bppp.h"
+#include "surjection.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -776,6 +777,57 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     hipLaunchKernelGGL(k_bp_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_res, sums, proof_ok, term_ok, gens_ok, (u32)T, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// surjection-proof batch verification (surjection.h): one proof per lane
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+k_sj_verify(int32_t* __restrict__ results, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off,
+            const unsigned char* __restrict__ in_tags, const uint64_t* __restrict__ tag_off, const unsigned char* __restrict__ out_tags,
+            const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int live = i < n;
+    const size_t ii = live ? i : 0;
+    const int r = sj_verify_lane(proofs + proof_off[ii], proof_off[ii + 1] - proof_off[ii], in_tags + 64 * tag_off[ii], tag_off[ii + 1] - tag_off[ii],
+                                 out_tags + 64 * ii, live, gtab, ptab + i * S2K_PTAB_WORDS);
+    if (live) results[i] = r;
+}
+extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* proofs,
+                                                          const uint64_t* proof_off, const unsigned char* input_tags64, const uint64_t* tag_off,
+                                                          const unsigned char* output_tags64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_surjectionproof_verify_batch_dev", "null engine");
+    if (n == 0) return 1;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if (!engine_ptab(e, ((n + 255) / 256) * 256)) return 0;
+    HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_sj_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, proofs, proof_off, input_tags64, tag_off, output_tags64, e->gtab, e->ptab, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off,
+                                                      const unsigned char* input_tags64, const uint64_t* tag_off, const unsigned char* output_tags64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_surjectionproof_verify_batch", "null engine");
+    if (n == 0) return 1;
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pbytes = (size_t)proof_off[n], ntags = (size_t)tag_off[n];
+    if (!engine_workspace(e, ws_need({4 * n, pbytes + 64, 8 * (n + 1), 64 * ntags + 64, 8 * (n + 1), 64 * n}))) return 0;
+    ws_carver w{e->ws, 0};
+    int32_t* d_res = w.take<int32_t>(n); unsigned char* d_pr = w.take<unsigned char>(pbytes + 64); uint64_t* d_po = w.take<uint64_t>(n + 1);
+    unsigned char* d_in = w.take<unsigned char>(64 * ntags + 64); uint64_t* d_to = w.take<uint64_t>(n + 1); unsigned char* d_out = w.take<unsigned char>(64 * n);
+    hipStream_t st = e->stream;
+    if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_po, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    if (ntags) HIPCHK(hipMemcpyAsync(d_in, input_tags64, 64 * ntags, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_to, tag_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_out, output_tags64, 64 * n, hipMemcpyHostToDevice, st));
+    if (!secp256k1_surjectionproof_verify_batch_dev(e, nullptr, d_res, d_pr, d_po, d_in, d_to, d_out, n)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;

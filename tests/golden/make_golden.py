@@ -112,7 +112,32 @@ def bip340():
     print("bip340:", len(vecs), "vectors", [v["result"] for v in vecs], "msg lens", sorted(set(len(v["msg"]) // 2 for v in vecs)))
 
 
+def surjection():
+    """src/modules/surjection/tests_impl.h:488-632: 5 accepted proofs over up to 5 fixed input tags + the rejection cases."""
+    path = os.path.join(REF, "src/modules/surjection/tests_impl.h")
+    text = open(path).read()
+    a = text.index("static void test_fixed_vectors(void)")
+    arrs = {n: v for n, v, _ in c_arrays(text[a:])}
+    tags = [arrs["tag%d_ser" % i].hex() for i in range(5)]
+    vecs = []
+    for name, n_in in (("total1_used1", 1), ("total2_used1", 2), ("total3_used2", 3), ("total5_used3", 5), ("total5_used5", 5)):
+        vecs.append(dict(name=name, proof=arrs[name].hex(), n_inputs=n_in, tag_first=0, output="out", result=1))
+    # "check invalid keys fail" (:611-613)
+    vecs.append(dict(name="total1_used1_wrong_input", proof=arrs["total1_used1"].hex(), n_inputs=1, tag_first=1, output="out", result=0))
+    vecs.append(dict(name="total1_used1_wrong_output", proof=arrs["total1_used1"].hex(), n_inputs=1, tag_first=0, output="tag0", result=0))
+    # parse failures (:609, :616-632): wrong length, extra / missing / out-of-range bitmap bits
+    t55 = bytearray(arrs["total5_used5"]); t53 = bytearray(arrs["total5_used3"])
+    vecs.append(dict(name="total5_used5_truncated", proof=bytes(t55[:len(t53)]).hex(), n_inputs=5, tag_first=0, output="out", result=0))
+    for nm, base, val, extra in (("t55_6bits", t55, 0x3f, 0), ("t55_6bits_len", t55, 0x3f, 32), ("t55_bit_off", t55, 0x37, 0),
+                                 ("t53_4bits", t53, 0x35, 0), ("t53_4bits_len", t53, 0x35, 32), ("t53_oor", t53, 0x34, 0)):
+        b = bytearray(base); b[2] = val
+        vecs.append(dict(name=nm, proof=(bytes(b) + b"\0" * extra).hex(), n_inputs=5, tag_first=0, output="out", result=0))
+    json.dump(dict(source="src/modules/surjection/tests_impl.h:488-632", tags33=tags, output_tag33=arrs["output_tag_ser"].hex(), vectors=vecs),
+              open(os.path.join(OUT, "surjection_vectors.json"), "w"), indent=0)
+    print("surjection:", len(vecs), "vectors")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at " + REF)
-    rangeproof(); bppp(); bip340()
+    rangeproof(); bppp(); bip340(); surjection()

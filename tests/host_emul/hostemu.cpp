@@ -10,6 +10,7 @@
 #include "../../secp256k1_zkp_amd/csrc/schnorr.h"
 #include "../../secp256k1_zkp_amd/csrc/msm.h"
 #include "../../secp256k1_zkp_amd/csrc/bppp.h"
+#include "../../secp256k1_zkp_amd/csrc/surjection.h"
 #include <string.h>
 #include <vector>
 
@@ -208,5 +209,9 @@ int emu_gej_sum(unsigned char* r64, const u32* gej28, size_t count) {
     gej acc; gej_set_infinity(acc);
     for (size_t i = 0; i < count; i++) { gej v, s; gej_load28_h(v, gej28 + 28 * i); gej_add_var(s, acc, v); acc = s; }
     return gej_to_b64(r64, acc);
+}
+
+int emu_surjection_verify(const unsigned char* proof, size_t plen, const unsigned char* in_tags64, size_t n_tags, const unsigned char* out_tag64) {
+    return sj_verify_lane(proof, plen, in_tags64, n_tags, out_tag64, 1, gtab_host(), g_ptab);
 }
 }

@@ -144,3 +144,29 @@ class Ref:
                                                    _p(np.ascontiguousarray(rhos[i])), _p(gens), ctypes.c_size_t(gens.shape[0]), ctypes.c_size_t(g_len),
                                                    _p(np.ascontiguousarray(cvs[i])), ctypes.c_size_t(h_len), _p(np.ascontiguousarray(commits[i])))
         return res
+
+    # --- surjection proofs
+    def make_surjection(self, rng, n_inputs, n_used, which=None):
+        """one valid proof (reference prover): returns (serialised proof bytes, in_tags (n_inputs,64) uint8, out_tag (64,) uint8)"""
+        which = int(rng.integers(0, n_inputs)) if which is None else which
+        seed = rng.integers(0, 256, 32, dtype=np.uint8)
+        buf = np.zeros(2 + 32 + 32 * 257 + 8, np.uint8); tags = np.zeros((n_inputs, 64), np.uint8); out = np.zeros(64, np.uint8)
+        self.lib.ref_surjection_make.restype = ctypes.c_size_t
+        ln = self.lib.ref_surjection_make(_p(buf), ctypes.c_size_t(buf.size), _p(tags), _p(out), _p(seed), ctypes.c_size_t(n_inputs), ctypes.c_size_t(n_used),
+                                          ctypes.c_size_t(which))
+        assert ln > 0
+        return buf[:ln].tobytes(), tags, out
+
+    def surjection_verify(self, proof, tags, out):
+        tags = np.ascontiguousarray(tags, np.uint8)
+        return self.lib.ref_surjectionproof_verify_ser(proof, ctypes.c_size_t(len(proof)), _p(tags), ctypes.c_size_t(tags.size // 64), _p(np.ascontiguousarray(out, np.uint8)))
+
+
+def lift_generator33(ser33):
+    """33-byte serialised generator (0x0a/0x0b || x) -> 64-byte x||y object (secp256k1_generator_parse, generator/main_impl.h:62-80)"""
+    x = int.from_bytes(ser33[1:], "big")
+    y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
+    assert y * y % P == (x * x * x + 7) % P and (ser33[0] & 0xFE) == 10
+    if ser33[0] & 1:
+        y = (P - y) % P
+    return x.to_bytes(32, "big") + y.to_bytes(32, "big")

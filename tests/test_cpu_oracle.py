@@ -191,6 +191,19 @@ def test_emu_bppp(emu, ref):
     assert list(exp) == [1, 0, 1]
 
 
+def test_emu_surjection(emu, ref):
+    from tests.test_cpu_restatement import _sj_golden
+    for name, proof, ins, n_in, out, result in _sj_golden():
+        assert emu.emu_surjection_verify(proof, ctypes.c_size_t(len(proof)), ins, ctypes.c_size_t(n_in), out) == result, name
+    rng = np.random.default_rng(42)
+    for (n_in, n_used) in ((1, 1), (3, 2), (9, 3)):
+        proof, tags, out = ref.make_surjection(rng, n_in, n_used)
+        assert emu.emu_surjection_verify(proof, ctypes.c_size_t(len(proof)), tags.tobytes(), ctypes.c_size_t(n_in), out.tobytes()) == 1
+        for k in range(3):
+            p = bytearray(proof); p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8)); p = bytes(p)
+            assert emu.emu_surjection_verify(p, ctypes.c_size_t(len(p)), tags.tobytes(), ctypes.c_size_t(n_in), out.tobytes()) == ref.surjection_verify(p, tags, out)
+
+
 # ---- (3) the C ABI ---------------------------------------------------------------------------------------------------------
 def test_abi_symbols_and_loud_failure():
     from secp256k1_zkp_amd import _native

@@ -122,3 +122,34 @@ def test_vs_reference_protocols(zo, ref):
     got = [zo.zo_bppp_norm_verify(proofs[i].tobytes(), ctypes.c_size_t(proofs.shape[1]), trs[i].tobytes(), rhos[i].tobytes(), gens.tobytes(),
                                   ctypes.c_size_t(gens.shape[0]), ctypes.c_size_t(gl), cvs[i].tobytes(), ctypes.c_size_t(cvs.shape[1]), commits[i].tobytes()) for i in range(3)]
     assert got == list(exp) == [1, 0, 1]
+
+
+def _sj_golden():
+    from tests.refapi import lift_generator33
+    g = _golden("surjection_vectors.json")
+    tags = [lift_generator33(bytes.fromhex(t)) for t in g["tags33"]]
+    out = lift_generator33(bytes.fromhex(g["output_tag33"]))
+    cases = []
+    for v in g["vectors"]:
+        ins = b"".join(tags[v["tag_first"]:v["tag_first"] + v["n_inputs"]])
+        cases.append((v["name"], bytes.fromhex(v["proof"]), ins, v["n_inputs"], out if v["output"] == "out" else tags[0], v["result"]))
+    return cases
+
+
+def test_golden_surjection(zo, ref):
+    for name, proof, ins, n_in, out, result in _sj_golden():
+        assert zo.zo_surjectionproof_verify(proof, ctypes.c_size_t(len(proof)), ins, ctypes.c_size_t(n_in), out) == result, name
+        assert ref.lib.ref_surjectionproof_verify_ser(proof, ctypes.c_size_t(len(proof)), ins, ctypes.c_size_t(n_in), out) == result, name
+
+
+def test_surjection_vs_reference(zo, ref):
+    rng = np.random.default_rng(41)
+    for (n_in, n_used) in ((1, 1), (3, 1), (3, 3), (8, 3), (20, 5)):
+        proof, tags, out = ref.make_surjection(rng, n_in, n_used)
+        assert ref.surjection_verify(proof, tags, out) == 1
+        assert zo.zo_surjectionproof_verify(proof, ctypes.c_size_t(len(proof)), tags.tobytes(), ctypes.c_size_t(n_in), out.tobytes()) == 1
+        for k in range(4):
+            p = bytearray(proof); p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8)); p = bytes(p)
+            t2 = tags.copy()
+            if k == 3: p = proof; t2[0, 40] ^= 1
+            assert zo.zo_surjectionproof_verify(p, ctypes.c_size_t(len(p)), t2.tobytes(), ctypes.c_size_t(n_in), out.tobytes()) == ref.surjection_verify(p, t2, out)
