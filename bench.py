@@ -127,9 +127,24 @@ def main():
     eng = Engine(local)
     torch.cuda.set_device(local)
     n = args.batch
-    commits, proofs, gens, data_desc, ref = make_inputs(n, seed=1234 + rank)
-    pdata, poff = Engine.pack(proofs)
     dev = torch.device("cuda", local)
+    if world > 1 and n % world == 0:
+        # signing 2^14 proofs costs ~10 s of host CPU: every rank signs n/world of them and the pieces are all-gathered, so
+        # that each rank ends up with the same n unique proofs (its replica of the batch) without N-fold host work
+        nl = n // world
+        c_l, p_l, g_l, data_desc, ref = make_inputs(nl, seed=1234 + rank)
+        plen = len(p_l[0]); assert all(len(p) == plen for p in p_l)
+        loc = torch.tensor(np.concatenate([np.ascontiguousarray(c_l).reshape(nl, 33), np.frombuffer(b"".join(p_l), np.uint8).reshape(nl, plen),
+                                           np.ascontiguousarray(g_l).reshape(nl, 64)], axis=1)).to(dev)
+        parts = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(parts, loc)
+        allr = torch.cat(parts).reshape(n, 33 + plen + 64).cpu().numpy()
+        commits = np.ascontiguousarray(allr[:, :33]); gens = np.ascontiguousarray(allr[:, 33 + plen:])
+        proofs = [allr[i, 33:33 + plen].tobytes() for i in range(n)]
+        data_desc = data_desc.replace("%d unique" % nl, "%d unique" % n)
+    else:
+        commits, proofs, gens, data_desc, ref = make_inputs(n, seed=1234 + rank)
+    pdata, poff = Engine.pack(proofs)
     d_commits = torch.tensor(commits).to(dev); d_gens = torch.tensor(np.ascontiguousarray(gens)).to(dev)
     d_proofs = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
     d_res = torch.zeros(n, dtype=torch.int32, device=dev); d_min = torch.zeros(n, dtype=torch.int64, device=dev); d_max = torch.zeros(n, dtype=torch.int64, device=dev)
