@@ -14,6 +14,7 @@
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,7 +48,8 @@ struct s2k_engine {
     size_t ptab_lanes;
     hipEvent_t ev[4];          // [0],[1] whole call; [2],[3] dominant kernel
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
-    std::mutex mu;
+    size_t max_lanes;          // lanes per launch (multiple of 256)
+    std::recursive_mutex mu;
 };
 
 // per-lane table scratch for `lanes` concurrent ecmult_lane callers (lane = global thread index of the launch)
@@ -61,6 +63,9 @@ static int engine_ptab(s2k_engine* e, size_t lanes) {
     e->ptab_lanes = lanes;
     return 1;
 }
+// Upper bound on lanes per launch: keeps the per-lane table arena at 1.2 GB however large the batch is; bigger
+// batches run as several launches over sub-ranges (same stream, so the order of results is unaffected).
+// (engine field max_lanes; default 2^20, $S2K_MAX_LANES overrides it -- the tests use a small value to exercise the split)
 static int engine_workspace(s2k_engine* e, size_t bytes) {
     if (bytes <= e->ws_bytes) return 1;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -147,6 +152,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     s2k_engine* e = new s2k_engine();
     e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0;
     schnorr_tag_midstate(e->bip340);
+    e->max_lanes = size_t(1) << 20;
+    if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
     HIPCHK_NULL(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK_NULL(hipEventCreate(&e->ev[i]));
     HIPCHK_NULL(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
@@ -207,12 +214,16 @@ extern "C" int s2k_ecmult_batch_dev(s2k_engine* e, void* stream, unsigned char* 
     if (!e) return s2k_fail("s2k_ecmult_batch_dev", "null engine");
     if (n == 0) return 1;
     HIPCHK(hipSetDevice(e->device));
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (!engine_ptab(e, (size_t)blocks * 256)) return 0;
+    if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_ecmult_batch, dim3(blocks), dim3(256), 0, st, r_xy, r_inf, a_xy, a_inf, na, ng, e->gtab, e->ptab, n);
+    for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {
+        const size_t m = std::min(n - i0, e->max_lanes);
+        hipLaunchKernelGGL(k_ecmult_batch, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, r_xy + 64 * i0, r_inf + i0, a_xy + 64 * i0,
+                           a_inf ? a_inf + i0 : nullptr, na + 32 * i0, ng ? ng + 32 * i0 : nullptr, e->gtab, e->ptab, m);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], st));
     HIPCHK(hipEventRecord(e->ev[1], st));
@@ -222,7 +233,7 @@ extern "C" int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
                                 const unsigned char* a_inf, const unsigned char* na, const unsigned char* ng, size_t n) {
     if (!e) return s2k_fail("s2k_ecmult_batch", "null engine");
     if (n == 0) return 1;
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     if (!engine_workspace(e, ws_need({64 * n, 4 * n, 64 * n, n, 32 * n, 32 * n}))) return 0;
     ws_carver w{e->ws, 0};
@@ -304,19 +315,25 @@ static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
     w.ring_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
 }
 // launches the five stages; `w` must already point into device memory
+#define RP_CHUNK (e->max_lanes / RP_MAX_RINGS)     /* proofs per launch group */
 static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
                      const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
-    const unsigned b64 = (unsigned)((n + 63) / 64), b256 = (unsigned)((n * 32 + 255) / 256);
-    if (!engine_ptab(e, (size_t)b256 * 256)) return 0;
+    if (!engine_ptab(e, ((std::min(n, RP_CHUNK) * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
-    hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
-    hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, n);
-    hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, n);
-    HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off, e->gtab, e->ptab, n);
-    HIPCHK(hipEventRecord(e->ev[3], st));
-    hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results, proofs, proof_off, n);
+    // the scratch records `w` hold one chunk; chunks run back to back on the stream and reuse them
+    for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
+        const size_t m = std::min(n - p0, RP_CHUNK);
+        const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
+        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value + p0, max_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
+                           extra_off ? extra_off + p0 : nullptr, gens64 + 64 * p0, m);
+        hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, m);
+        hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);
+        if (p0 == 0) HIPCHK(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m);
+        if (p0 == 0) HIPCHK(hipEventRecord(e->ev[3], st));
+        hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
@@ -326,10 +343,11 @@ extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream
                                                      const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
     if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_dev", "null engine");
     if (n == 0) return 1;
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
-    if (!engine_workspace(e, rp_ws_bytes(n))) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, n);
+    const size_t nw = std::min(n, RP_CHUNK);
+    if (!engine_workspace(e, rp_ws_bytes(nw))) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
     return rp_launch(e, stream ? (hipStream_t)stream : e->stream, w, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
 }
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
@@ -337,12 +355,13 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
                                                  const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
     if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch", "null engine");
     if (n == 0) return 1;
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
     const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n});
-    if (!engine_workspace(e, rp_ws_bytes(n) + io)) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, n);
+    const size_t nw = std::min(n, RP_CHUNK);
+    if (!engine_workspace(e, rp_ws_bytes(nw) + io)) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
     int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
     unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
     uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
@@ -400,10 +419,15 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
     if (!e) return s2k_fail("secp256k1_schnorrsig_verify_batch_dev", "null engine");
     if (n == 0) return 1;
     HIPCHK(hipSetDevice(e->device));
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    if (!engine_ptab(e, ((n + 255) / 256) * 256)) return 0;
+    if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_schnorr_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, e->bip340, sigs, msgs, msglen, pubkeys, pk_format, e->gtab, e->ptab, n);
+    for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {
+        const size_t m = std::min(n - i0, e->max_lanes);
+        hipLaunchKernelGGL(k_schnorr_verify, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, results + i0, e->bip340, sigs + 64 * i0, msgs + msglen * i0, msglen,
+                           pubkeys + (pk_format ? 64 : 32) * i0, pk_format, e->gtab, e->ptab, m);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
@@ -412,7 +436,7 @@ extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results
                                                  size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n) {
     if (!e) return s2k_fail("secp256k1_schnorrsig_verify_batch", "null engine");
     if (n == 0) return 1;
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t pkb = pk_format ? 64 : 32;
     if (!engine_workspace(e, ws_need({4 * n, 64 * n, msglen * n + 64, pkb * n}))) return 0;
@@ -630,7 +654,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
 extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
                                             const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
     if (!e) return s2k_fail("s2k_ecmult_multi_partial_dev", "null engine");
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const size_t nt = n + (g_sc ? 1 : 0);
@@ -646,7 +670,7 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
 extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
                                     const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
     if (!e) return s2k_fail("s2k_ecmult_multi_dev", "null engine");
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const size_t nt = n + (g_sc ? 1 : 0);
@@ -663,7 +687,7 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
 extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count) {
     if (!e) return s2k_fail("s2k_gej_sum_dev", "null engine");
     if (count == 0) return s2k_fail("s2k_gej_sum_dev", "count == 0");
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     if (!engine_workspace(e, ws_need({(count / 1024 + 64) * 28 * 4, (count / 1024 + 64) * 28 * 4}))) return 0;
@@ -744,7 +768,18 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     if (n == 0) return 1;
     bp_shape sh;
     if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { for (size_t i = 0; i < n; i++) results[i] = 0; return 1; }   // :446-461
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    {
+        const size_t per = std::max<size_t>(1, e->max_lanes / sh.n_terms);        // proofs per launch group
+        if (n > per) {
+            for (size_t p0 = 0; p0 < n; p0 += per) {
+                const size_t m = std::min(n - p0, per);
+                if (!secp256k1_bppp_norm_product_verify_batch(e, results + p0, proofs + p0 * proof_len, proof_len, transcripts + 104 * p0, rho + 32 * p0, gens33, n_gens,
+                                                              g_len, c_vec + 32 * c_vec_len * p0, c_vec_len, commits33 + 33 * p0, m)) return 0;
+            }
+            return 1;
+        }
+    }
     HIPCHK(hipSetDevice(e->device));
     const size_t T = sh.n_terms, nt = n * T;
     const size_t need = ws_need({4 * n, n * proof_len + 64, 104 * n, 32 * n, 33 * n_gens, 32 * c_vec_len * n, 33 * n, n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n,
@@ -802,10 +837,15 @@ extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* s
     if (!e) return s2k_fail("secp256k1_surjectionproof_verify_batch_dev", "null engine");
     if (n == 0) return 1;
     HIPCHK(hipSetDevice(e->device));
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    if (!engine_ptab(e, ((n + 255) / 256) * 256)) return 0;
+    if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_sj_verify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, results, proofs, proof_off, input_tags64, tag_off, output_tags64, e->gtab, e->ptab, n);
+    for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {     // offsets are absolute, so a sub-range only shifts the per-item arrays
+        const size_t m = std::min(n - i0, e->max_lanes);
+        hipLaunchKernelGGL(k_sj_verify, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, results + i0, proofs, proof_off + i0, input_tags64, tag_off + i0,
+                           output_tags64 + 64 * i0, e->gtab, e->ptab, m);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
@@ -814,7 +854,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* re
                                                       const unsigned char* input_tags64, const uint64_t* tag_off, const unsigned char* output_tags64, size_t n) {
     if (!e) return s2k_fail("secp256k1_surjectionproof_verify_batch", "null engine");
     if (n == 0) return 1;
-    std::lock_guard<std::mutex> lock(e->mu);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t pbytes = (size_t)proof_off[n], ntags = (size_t)tag_off[n];
     if (!engine_workspace(e, ws_need({4 * n, pbytes + 64, 8 * (n + 1), 64 * ntags + 64, 8 * (n + 1), 64 * n}))) return 0;
@@ -834,4 +874,4 @@ extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* re
 }
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
-extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
+extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::recursive_mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
