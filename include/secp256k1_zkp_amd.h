@@ -44,6 +44,8 @@ S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
 /* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
  * `which`: 0 = whole call, 1 = dominant kernel only.  Valid after s2k_engine_sync(). */
 S2K_API float s2k_engine_last_ms(s2k_engine* e, int which);
+/* 1 if the most recent bucket MSM on this engine overflowed a bucket region and re-sorted exactly (diagnostics / tests). */
+S2K_API int s2k_engine_last_msm_fallback(s2k_engine* e);
 
 /* ---- batch double multiplication ---------------------------------------------------------------------------
  * r[i] = na[i]*A[i] + ng[i]*G          replaces: static void secp256k1_ecmult(secp256k1_gej *r,

@@ -64,6 +64,10 @@ class Engine:
     def last_ms(self, which=0):
         return float(self._lib.s2k_engine_last_ms(self._h, which))
 
+    def last_msm_fallback(self):
+        """True if the most recent bucket MSM re-sorted exactly after a bucket region overflowed."""
+        return bool(self._lib.s2k_engine_last_msm_fallback(self._h))
+
     # ---- secp256k1_ecmult (src/ecmult.h:47), batched ------------------------------------------------------
     def ecmult_batch(self, a_xy, na, ng=None, a_inf=None):
         a_xy = _u8(a_xy); n = a_xy.size // 64

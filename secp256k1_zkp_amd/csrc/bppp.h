@@ -143,7 +143,7 @@ S2K_HD int bp_parse_one_of_points(ge& p, int& inf, const unsigned char* in65, in
 
 // One lane per (proof, term): returns the term's contribution (Jacobian) and whether its point parsed.
 S2K_HD int bp_term(gej& out, const bp_shape& sh, u32 t, const u32* term_sc, const u32* gens18, const unsigned char* proof,
-                   const unsigned char* commit33, int live, const u32* gtab, u32* ptab) {
+                   const unsigned char* commit33, int live, const u32* gtab, const lane_mem& lm) {
     scalar k, g; sc_set_zero(g);
     for (int i = 0; i < 8; i++) k.d[i] = term_sc[8 * t + i];
     gej A; gej_set_infinity(A);
@@ -163,6 +163,6 @@ S2K_HD int bp_term(gej& out, const bp_shape& sh, u32 t, const u32* term_sc, cons
         gej_set_ge(A, p); A.inf = inf | !ok;
     }
     if (!live) { sc_set_zero(k); sc_set_zero(g); gej_set_infinity(A); }
-    ecmult_lane(out, A, k, g, has_g, gtab, ptab);
+    ecmult_lane(out, A, k, g, has_g, gtab, lm);
     return ok;
 }

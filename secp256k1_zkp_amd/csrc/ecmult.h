@@ -113,6 +113,24 @@ S2K_HD void ptab_fetch(ge& o, const u32* ptab, u32 v, int half, int sign_flip) {
 #define S2K_WAVE_ANY(p) (p)
 #endif
 
+// Per-lane memory handed to ecmult_lane: the table slice in HBM and the digit stream in LDS.  The digit stream is what the
+// main loop would otherwise carry in ~18 registers (two 160-bit digit shift registers and the 256-bit generator scalar) and
+// spill around every point operation; in LDS it costs one ds_read per addition.  Word-major layout (word k of lane t at
+// [k * S2K_DIG_STRIDE + t]) keeps the accesses bank-conflict free.
+//   words 0..8 : 4-bit digit of addition a (2 <= a < 66) in nibble a & 7 of word a >> 3
+//   words 9..16: ng, 16-bit window g of the generator phase in half g & 1 of word 9 + (g >> 1)
+#define S2K_DIG_WORDS 17
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) u32* s2k_lds_ptr;
+#define S2K_DIG_STRIDE 256                  /* every kernel that calls ecmult_lane runs 256-lane workgroups */
+#define S2K_LANE_DIG(shared_array) ((s2k_lds_ptr)(shared_array) + threadIdx.x)
+#else
+typedef u32* s2k_lds_ptr;
+#define S2K_DIG_STRIDE 1
+#define S2K_LANE_DIG(array) (array)
+#endif
+struct lane_mem { u32* ptab; s2k_lds_ptr dig; };
+
 // 160-bit shift register holding a 129-bit magnitude: the next 4-bit digit window is always the top nibble
 struct digit_reg { u32 w[5]; };
 S2K_HD void digit_reg_init(digit_reg& r, const u32 k[5]) {          // k' << 31 : window of digit 31 (bits 125..128) at the top
@@ -138,10 +156,11 @@ S2K_HD u32 digit_reg_pop(digit_reg& r) {
 // R = na*A + ng*G for this lane.  A is Jacobian (A.inf allowed), ng may be absent (has_ng = 0).
 // gtab: generator table; ptab: this lane's private S2K_PTAB_WORDS-word slice of scratch memory.
 // R is returned on the real curve, magnitudes (<=5,<=3,1).
-S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng, int has_ng, const u32* gtab, u32* ptab) {
+S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng, int has_ng, const u32* gtab, const lane_mem& lm) {
+    u32* const ptab = lm.ptab; const s2k_lds_ptr dig = lm.dig;
     const int p_active = (!A.inf) & (!sc_is_zero(na));
     const int g_active = has_ng & (!sc_is_zero(ng));
-    digit_reg dr0, dr1; int hneg0, hneg1, skew0, skew1;
+    int hneg0, hneg1, skew0, skew1;
     fe ziso;
     {
         scalar k1s, k2s; half_scalar h0, h1;
@@ -155,7 +174,16 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         c = (u32)skew1;
 #pragma unroll
         for (int i = 0; i < 5; i++) { const u32 t = h1.w[i] + c; c = (t < c); h1.w[i] = t; }
-        digit_reg_init(dr0, h0.w); digit_reg_init(dr1, h1.w);
+        {
+            digit_reg dr0, dr1; digit_reg_init(dr0, h0.w); digit_reg_init(dr1, h1.w);
+            u32 dw[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) dw[i] = 0;
+#pragma unroll
+            for (int i = 2; i < S2K_ADDS_P; i++) { const u32 v = (i & 1) ? digit_reg_pop(dr1) : digit_reg_pop(dr0); dw[i >> 3] |= v << ((i & 7) * 4); }
+#pragma unroll
+            for (int i = 0; i < 9; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
+        }
         if (S2K_WAVE_ANY(p_active)) {
             ptab_build(ziso, ptab, A);
 #pragma unroll
@@ -163,10 +191,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) ptab[S2K_PTAB_NG + i] = ng.d[i];
-    u32 gw[8];                // ng, shifted right one 16-bit window per generator addition; loaded when the G phase starts
-#pragma unroll
-    for (int i = 0; i < 8; i++) gw[i] = 0;
+    for (int i = 0; i < 8; i++) dig[(9 + i) * S2K_DIG_STRIDE] = ng.d[i];
 
     // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
     int a = p_active ? 0 : S2K_ADD_G0;
@@ -184,16 +209,14 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             const int _h = _i & 1;                                                                                  \
             const int _hn = _h ? hneg1 : hneg0;                                                                     \
             u32 _v = 8u; int _flip = _hn; dst_valid = 1;                       /* top digit (a = 0, 1) is always +1 */ \
-            if (_i >= 2 && _i < S2K_ADDS_P) { if (_h) _v = digit_reg_pop(dr1); else _v = digit_reg_pop(dr0); }      \
+            if (_i >= 2 && _i < S2K_ADDS_P) _v = (dig[(_i >> 3) * S2K_DIG_STRIDE] >> ((_i & 7) * 4)) & 15u;          \
             if (_i >= S2K_ADDS_P) { _flip = !_hn; dst_valid = _h ? skew1 : skew0; }      /* skew correction: -(+-P) */ \
             ptab_fetch(dst, ptab, _v, _h, _flip);                                                                   \
         }                                                                                                           \
         else if (_i < S2K_ADDS_TOTAL) {                                                                             \
-            if (_i == S2K_ADD_G0) { _Pragma("unroll") for (int _k = 0; _k < 8; _k++) gw[_k] = ptab[S2K_PTAB_NG + _k]; } \
-            const u32 _v = gw[0] & 0xFFFFu;                                                                         \
-            _Pragma("unroll") for (int _k = 0; _k < 7; _k++) gw[_k] = (gw[_k] >> 16) | (gw[_k + 1] << 16);          \
-            gw[7] >>= 16;                                                                                           \
-            if (_v) { gtab_load(dst, gtab, (u32)(_i - S2K_ADD_G0), _v); dst_valid = 1; }                            \
+            const int _g = _i - S2K_ADD_G0;                                                                         \
+            const u32 _v = (dig[(9 + (_g >> 1)) * S2K_DIG_STRIDE] >> ((_g & 1) * 16)) & 0xFFFFu;                    \
+            if (_v) { gtab_load(dst, gtab, (u32)_g, _v); dst_valid = 1; }                                           \
         }                                                                                                           \
     } while (0)
     if (a < a_end) S2K_FETCH(cur, cur_valid, a);

@@ -49,6 +49,8 @@ struct s2k_engine {
     hipEvent_t ev[4];          // [0],[1] whole call; [2],[3] dominant kernel
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
+    u32* host_flags;           // pinned, 64 bytes: device -> host flags of the MSM binning pass
+    int msm_fallback;          // the most recent bucket MSM took the exact-sort fallback
     std::recursive_mutex mu;
 };
 
@@ -131,7 +133,9 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
     if (ng) sc_set_b32(sg, ng + 32 * ii, nullptr); else sc_set_zero(sg);
     if (!live) { sc_set_zero(sa); sc_set_zero(sg); }
     gej R;
-    ecmult_lane(R, A, sa, sg, ng != nullptr, gtab, ptab + i * S2K_PTAB_WORDS);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + i * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    ecmult_lane(R, A, sa, sg, ng != nullptr, gtab, lm);
     ge out;
     ge_set_gej(out, R);
     if (live) {
@@ -150,12 +154,13 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0;
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
     if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
     HIPCHK_NULL(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK_NULL(hipEventCreate(&e->ev[i]));
+    HIPCHK_NULL(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
     HIPCHK_NULL(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
     HIPCHK_NULL(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
@@ -171,6 +176,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
     if (e->gtab) hipFree(e->gtab);
+    if (e->host_flags) hipHostFree(e->host_flags);
     for (int i = 0; i < 4; i++) hipEventDestroy(e->ev[i]);
     hipStreamDestroy(e->stream);
     delete e;
@@ -185,6 +191,7 @@ extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
     if (bytes) *bytes = sizeof(u32) * S2K_GTAB_WORDS;
     return e ? e->gtab : nullptr;
 }
+extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) { return e ? e->msm_fallback : 0; }
 extern "C" float s2k_engine_last_ms(s2k_engine* e, int which) {
     float ms = -1.0f;
     if (!e) return ms;
@@ -293,8 +300,10 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     if (!live) p = 0;
     const rp_rec& rec = ws.rec[p];
     live &= (ring < rec.rings);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, ptab + t * S2K_PTAB_WORDS);
+            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm);
 }
 __global__ void __launch_bounds__(64)
 k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
@@ -411,7 +420,9 @@ k_schnorr_verify(int32_t* __restrict__ results, schnorr_midstate mid, const unsi
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int live = i < n;
     const size_t ii = live ? i : 0;
-    const int r = schnorr_verify_lane(mid, sigs + 64 * ii, msgs + msglen * ii, msglen, pks + (pk_format ? 64 : 32) * ii, pk_format, live, gtab, ptab + i * S2K_PTAB_WORDS);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + i * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    const int r = schnorr_verify_lane(mid, sigs + 64 * ii, msgs + msglen * ii, msglen, pks + (pk_format ? 64 : 32) * ii, pk_format, live, gtab, lm);
     if (live) results[i] = r;
 }
 extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* sigs,
@@ -456,52 +467,129 @@ extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results
 // multi-scalar multiplication (msm.h)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_msm_prep(u32* term, u32* keys, u32* hist, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
-           size_t n, size_t nt, msm_plan pl) {
+k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf, size_t n, size_t nt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
     const int isg = (i == n);       // only when g_sc != NULL (nt == n + 1)
-    msm_prep(term + i * MSM_TERM_WORDS, keys + i * 2 * pl.windows, hist, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
-             isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg, pl);
+    msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
+                  isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg);
 }
-// exclusive scan of hist[0..nk) into off[0..nk] and cur (copy), one workgroup
-__global__ void __launch_bounds__(1024)
-k_scan_u32(u32* off, u32* cur, const u32* hist, u32 nk) {
-    __shared__ u32 part[1024];
-    const u32 t = threadIdx.x, per = (nk + 1023) / 1024, lo = t * per, hi = min(lo + per, nk);
-    u32 s = 0;
-    for (u32 k = lo; k < hi; k++) s += hist[k];
+// Binning: workgroup (chunk, window).  Two sweeps over the chunk's half-scalar records: count into the LDS histogram, reserve
+// each bucket's slots with one global atomic, then hand the slots out with LDS atomics and write the references.
+// refs layout: bucket k owns refs[k*cap .. k*cap + cap); gcnt[k] ends up as the bucket's full size even when it overflows.
+// The top window only has 128 - c*(windows-1) live bits (both GLV halves are below 2^128, scalar_impl.h:183-285), so its
+// few buckets are proportionally fuller: they get their own capacity.  Bucket k = w*nb + b starts at msm_region(k).
+struct msm_layout { u32 cap, cap_top, top_used; };     // top_used: buckets 0..top_used-1 of the top window have a region
+__device__ __forceinline__ size_t msm_region(const msm_layout& L, const msm_plan& pl, u32 w, u32 b) {
+    return (w + 1 < pl.windows) ? ((size_t)w * pl.nb + b) * L.cap : (size_t)(pl.windows - 1) * pl.nb * L.cap + (size_t)b * L.cap_top;
+}
+#define MSM_BIN_THREADS 1024
+__global__ void __launch_bounds__(MSM_BIN_THREADS)
+k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt, msm_plan pl, msm_layout L, u32 chunk) {
+    __shared__ u32 s_cnt[4097 + 7];
+    const u32 w = blockIdx.y, tid = threadIdx.x;
+    const size_t t0 = (size_t)blockIdx.x * chunk;
+    const size_t t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
+    for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) s_cnt[b] = 0;
+    msm_wconst wc; msm_window_const(wc, w, pl.c);
+    __syncthreads();
+    for (size_t t = t0 + tid; t < t1; t += MSM_BIN_THREADS) {
+        u32 h[MSM_HALF_WORDS];
+        const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+#pragma unroll
+        for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
+            if (key) atomicAdd(&s_cnt[key >> 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) {
+        const u32 c = s_cnt[b];
+        s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;
+    }
+    __syncthreads();
+    int over = 0;
+    for (size_t t = t0 + tid; t < t1; t += MSM_BIN_THREADS) {
+        u32 h[MSM_HALF_WORDS];
+        const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+#pragma unroll
+        for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 key = msm_key_at(h, half, 0, wc, pl);
+            if (key) {
+                const u32 b = key >> 1, slot = atomicAdd(&s_cnt[b], 1u);
+                const int top = (w + 1 == pl.windows);
+                if (slot < (top ? L.cap_top : L.cap) && (!top || b < L.top_used)) refs[msm_region(L, pl, w, b) + slot] = (u32)(t << 2) | ((u32)half << 1) | (key & 1u);
+                else over = 1;
+            }
+        }
+    }
+    if (over) flags[0] = 1u;
+}
+// exact counting-sort scatter (fallback when a bucket region overflowed): cur = exclusive scan of gcnt
+__global__ void __launch_bounds__(256)
+k_msm_scatter(u32* refs, u32* cur, const u32* halves, size_t nt, msm_plan pl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    u32 h[MSM_HALF_WORDS];
+    for (int q = 0; q < MSM_HALF_WORDS; q++) h[q] = halves[i * MSM_HALF_WORDS + q];
+    for (u32 w = 0; w < pl.windows; w++) {
+        msm_wconst wc; msm_window_const(wc, w, pl.c);
+        for (int half = 0; half < 2; half++) {
+            const u32 key = msm_key_at(h, half, w, wc, pl);
+            if (key) { const u32 pos = atomicAdd(&cur[key >> 1], 1u); refs[pos] = (u32)(i << 2) | ((u32)half << 1) | (key & 1u); }
+        }
+    }
+}
+// exclusive scan of in[0..nk) into off[0..nk] (and a copy in cur if non-null): tiles of 1024, then the tile totals
+__global__ void __launch_bounds__(256)
+k_scan_tiles(u32* off, u32* tile_sum, const u32* in, u32 nk) {
+    __shared__ u32 part[256];
+    const u32 t = threadIdx.x, base = blockIdx.x * 1024 + t * 4;
+    u32 v[4]; u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (base + k < nk) ? in[base + k] : 0u; s += v[k]; }
     part[t] = s;
     __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        u32 v = (t >= d) ? part[t - d] : 0;
+    for (u32 d = 1; d < 256; d <<= 1) {
+        const u32 x = (t >= d) ? part[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
     u32 run = part[t] - s;
-    for (u32 k = lo; k < hi; k++) { off[k] = run; cur[k] = run; run += hist[k]; }
-    if (t == 1023) off[nk] = part[1023];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (base + k < nk) off[base + k] = run; run += v[k]; }
+    if (t == 255) tile_sum[blockIdx.x] = part[255];
 }
 __global__ void __launch_bounds__(256)
-k_msm_scatter(u32* refs, u32* cur, const u32* keys, size_t nt, msm_plan pl) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nt) return;
-    for (u32 h = 0; h < 2; h++) for (u32 w = 0; w < pl.windows; w++) {
-        const u32 key = keys[i * 2 * pl.windows + h * pl.windows + w];
-        if (key) { const u32 pos = atomicAdd(&cur[key >> 1], 1u); refs[pos] = (u32)(i << 2) | (h << 1) | (key & 1u); }
+k_scan_fix(u32* off, u32* cur, const u32* tile_sum, u32 nk) {
+    u32 pre = 0;
+    for (u32 b = 0; b < blockIdx.x; b++) pre += tile_sum[b];
+    const u32 t = threadIdx.x, base = blockIdx.x * 1024 + t * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (base + k < nk) { const u32 o = off[base + k] + pre; off[base + k] = o; if (cur) cur[base + k] = o; }
+    if (blockIdx.x == gridDim.x - 1 && t == 0) off[nk] = pre + tile_sum[blockIdx.x];
+}
+__global__ void k_msm_counts(u32* cnt_out, const u32* cnt_in, u32 nk, u32 T, u32* max_out) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nk) {
+        const u32 c = cnt_in[k];
+        cnt_out[k] = (c + T - 1) / T;
+        if (max_out && c > T) atomicMax(max_out, c);      // only buckets that need more than one round matter
     }
 }
-__global__ void k_msm_counts(u32* cnt_out, const u32* cnt_in, u32 nk, u32 T) {
-    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nk) cnt_out[k] = (cnt_in[k] + T - 1) / T;
-}
 __global__ void __launch_bounds__(256, 2)
-k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* off_out, const u32* term, u32 nk, u32 T) {
+k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* cnt_in, msm_layout L, msm_plan pl, const u32* off_out, const u32* term, u32 nk, u32 T) {
     const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= off_out[nk]) return;
     const u32 k = msm_find_key(off_out, nk, m), j = m - off_out[k];
-    const u32 start = off_in[k] + j * T, end = min(start + T, off_in[k + 1]);
+    // bucket k's references: its region of the fixed-capacity layout (off_in == NULL), refs[off_in[k] ..) after the exact sort
+    const size_t first = off_in ? (size_t)off_in[k] : msm_region(L, pl, k / pl.nb, k % pl.nb);
+    const size_t start = first + (size_t)j * T, end = min(start + T, first + cnt_in[k]);
     gej o; msm_sum_refs(o, refs, start, end, term);
     gej_store28(out28 + (size_t)m * 28, o);
 }
@@ -566,7 +654,9 @@ k_msm_small(u32* out28, const unsigned char* g_sc, const unsigned char* sc, cons
         sc_set_b32(k, sc + 32 * i, nullptr);
     }
     if (isg) sc_set_b32(g, g_sc, nullptr);
-    gej R; ecmult_lane(R, A, k, g, 1, gtab, ptab + i * S2K_PTAB_WORDS);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + i * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    gej R; ecmult_lane(R, A, k, g, 1, gtab, lm);
     if (live) gej_store28(out28 + i * 28, R);
 }
 __global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in28) {
@@ -587,13 +677,44 @@ static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u3
     }
     return cur;
 }
+// bucket-region capacity of the fixed-capacity layout: the mean load plus ten standard deviations of a uniform digit
+static u32 msm_cap_for(double mean) {
+    double sd = 1.0; while (sd * sd < mean) sd += 1.0;
+    size_t cap = (size_t)(mean + 10.0 * sd) + 8;
+    return (u32)((cap + 7) & ~size_t(7));
+}
+static msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
+    msm_layout L;
+    L.cap = msm_cap_for(2.0 * (double)nt / (double)(pl.nb - 1));
+    const u32 top_bits = 128u - pl.c * (pl.windows - 1);              // live bits of the top window (0: only the carry reaches it)
+    const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
+    L.top_used = top_vals + 1;
+    // |k1| and |k2| stay below ~2^127.4 and ~2^126.9 (the GLV lattice bounds), so the top window's values are not uniform:
+    // the low ones carry up to ~1.9x the uniform share.  4x (never more than every reference) leaves the same margin as below.
+    double mean_top = 8.0 * (double)nt / (double)top_vals; if (mean_top > 2.0 * (double)nt) mean_top = 2.0 * (double)nt;
+    L.cap_top = msm_cap_for(mean_top);
+    return L;
+}
+static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
+    return (size_t)(pl.windows - 1) * pl.nb * L.cap + (size_t)L.top_used * L.cap_top;
+}
+static u32 msm_run_len(size_t E) { u32 T = (u32)(E / 262144); if (T < 8) T = 8; if (T > 64) T = 64; return T; }
 static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
-    return ws_need({nt * MSM_TERM_WORDS * 4, E * 4, (nk + 1) * 4 * 7, E * 4, (nk + nt + 64) * 28 * 4, (nk + E / 8 + 2) * 28 * 4, (nk * 2 + E / 64 + 64) * 28 * 4,
-                    (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2, 64 * 28 * 4}) + 16 * 256;
+    const size_t T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
+    return ws_need({28 * 4, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4, 64, msm_refs_words(pl, L) * 4, E * 4, nk * 28 * 4,
+                    (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / T + 64) * 28 * 4, (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2,
+                    (nt + 2) * 28 * 4, 64 * 28 * 4 * 2}) + 32 * 256;
+}
+static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
+    const u32 tiles = (nk + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, st, off, tile_sum, in, nk);
+    hipLaunchKernelGGL(k_scan_fix, dim3(tiles), dim3(256), 0, st, off, cur, tile_sum, nk);
 }
 // core: leaves the Jacobian result (28 words) at *result28 (device).  Workspace must already be large enough.
+// Stream-ordered, but not asynchronous: the host waits for the binning pass to learn the largest bucket (which fixes the number
+// of partial-sum rounds) and whether a bucket region overflowed.
 static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
                       const unsigned char* pt, const unsigned char* pt_inf, size_t n) {
     const size_t nt = n + (g_sc ? 1 : 0);
@@ -614,33 +735,46 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const msm_plan pl = msm_make_plan(nt);
     const u32 nk = pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;                      // upper bound on bucket references
-    u32 T = (u32)(E / 262144); if (T < 8) T = 8; if (T > 64) T = 64;
-    int rounds = 1; { size_t cap = T; while (cap < E) { cap *= T; rounds++; } }
+    const u32 T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
     const size_t bound1 = (size_t)nk + E / T + 2;
-    u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* keys = c.take<u32>(E);
-    u32* hist = c.take<u32>(nk + 1); u32* off0 = c.take<u32>(nk + 1); u32* cur = c.take<u32>(nk + 1);
+    u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
+    u32* gcnt = c.take<u32>(nk + 1); u32* off0 = c.take<u32>(nk + 1); u32* cur = c.take<u32>(nk + 1);
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
-    u32* refs = c.take<u32>(E); u32* buckets = c.take<u32>((size_t)nk * 28);
+    u32* tile_sum = c.take<u32>(1024); u32* flags = c.take<u32>(16);           // flags[0] overflow, flags[1] largest bucket (if > T)
+    u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* refs_dense = c.take<u32>(E); u32* buckets = c.take<u32>((size_t)nk * 28);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / T + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
-    HIPCHK(hipMemsetAsync(hist, 0, (nk + 1) * 4, st));
+    HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
+    HIPCHK(hipMemsetAsync(flags, 0, 64, st));
     const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
-    hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, keys, hist, g_sc, sc, pt, pt_inf, n, nt, pl);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, off0, cur, hist, nk);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(bt), dim3(256), 0, st, refs, cur, keys, nt, pl);
+    hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
+    u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.windows < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
+    hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.windows), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gcnt, nk, T, flags + 1);
+    HIPCHK(hipMemcpyAsync(e->host_flags, flags, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int overflow = e->host_flags[0] != 0;
+    e->msm_fallback = overflow;
+    const u32 maxcnt = e->host_flags[1];
+    int rounds = 1; { size_t reach = T; while (reach < maxcnt) { reach *= T; rounds++; } }
+    const u32* refs = refs_cap; const u32* first = nullptr;
+    if (overflow) {                                           // exact counting sort of the same references
+        launch_scan(st, off0, cur, tile_sum, gcnt, nk);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(bt), dim3(256), 0, st, refs_dense, cur, halves, nt, pl);
+        refs = refs_dense; first = off0;
+    }
     // round 1: references -> partial sums (at most T references each)
-    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, hist, nk, T);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, offA, cur, cntA, nk);
+    launch_scan(st, offA, nullptr, tile_sum, cntA, nk);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs, off0, offA, term, nk, T);
+    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs, first, gcnt, L, pl, offA, term, nk, T);
     HIPCHK(hipEventRecord(e->ev[3], st));
     // rounds 2..R: partial sums of partial sums until every bucket holds at most one
     u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
     size_t bound = bound1;
     for (int r = 2; r <= rounds; r++) {
         bound = (size_t)nk + bound / T + 2;
-        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, oout, cur, cout, nk);
+        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T, (u32*)nullptr);
+        launch_scan(st, oout, nullptr, tile_sum, cout, nk);
         hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T);
         u32* t;
         t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
@@ -749,7 +883,9 @@ k_bp_terms(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, 
     int live = p < n;
     if (!live) p = 0;
     live &= proof_ok[p];
-    gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab, ptab + t * S2K_PTAB_WORDS);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab, lm);
     if (t < n * sh.n_terms) { gej_store28(out28 + t * 28, o); term_ok[t] = (unsigned char)ok; }
 }
 __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
@@ -827,8 +963,10 @@ k_sj_verify(int32_t* __restrict__ results, const unsigned char* __restrict__ pro
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int live = i < n;
     const size_t ii = live ? i : 0;
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + i * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     const int r = sj_verify_lane(proofs + proof_off[ii], proof_off[ii + 1] - proof_off[ii], in_tags + 64 * tag_off[ii], tag_off[ii + 1] - tag_off[ii],
-                                 out_tags + 64 * ii, live, gtab, ptab + i * S2K_PTAB_WORDS);
+                                 out_tags + 64 * ii, live, gtab, lm);
     if (live) results[i] = r;
 }
 extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* proofs,

@@ -4,10 +4,14 @@
 // The reference walks one window at a time over one bucket array on one core.  On the GPU every (window, bucket)
 // pair is its own lane and the windows are independent, so the whole bucket phase is three data-parallel passes:
 //
-//   msm_prep     1 lane / term   : byte decode, GLV split (scalar.h), signed c-bit digits of both 128-bit halves;
-//                                  limb-form point (x, beta*x, y) written once; one histogram atomic per digit
-//   (scan)       exclusive prefix sum of the (window,bucket) histogram
-//   msm_scatter  1 lane / term   : counting-sort scatter of (term, half, sign) references into bucket order
+//   msm_prep_term 1 lane / term  : byte decode, GLV split (scalar.h); limb-form point (x, beta*x, y) and the two 129-bit
+//                                  half-scalar magnitudes written once
+//   bin          1 workgroup / (window, chunk of terms): the signed c-bit digit of every half-scalar in the chunk for this
+//                                  window (msm_digit_at needs no carry from the windows below), counted in an LDS
+//                                  histogram; one global atomic per non-empty (workgroup, bucket) pair reserves the slots,
+//                                  and the (term, half, sign) references go straight into fixed-capacity bucket regions.
+//                                  A bucket that outgrows its region (adversarially equal scalars) sets a flag and the
+//                                  launch falls back to the exact counting sort (scan of the same histogram + scatter)
 //   msm_round1   1 lane / <=T refs: partial sums of runs of at most T consecutive references of one bucket (mixed additions).
 //   msm_roundN   1 lane / <=T part.: the same on the partial sums, repeated until every bucket has at most one -- bucket
 //                                  sizes are data dependent (the top window of a 129-bit half only has 2-3 live bits, and
@@ -22,7 +26,7 @@
 // double-and-add per lane (ecmult.h) and a tree sum -- the analogue of the reference switching to Strauss below 88
 // points (:55, :848-855).
 #pragma once
-#include "ecmult.h"
+#include "gtable.h"
 
 #define MSM_SMALL_N 192
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
@@ -49,7 +53,65 @@ S2K_HD int msm_digit(const u32 k[5], u32 w, u32 c, int& carry) {
     carry = 0; return (int)d;
 }
 
-// ---- pass 1: per-term preparation ------------------------------------------------------------------------------
+// Carry-free form of msm_digit: the carry into window w is 1 exactly when the bits below the window exceed the pattern
+// "top bit of every lower window", so adding C_w = sum_{j<w} (2^(c-1) - 1) 2^(cj) to k produces it as an ordinary carry.
+// (Induction over msm_digit's recurrence: t_w = raw_w + carry_w > H  <=>  (raw_w, lower bits) > (H, pattern_w).)
+struct msm_wconst { u32 add[5]; u32 shift; };
+S2K_HD void msm_window_const(msm_wconst& wc, u32 w, u32 c) {
+    for (int i = 0; i < 5; i++) wc.add[i] = 0;
+    const u32 hm1 = (1u << (c - 1)) - 1u;
+    for (u32 j = 0; j < w; j++) {
+        const u32 bit = j * c, word = bit >> 5, sh = bit & 31;
+        const u64 v = (u64)hm1 << sh;
+        if (word < 5) wc.add[word] |= (u32)v;
+        if (word + 1 < 5) wc.add[word + 1] |= (u32)(v >> 32);
+    }
+    wc.shift = w * c;
+}
+S2K_HD int msm_digit_at(const u32 k[5], const msm_wconst& wc, u32 c) {
+    u32 s[6]; u64 cy = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { cy += (u64)k[i] + wc.add[i]; s[i] = (u32)cy; cy >>= 32; }
+    s[5] = 0;
+    const u32 word = wc.shift >> 5, sh = wc.shift & 31;
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) if ((u32)i == word) v = (u64)s[i] | ((u64)s[i + 1] << 32);
+    const u32 d = (u32)(v >> sh) & ((1u << c) - 1u);
+    return d > (1u << (c - 1)) ? (int)d - (int)(1u << c) : (int)d;
+}
+
+// half-scalar record of a term: k1 magnitude [5], k2 magnitude [5], flags (bit0 k1 negative, bit1 k2 negative, bit2 active), pad
+#define MSM_HALF_WORDS 12
+// byte decode + GLV split of one term (no digits): term record as below, half-scalar record as above
+S2K_HD void msm_prep_term(u32* term, u32* halves, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g) {
+    scalar k; sc_set_b32(k, sc32, nullptr);
+    ge P;
+    if (is_g) ge_set_generator(P);
+    else { fe_set_b32_mod(P.x, pt64); fe_set_b32_mod(P.y, pt64 + 32); fe_norm_weak(P.x); fe_norm_weak(P.y); }
+    const int active = (!pt_inf) & (!sc_is_zero(k));
+    fe beta, bx; fe_set_beta(beta); fe_mul(bx, P.x, beta);
+    for (int i = 0; i < 9; i++) { term[i] = P.x.n[i]; term[9 + i] = bx.n[i]; term[18 + i] = P.y.n[i]; }
+    term[27] = (u32)active;
+    scalar k1s, k2s; half_scalar h0, h1;
+    sc_split_lambda(k1s, k2s, k);
+    sc_to_half(h0, k1s); sc_to_half(h1, k2s);
+    for (int i = 0; i < 5; i++) { halves[i] = h0.w[i]; halves[5 + i] = h1.w[i]; }
+    halves[10] = (u32)h0.neg | ((u32)h1.neg << 1) | ((u32)active << 2);
+    halves[11] = 0;
+}
+// bucket key of (half-scalar record, half, window): (w*nb + |d|) << 1 | sign, 0 = no contribution
+S2K_HD u32 msm_key_at(const u32* halves, int half, u32 w, const msm_wconst& wc, const msm_plan& pl) {
+    const u32 fl = halves[10];
+    if (!(fl & 4u)) return 0;
+    const int d = msm_digit_at(halves + 5 * half, wc, pl.c);
+    if (d == 0) return 0;
+    const int neg = (d < 0) ^ (int)((fl >> half) & 1u);
+    const u32 mag = (u32)(d < 0 ? -d : d);
+    return ((w * pl.nb + mag) << 1) | (u32)neg;
+}
+
+// ---- pass 1 (exact counting-sort form, used by the host emulation and kept as the reference for msm_digit_at) ------------------------------------------------------------------------------
 // term_data[i] : 28 words (x, beta x, y limbs, flags bit0 = active)
 // keys[(2*i + h) * W + w] = bucket key (w*nb + |d|) << 1 | sign  (0 = no contribution)
 S2K_HD void msm_prep(u32* term, u32* keys, u32* hist, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g,
@@ -95,9 +157,9 @@ S2K_HD u32 msm_find_key(const u32* off, u32 nk, u32 m) {
     return lo;
 }
 // refs[j] = term_index << 2 | half << 1 | neg
-S2K_HD void msm_sum_refs(gej& out, const u32* refs, u32 start, u32 end, const u32* term_data) {
+S2K_HD void msm_sum_refs(gej& out, const u32* refs, size_t start, size_t end, const u32* term_data) {
     gej acc; gej_set_infinity(acc);
-    for (u32 j = start; j < end; j++) {
+    for (size_t j = start; j < end; j++) {
         const u32 r = refs[j];
         const u32* t = term_data + (size_t)(r >> 2) * MSM_TERM_WORDS;
         ge p; const int half = (r >> 1) & 1, neg = r & 1;

@@ -273,7 +273,7 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
 }
 
 S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
-                    const unsigned char* proof, u32 ring, int live, const u32* gtab, u32* ptab) {
+                    const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
     u32 e[8];
@@ -308,7 +308,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
             if (live) gej_store28_h(pub28, nxt);
         }
         gej R;
-        ecmult_lane(R, pub, ens, s, 1, gtab, ptab);
+        ecmult_lane(R, pub, ens, s, 1, gtab, lm);
         good &= !R.inf;
         ge a; ge_set_gej(a, R);
         u32 xw[8]; fe_to_words(xw, a.x);

@@ -25,7 +25,7 @@ S2K_HD void fe_set_le32(fe& r, const unsigned char* b) {
 }
 // pk_format 0: 32-byte x-only serialisation (lift with even y, as secp256k1_xonly_pubkey_parse); 1: 64-byte opaque object
 S2K_HD int schnorr_verify_lane(const schnorr_midstate& mid, const unsigned char* sig64, const unsigned char* msg, size_t msglen,
-                               const unsigned char* pk, int pk_format, int live, const u32* gtab, u32* ptab) {
+                               const unsigned char* pk, int pk_format, int live, const u32* gtab, const lane_mem& lm) {
     int ok = live;
     fe rx; scalar s, e; ge P; int ov;
     ok &= fe_set_b32_limit(rx, sig64);
@@ -54,7 +54,7 @@ S2K_HD int schnorr_verify_lane(const schnorr_midstate& mid, const unsigned char*
     }
     if (!ok) { sc_set_zero(e); sc_set_zero(s); }
     gej Pj, R; gej_set_ge(Pj, P);
-    ecmult_lane(R, Pj, e, s, 1, gtab, ptab);
+    ecmult_lane(R, Pj, e, s, 1, gtab, lm);
     ge a; ge_set_gej(a, R);
     ok &= !R.inf;
     ok &= !fe_is_odd(a.y);

@@ -11,7 +11,7 @@
 
 // proof: serialised form (2-byte LE n_inputs | bitmap | e0 | s_0..).  tags: n_tags 64-byte generators (x||y).
 S2K_HD int sj_verify_lane(const unsigned char* proof, u64 plen, const unsigned char* in_tags64, u64 n_tags, const unsigned char* out_tag64,
-                          int live, const u32* gtab, u32* ptab) {
+                          int live, const u32* gtab, const lane_mem& lm) {
     int ok = live;
     // ---- parse (secp256k1_surjectionproof_parse :45-82)
     u32 n_inputs = 0, bm_len = 0, n_used = 0;
@@ -79,7 +79,7 @@ S2K_HD int sj_verify_lane(const unsigned char* proof, u64 plen, const unsigned c
         int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens) & !pub.inf;
         if (!good) { sc_set_zero(ens); sc_set_zero(s); }
         gej R;
-        ecmult_lane(R, pub, ens, s, 1, gtab, ptab);
+        ecmult_lane(R, pub, ens, s, 1, gtab, lm);
         good &= !R.inf;
         ge a; ge_set_gej(a, R);
         u32 xw[8]; fe_to_words(xw, a.x);

@@ -79,6 +79,8 @@ int emu_ge_set_xquad(unsigned char* r64, const unsigned char* x32) {
 
 static std::vector<u32> g_gtab;
 static u32 g_ptab[S2K_PTAB_WORDS];
+static u32 g_dig[S2K_DIG_WORDS];
+static const lane_mem g_lm{g_ptab, g_dig};
 // Host-only construction of the 16-bit window table: same entries as gtable.h's device kernels, but built by running
 // sums + Montgomery batch inversion so that a CPU test does not spend a minute on a million inversions.
 static const u32* gtab_host() {
@@ -119,7 +121,8 @@ int emu_ecmult(unsigned char* r64, const unsigned char* a64, int ainf, const uns
     if (z32 && !ainf) { fe z, z2, z3; fe_from_b32(z, z32); fe_norm_weak(z); fe_sqr(z2, z); fe_mul(z3, z2, z); fe_mul(A.x, A.x, z2); fe_mul(A.y, A.y, z3); A.z = z; }
     sc_set_b32(na, na32, 0);
     if (ng32) sc_set_b32(ng, ng32, 0); else sc_set_zero(ng);
-    ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host(), g_ptab);
+    u32 dig[S2K_DIG_WORDS]; const lane_mem lm{g_ptab, dig};
+    ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host(), lm);
     return gej_to_b64(r64, R);
 }
 void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
@@ -135,13 +138,13 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
     *min_value = mn; *max_value = mx;
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
-    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_ptab);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm);
     return rp_final(rec, ring_out, ring_ok, proof);
 }
 
 int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, size_t msglen, const unsigned char* pk, int pk_format) {
     schnorr_midstate mid; schnorr_tag_midstate(mid);
-    return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host(), g_ptab);
+    return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host(), g_lm);
 }
 
 // the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width)
@@ -155,6 +158,17 @@ int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* 
         const int isg = (g_sc && i == n);
         msm_prep(term.data() + i * MSM_TERM_WORDS, keys.data() + i * 2 * pl.windows, hist.data(), isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
                  isg ? 0 : (inf ? inf[i] : 0), isg, pl);
+    }
+    // the carry-free digit form the binning kernel uses (msm_prep_term + msm_key_at) must give exactly the same keys
+    for (size_t i = 0; i < nt; i++) {
+        const int isg = (g_sc && i == n);
+        u32 t2[MSM_TERM_WORDS], hv[MSM_HALF_WORDS];
+        msm_prep_term(t2, hv, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i, isg ? 0 : (inf ? inf[i] : 0), isg);
+        for (int q = 0; q < MSM_TERM_WORDS; q++) if (t2[q] != term[i * MSM_TERM_WORDS + q]) return -1;
+        for (u32 w = 0; w < pl.windows; w++) {
+            msm_wconst wc; msm_window_const(wc, w, pl.c);
+            for (int half = 0; half < 2; half++) if (msm_key_at(hv, half, w, wc, pl) != keys[i * 2 * pl.windows + half * pl.windows + w]) return -2;
+        }
     }
     for (size_t k = 0; k < nk; k++) off[k + 1] = off[k] + hist[k];
     cur = off;
@@ -187,7 +201,7 @@ int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned
     if (!ok) return 0;
     gej sum; gej_set_infinity(sum);
     for (u32 t = 0; t < sh.n_terms; t++) {
-        gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host(), g_ptab);
+        gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host(), g_lm);
         gej s; gej_add_var(s, sum, o); sum = s;
     }
     return ok & sum.inf;
@@ -200,7 +214,8 @@ void emu_msm_partial(u32* out28, const unsigned char* g_sc, const unsigned char*
         gej A, R; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
         if (i < n) { ge a; ge_from_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a); A.inf = inf ? inf[i] : 0; sc_set_b32(k, sc + 32 * i, 0); }
         else sc_set_b32(g, g_sc, 0);
-        ecmult_lane(R, A, k, g, 1, gtab_host(), g_ptab);
+        u32 dig[S2K_DIG_WORDS]; const lane_mem lm{g_ptab, dig};
+        ecmult_lane(R, A, k, g, 1, gtab_host(), lm);
         gej s; gej_add_var(s, acc, R); acc = s;
     }
     gej_store28_h(out28, acc);
@@ -212,6 +227,6 @@ int emu_gej_sum(unsigned char* r64, const u32* gej28, size_t count) {
 }
 
 int emu_surjection_verify(const unsigned char* proof, size_t plen, const unsigned char* in_tags64, size_t n_tags, const unsigned char* out_tag64) {
-    return sj_verify_lane(proof, plen, in_tags64, n_tags, out_tag64, 1, gtab_host(), g_ptab);
+    return sj_verify_lane(proof, plen, in_tags64, n_tags, out_tag64, 1, gtab_host(), g_lm);
 }
 }

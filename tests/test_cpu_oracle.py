@@ -159,7 +159,7 @@ def test_emu_schnorr(emu, ref):
 def test_emu_msm(emu, ref):
     rng = np.random.default_rng(9)
     pts = [ref.rand_point(rng) for _ in range(32)]
-    for (n, g, c) in ((1, 0, 0), (1, 1, 0), (2, 1, 0), (5, 0, 4), (17, 1, 5), (100, 1, 0), (300, 1, 6), (600, 0, 0)):
+    for (n, g, c) in ((1, 0, 0), (1, 1, 0), (2, 1, 0), (5, 0, 4), (17, 1, 5), (100, 1, 0), (300, 1, 6), (600, 0, 0), (40, 1, 13), (40, 0, 11), (64, 1, 8)):
         Pn = np.frombuffer(b"".join(pts[i % 32] for i in range(n)), np.uint8).reshape(n, 64)
         S = rng.integers(0, 256, (n, 32), dtype=np.uint8); inf = np.zeros(n, np.uint8)
         if n > 3:

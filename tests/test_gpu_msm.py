@@ -35,6 +35,32 @@ def test_msm_sizes(engine, ref, n):
         exp, einf = ref.ecmult_multi(sc, pts, g, inf)
         got, ginf = engine.ecmult_multi(sc, pts, g, inf)
         assert ginf == einf and np.array_equal(got, exp), (n, g is not None)
+        if n >= 192:
+            assert not engine.last_msm_fallback()          # uniformly random digits stay inside the bucket regions
+
+
+def test_msm_skewed_scalars(engine, ref):
+    """Equal scalars put every point of a window into ONE bucket: the bucket regions overflow, the launch re-sorts exactly, and
+    the bounded-run partial-sum rounds keep the work spread over lanes.  Also a few-distinct-scalars mix and tiny scalars."""
+    rng = np.random.default_rng(17)
+    n = 6000
+    pts = _points(engine, rng, n)
+    one = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    sc = np.repeat(one, n, 0)
+    exp, einf = ref.ecmult_multi(sc, pts, None, None)
+    got, ginf = engine.ecmult_multi(sc, pts, None, None)
+    assert engine.last_msm_fallback()
+    assert ginf == einf and np.array_equal(got, exp)
+    few = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    sc = few[rng.integers(0, 3, n)]
+    g = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    exp, einf = ref.ecmult_multi(sc, pts, g, None)
+    got, ginf = engine.ecmult_multi(sc, pts, g, None)
+    assert ginf == einf and np.array_equal(got, exp)
+    sc = np.zeros((n, 32), np.uint8); sc[:, 31] = rng.integers(1, 4, n)       # scalars 1..3: one live window, three buckets
+    exp, einf = ref.ecmult_multi(sc, pts, None, None)
+    got, ginf = engine.ecmult_multi(sc, pts, None, None)
+    assert ginf == einf and np.array_equal(got, exp)
 
 
 def test_msm_degenerate(engine, ref):
