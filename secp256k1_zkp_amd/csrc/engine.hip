@@ -698,13 +698,16 @@ static msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
 static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
     return (size_t)(pl.windows - 1) * pl.nb * L.cap + (size_t)L.top_used * L.cap_top;
 }
-static u32 msm_run_len(size_t E) { u32 T = (u32)(E / 262144); if (T < 8) T = 8; if (T > 64) T = 64; return T; }
+// run lengths of the partial-sum rounds: round 1 sums up to T references per lane (about 1.3e5 lanes' worth at the largest
+// sizes), later rounds up to MSM_T2 partial sums -- short, because there are only a few per bucket left and lanes are scarce
+static u32 msm_run_len(size_t E) { u32 T = (u32)(E / 131072); if (T < 8) T = 8; if (T > 128) T = 128; return T; }
+#define MSM_T2 8u
 static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
     const size_t T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
     return ws_need({28 * 4, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4, 64, msm_refs_words(pl, L) * 4, E * 4, nk * 28 * 4,
-                    (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / T + 64) * 28 * 4, (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2,
+                    (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4, (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2,
                     (nt + 2) * 28 * 4, 64 * 28 * 4 * 2}) + 32 * 256;
 }
 static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
@@ -735,14 +738,14 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const msm_plan pl = msm_make_plan(nt);
     const u32 nk = pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;                      // upper bound on bucket references
-    const u32 T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
+    const u32 T = msm_run_len(E), T2 = MSM_T2; const msm_layout L = msm_make_layout(nt, pl);
     const size_t bound1 = (size_t)nk + E / T + 2;
     u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
     u32* gcnt = c.take<u32>(nk + 1); u32* off0 = c.take<u32>(nk + 1); u32* cur = c.take<u32>(nk + 1);
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
     u32* tile_sum = c.take<u32>(1024); u32* flags = c.take<u32>(16);           // flags[0] overflow, flags[1] largest bucket (if > T)
     u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* refs_dense = c.take<u32>(E); u32* buckets = c.take<u32>((size_t)nk * 28);
-    u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / T + 64) * 28);
+    u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
     HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
     HIPCHK(hipMemsetAsync(flags, 0, 64, st));
@@ -756,7 +759,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const int overflow = e->host_flags[0] != 0;
     e->msm_fallback = overflow;
     const u32 maxcnt = e->host_flags[1];
-    int rounds = 1; { size_t reach = T; while (reach < maxcnt) { reach *= T; rounds++; } }
+    int rounds = 1; { size_t reach = T; while (reach < maxcnt) { reach *= T2; rounds++; } }
     const u32* refs = refs_cap; const u32* first = nullptr;
     if (overflow) {                                           // exact counting sort of the same references
         launch_scan(st, off0, cur, tile_sum, gcnt, nk);
@@ -772,10 +775,10 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
     size_t bound = bound1;
     for (int r = 2; r <= rounds; r++) {
-        bound = (size_t)nk + bound / T + 2;
-        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T, (u32*)nullptr);
+        bound = (size_t)nk + bound / T2 + 2;
+        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T2, (u32*)nullptr);
         launch_scan(st, oout, nullptr, tile_sum, cout, nk);
-        hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T);
+        hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T2);
         u32* t;
         t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
     }
