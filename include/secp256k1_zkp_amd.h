@@ -85,6 +85,16 @@ S2K_API int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results, c
 S2K_API int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* sigs,
                                                   const unsigned char* msgs, size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n);
 
+/* ---- half-aggregated Schnorr signature verification ------------------------------------------------------------------
+ * *result = secp256k1_schnorrsig_aggverify(ctx, pubkeys, msgs32, n, aggsig, aggsig_len)
+ *                                       (include/secp256k1_schnorrsig_halfagg.h, src/modules/schnorrsig_halfagg/main_impl.h:108-198)
+ * evaluated as one (2n+1)-term multi-scalar multiplication  -s*G + sum z_i*R_i + sum (z_i e_i)*P_i == infinity  on the GPU
+ * (the reference does two single multiplications per signature).  pubkeys / pk_format as in the BIP-340 batch call
+ * (0 = n*32 serialised x-only keys, 1 = n*64 secp256k1_xonly_pubkey objects); msgs32 n*32; aggsig = r_0|...|r_{n-1}|s,
+ * aggsig_len must be 32*(n+1) or the verdict is 0.  The return value is the call's success, the verdict goes to *result. */
+S2K_API int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format,
+                                               const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len);
+
 /* ---- Borromean rangeproof batch verification ---------------------------------------------------------------------
  * results[i], min_value[i], max_value[i] = secp256k1_rangeproof_verify(ctx, &min, &max, commit_i, proof_i, plen_i,
  *                                          extra_commit_i, extra_commit_len_i, gen_i)

@@ -387,3 +387,39 @@ REF_EXPORT size_t ref_surjection_make(unsigned char *proof_ser, size_t max_len, 
     free(fixed); free(eph); free(blinds); secp256k1_context_destroy(ctx);
     return ok ? len : 0;
 }
+
+/* ---- half-aggregated Schnorr signatures (src/modules/schnorrsig_halfagg/main_impl.h) --------------------------------
+ * keys travel as 32-byte x-only serialisations; a key that does not parse makes both calls return -1. */
+REF_EXPORT int ref_halfagg_aggregate(unsigned char *aggsig, size_t *aggsig_len, const unsigned char *pks32, const unsigned char *msgs32,
+                                     const unsigned char *sigs64, size_t n) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    secp256k1_xonly_pubkey *pk = (secp256k1_xonly_pubkey*)malloc(sizeof(secp256k1_xonly_pubkey) * (n ? n : 1));
+    size_t i; int r = 1;
+    for (i = 0; i < n; i++) if (!secp256k1_xonly_pubkey_parse(ctx, &pk[i], pks32 + 32 * i)) r = -1;
+    if (r == 1) r = secp256k1_schnorrsig_aggregate(ctx, aggsig, aggsig_len, pk, msgs32, sigs64, n);
+    free(pk);
+    secp256k1_context_destroy(ctx);
+    return r;
+}
+REF_EXPORT int ref_halfagg_verify(const unsigned char *pks32, const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    secp256k1_xonly_pubkey *pk = (secp256k1_xonly_pubkey*)malloc(sizeof(secp256k1_xonly_pubkey) * (n ? n : 1));
+    size_t i; int r = 1;
+    for (i = 0; i < n; i++) if (!secp256k1_xonly_pubkey_parse(ctx, &pk[i], pks32 + 32 * i)) r = -1;
+    if (r == 1) r = secp256k1_schnorrsig_aggverify(ctx, n ? pk : NULL, n ? msgs32 : NULL, n, aggsig, aggsig_len);
+    free(pk);
+    secp256k1_context_destroy(ctx);
+    return r;
+}
+/* the 64-byte in-memory secp256k1_xonly_pubkey objects of serialised keys (0 if one does not parse) */
+REF_EXPORT int ref_xonly_objects(unsigned char *out64, const unsigned char *pks32, size_t n) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    size_t i; int ok = 1;
+    for (i = 0; i < n; i++) {
+        secp256k1_xonly_pubkey pk;
+        if (!secp256k1_xonly_pubkey_parse(ctx, &pk, pks32 + 32 * i)) { ok = 0; memset(&pk, 0, sizeof(pk)); }
+        memcpy(out64 + 64 * i, &pk, 64);
+    }
+    secp256k1_context_destroy(ctx);
+    return ok;
+}

@@ -525,6 +525,38 @@ int zo_schnorrsig_verify(const unsigned char *sig64, const unsigned char *msg, s
     return !fe_is_odd(&ra.y) && fe_equal(&rx, &ra.x);
 }
 
+/* ======================================================= half-aggregated schnorr ======================================== */
+/* secp256k1_schnorrsig_aggverify, modules/schnorrsig_halfagg/main_impl.h:108-198, statement for statement: the running
+ * randomizer hash over r_i | pk_i | m_i with a finalised copy per item (:153-163), T_i = R_i + e_i P_i (:165-181),
+ * rhs += z_i T_i with z_0 = 1 (:183-185), accept iff s G == rhs (:187-197).  pks32 = x-only serialisations. */
+int zo_schnorrsig_aggverify(const unsigned char *pks32, const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len) {
+    static const char tag_agg[] = "HalfAgg/randomizer", tag_ch[] = "BIP0340/challenge";
+    sha256 hash, copy, h; unsigned char th[32], tc[32], out[32]; gej rhs, lhs; sc s; size_t i; int overflow;
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 0;
+    sha256_init(&h); sha256_write(&h, (const unsigned char *)tag_agg, sizeof(tag_agg) - 1); sha256_final(&h, th);
+    sha256_init(&h); sha256_write(&h, (const unsigned char *)tag_ch, sizeof(tag_ch) - 1); sha256_final(&h, tc);
+    sha256_init(&hash); sha256_write(&hash, th, 32); sha256_write(&hash, th, 32);      /* the midstate of :12-18 */
+    memset(&rhs, 0, sizeof(rhs)); rhs.inf = 1;
+    for (i = 0; i < n; i++) {
+        fe rx, px; ge rp, pp; gej ppj, ti, t2; sc ei, zi;
+        if (!fe_set_b32_limit(&px, pks32 + 32 * i) || !ge_set_xo(&pp, &px, 0)) return 0;       /* the caller's xonly_pubkey_parse */
+        sha256_write(&hash, aggsig + 32 * i, 32); sha256_write(&hash, pks32 + 32 * i, 32); sha256_write(&hash, msgs32 + 32 * i, 32);
+        copy = hash; sha256_final(&copy, out); sc_set_b32(&zi, out, NULL);
+        if (!fe_set_b32_limit(&rx, aggsig + 32 * i)) return 0;
+        if (!ge_set_xo(&rp, &rx, 0)) return 0;
+        sha256_init(&h); sha256_write(&h, tc, 32); sha256_write(&h, tc, 32);
+        sha256_write(&h, aggsig + 32 * i, 32); sha256_write(&h, pks32 + 32 * i, 32); sha256_write(&h, msgs32 + 32 * i, 32); sha256_final(&h, out);
+        sc_set_b32(&ei, out, NULL);
+        gej_set_ge(&ppj, &pp); ecmult(&ti, &ppj, &ei, NULL);
+        gej_add_ge(&t2, &ti, &rp); ti = t2;
+        if (i != 0) { ecmult(&t2, &ti, &zi, NULL); ti = t2; }
+        gej_add(&t2, &rhs, &ti); rhs = t2;
+    }
+    sc_set_b32(&s, aggsig + 32 * n, &overflow); if (overflow) return 0;
+    { gej gj, ng; memset(&gj, 0, sizeof(gj)); gj.inf = 1; ecmult(&lhs, &gj, NULL, &s); gej_neg(&ng, &lhs); gej_add(&lhs, &ng, &rhs); }
+    return lhs.inf;
+}
+
 /* ============================================================= bppp ===================================================== */
 static int parse33(ge *p, const unsigned char *in) {                   /* eckey_impl.h:18-22 */
     fe x;

@@ -20,6 +20,8 @@ ZO_API int zo_rangeproof_verify(uint64_t *min_value, uint64_t *max_value, const 
 ZO_API void zo_rangeproof_verify_many(int *results, uint64_t *min_v, uint64_t *max_v, const unsigned char *commits33, const unsigned char *proofs, size_t stride,
                                       const size_t *plens, const unsigned char *gens64, size_t n, int threads);
 ZO_API int zo_schnorrsig_verify(const unsigned char *sig64, const unsigned char *msg, size_t msglen, const unsigned char *pk32);
+/* secp256k1_schnorrsig_aggverify (modules/schnorrsig_halfagg/main_impl.h:108-198); keys as 32-byte x-only serialisations */
+ZO_API int zo_schnorrsig_aggverify(const unsigned char *pks32, const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len);
 ZO_API int zo_bppp_norm_verify(const unsigned char *proof, size_t proof_len, const unsigned char *transcript104, const unsigned char *rho32,
                                const unsigned char *gens33, size_t n_gens, size_t g_len, const unsigned char *c_vec32, size_t c_len, const unsigned char *commit33);
 ZO_API int zo_surjectionproof_verify(const unsigned char *proof, size_t plen, const unsigned char *in_tags64, size_t n_tags, const unsigned char *out_tag64);

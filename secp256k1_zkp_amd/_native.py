@@ -31,6 +31,7 @@ SIGNATURES = {
     "s2k_gej_sum_dev": (_c.c_int, [_vp, _vp] + [_vp] * 3 + [_sz]),
     "secp256k1_schnorrsig_verify_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
     "secp256k1_schnorrsig_verify_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
+    "secp256k1_schnorrsig_aggverify_amd": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _vp, _sz, _vp, _sz]),
     "secp256k1_rangeproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -115,6 +115,18 @@ class Engine:
         self._check(self._lib.secp256k1_schnorrsig_verify_batch_dev(self._h, stream, _dp(results), _dp(sigs), _dp(msgs), msglen, _dp(pubkeys),
                                                                     pk_format, n), "secp256k1_schnorrsig_verify_batch_dev")
 
+    # ---- secp256k1_schnorrsig_aggverify (modules/schnorrsig_halfagg/main_impl.h:108-198) as one MSM -------------
+    def schnorrsig_aggverify(self, pubkeys, msgs32, aggsig, pk_format=0, n=None):
+        """pubkeys: (n,32) serialised x-only keys (or (n,64) objects with pk_format=1); msgs32: (n,32); aggsig: bytes r_0..r_{n-1}|s.
+        n defaults to the number of messages.  Returns the reference's verdict (0/1)."""
+        pubkeys = _u8(pubkeys); msgs32 = _u8(msgs32); aggsig = _u8(aggsig)
+        if n is None:
+            n = msgs32.size // 32
+        res = np.zeros(1, np.int32)
+        self._check(self._lib.secp256k1_schnorrsig_aggverify_amd(self._h, _p(res), _p(pubkeys) if n else None, pk_format, _p(msgs32) if n else None, n,
+                                                                 _p(aggsig), aggsig.size), "secp256k1_schnorrsig_aggverify_amd")
+        return int(res[0])
+
     # ---- secp256k1_rangeproof_verify (modules/rangeproof/main_impl.h:54-71), batched ---------------------------
     @staticmethod
     def pack(items):

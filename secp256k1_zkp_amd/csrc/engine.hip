@@ -11,6 +11,7 @@
 #include "msm.h"
 #include "bppp.h"
 #include "surjection.h"
+#include "halfagg.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -1013,6 +1014,102 @@ extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* re
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }
+// ------------------------------------------------------------------------------------------------------------
+// half-aggregated Schnorr signatures (halfagg.h): one (2n+1)-term MSM per aggregate
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_ha_points(unsigned char* pts, unsigned char* pkx32, u32* flags, const unsigned char* aggsig, const unsigned char* pks, int pk_format, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!ha_points(pts + 128 * i, pkx32 + 32 * i, aggsig + 32 * i, pks + (pk_format ? 64 : 32) * i, pk_format)) flags[0] = 1u;
+}
+__global__ void __launch_bounds__(256)
+k_ha_schedule(u32* wk, const unsigned char* aggsig, const unsigned char* pkx32, const unsigned char* msgs32, size_t nblocks) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nblocks) ha_schedule(wk + 64 * j, aggsig, pkx32, msgs32, j);
+}
+// ha_rounds with the three-input logic spelled out (v_bitop3_b32: xor3 = 0x96, ch = 0xCA, maj = 0xE8): 14 vector
+// instructions per round instead of the 18 the generic source compiles to -- this chain is pure single-wave issue latency
+__device__ __forceinline__ void ha_rounds_dev(u32 s[8], const u32* __restrict__ wk) {
+    u32 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+#pragma unroll
+    for (int t = 0; t < 64; t++) {
+        const u32 S1 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbit(e, e, 6), __builtin_amdgcn_alignbit(e, e, 11), __builtin_amdgcn_alignbit(e, e, 25), 0x96);
+        const u32 ch = __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);
+        const u32 t1 = h + S1 + ch + wk[t];
+        const u32 S0 = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_alignbit(a, a, 2), __builtin_amdgcn_alignbit(a, a, 13), __builtin_amdgcn_alignbit(a, a, 22), 0x96);
+        const u32 mj = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+    }
+    s[0] += a; s[1] += b; s[2] += c; s[3] += d; s[4] += e; s[5] += f; s[6] += g; s[7] += h;
+}
+__global__ void __launch_bounds__(64)
+k_ha_chain(u32* states, const u32* __restrict__ wk, size_t nblocks) {
+    u32 st[8]; ha_tag_midstate(st);
+    // keep the state in vector registers: left to itself the compiler puts these wave-uniform values in SGPRs and then bounces
+    // every rotate through v_alignbit_b32 + v_readfirstlane_b32 (the scalar unit has no rotate), which is ~2.5x slower
+    for (int k = 0; k < 8; k++) S2K_OPAQUE(st[k]);
+    for (size_t j = 0; j < nblocks; j++) {
+        ha_rounds_dev(st, wk + 64 * j);
+        if (threadIdx.x == 0) { for (int k = 0; k < 8; k++) states[8 * j + k] = st[k]; }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_ha_scalars(unsigned char* sc, unsigned char* g32, u32* flags, const u32* states, schnorr_midstate bip340, const unsigned char* aggsig,
+             const unsigned char* pkx32, const unsigned char* msgs32, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && !ha_gscalar(g32, aggsig + 32 * n)) flags[0] = 1u;
+    if (i < n) ha_scalars(sc + 64 * i, states, bip340, aggsig, pkx32, msgs32, i);
+}
+__global__ void k_ha_final(int32_t* result, const u32* flags, const u32* res28) {
+    if (threadIdx.x || blockIdx.x) return;
+    *result = (flags[0] == 0u) && (res28[27] != 0u);
+}
+extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32,
+                                                  size_t n, const unsigned char* aggsig, size_t aggsig_len) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "null engine");
+    if (!result || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "illegal argument (ARG_CHECK)");
+    *result = 0;
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 1;          // main_impl.h:122-125
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pkb = pk_format ? 64 : 32, nblocks = (3 * n) >> 1, nt = 2 * n + 1;
+    const msm_plan pl = msm_make_plan(nt);
+    const size_t own = ws_need({pkb * n + 64, 32 * n + 64, 32 * (n + 1), 128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16});
+    if (!engine_workspace(e, own + msm_ws_bytes(nt + 1, pl))) return 0;
+    ws_carver c{e->ws, 0};
+    unsigned char* d_pk = c.take<unsigned char>(pkb * n + 64); unsigned char* d_msg = c.take<unsigned char>(32 * n + 64);
+    unsigned char* d_agg = c.take<unsigned char>(32 * (n + 1)); unsigned char* d_pts = c.take<unsigned char>(128 * n + 64);
+    unsigned char* d_pkx = c.take<unsigned char>(32 * n + 64); u32* d_wk = c.take<u32>(nblocks * 64 + 16); u32* d_states = c.take<u32>(nblocks * 8 + 16);
+    unsigned char* d_sc = c.take<unsigned char>(64 * n + 64); unsigned char* d_g = c.take<unsigned char>(64); u32* d_flags = c.take<u32>(16);
+    int32_t* d_res = c.take<int32_t>(4);
+    hipStream_t st = e->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(d_pk, pubkeys, pkb * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_msg, msgs32, 32 * n, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(d_agg, aggsig, 32 * (n + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_flags, 0, 64, st));
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    const unsigned bn = (unsigned)((n + 255) / 256);
+    if (n) hipLaunchKernelGGL(k_ha_points, dim3(bn), dim3(256), 0, st, d_pts, d_pkx, d_flags, d_agg, d_pk, pk_format, n);
+    if (nblocks) {
+        hipLaunchKernelGGL(k_ha_schedule, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, d_wk, d_agg, d_pkx, d_msg, nblocks);
+        hipLaunchKernelGGL(k_ha_chain, dim3(1), dim3(64), 0, st, d_states, d_wk, nblocks);
+    }
+    hipLaunchKernelGGL(k_ha_scalars, dim3(bn ? bn : 1), dim3(256), 0, st, d_sc, d_g, d_flags, d_states, e->bip340, d_agg, d_pkx, d_msg, n);
+    HIPCHK(hipGetLastError());
+    u32* res28 = nullptr;
+    // the MSM's points are R_0, P_0, R_1, P_1, ... with scalars z_0, z_0 e_0, z_1, z_1 e_1, ...; the generator term carries -s
+    if (!msm_launch(e, st, c, &res28, d_g, d_sc, d_pts, nullptr, 2 * n)) return 0;
+    hipLaunchKernelGGL(k_ha_final, dim3(1), dim3(64), 0, st, d_res, d_flags, res28);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipMemcpyAsync(result, d_res, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+
 // ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
 #define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::recursive_mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }

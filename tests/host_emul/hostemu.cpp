@@ -11,6 +11,7 @@
 #include "../../secp256k1_zkp_amd/csrc/msm.h"
 #include "../../secp256k1_zkp_amd/csrc/bppp.h"
 #include "../../secp256k1_zkp_amd/csrc/surjection.h"
+#include "../../secp256k1_zkp_amd/csrc/halfagg.h"
 #include <string.h>
 #include <vector>
 
@@ -228,5 +229,24 @@ int emu_gej_sum(unsigned char* r64, const u32* gej28, size_t count) {
 
 int emu_surjection_verify(const unsigned char* proof, size_t plen, const unsigned char* in_tags64, size_t n_tags, const unsigned char* out_tag64) {
     return sj_verify_lane(proof, plen, in_tags64, n_tags, out_tag64, 1, gtab_host(), g_lm);
+}
+
+// the kernel sequence of secp256k1_schnorrsig_aggverify_amd (engine.hip) run sequentially: points, schedules, chain, scalars, MSM
+int emu_halfagg_verify(const unsigned char* pks, int pk_format, const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len) {
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 0;
+    const size_t nblocks = (3 * n) >> 1;
+    std::vector<unsigned char> pts(128 * n + 1), pkx(32 * n + 1), sc(64 * n + 1);
+    std::vector<u32> wk(64 * nblocks + 1), states(8 * nblocks + 1);
+    int ok = 1;
+    for (size_t i = 0; i < n; i++) ok &= ha_points(pts.data() + 128 * i, pkx.data() + 32 * i, aggsig + 32 * i, pks + (pk_format ? 64 : 32) * i, pk_format);
+    for (size_t j = 0; j < nblocks; j++) ha_schedule(wk.data() + 64 * j, aggsig, pkx.data(), msgs32, j);
+    u32 st[8]; ha_tag_midstate(st);
+    for (size_t j = 0; j < nblocks; j++) { ha_rounds(st, wk.data() + 64 * j); for (int k = 0; k < 8; k++) states[8 * j + k] = st[k]; }
+    schnorr_midstate mid; schnorr_tag_midstate(mid);
+    for (size_t i = 0; i < n; i++) ha_scalars(sc.data() + 64 * i, states.data(), mid, aggsig, pkx.data(), msgs32, i);
+    unsigned char g32[32], r64[64];
+    ok &= ha_gscalar(g32, aggsig + 32 * n);
+    const int inf = emu_msm(r64, g32, sc.data(), pts.data(), nullptr, 2 * n, 0);
+    return ok && inf;
 }
 }

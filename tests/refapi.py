@@ -112,6 +112,36 @@ class Ref:
         assert self.lib.ref_bppp_generators(_p(out), ctypes.c_size_t(n)) == 1
         return out
 
+    def xonly_objects(self, pks):
+        """(n,32) serialised x-only keys -> (n,64) secp256k1_xonly_pubkey objects as the reference holds them in memory"""
+        pks = np.ascontiguousarray(pks, np.uint8); n = pks.size // 32
+        out = np.zeros((n, 64), np.uint8)
+        assert self.lib.ref_xonly_objects(_p(out), _p(pks), ctypes.c_size_t(n)) == 1
+        return out
+
+    def xonly_valid(self, pks):
+        """which of the (n,32) serialised keys secp256k1_xonly_pubkey_parse accepts"""
+        pks = np.ascontiguousarray(pks, np.uint8).reshape(-1, 32); tmp = np.zeros(64, np.uint8)
+        return np.array([self.lib.ref_xonly_objects(_p(tmp), _p(pks[i].copy()), ctypes.c_size_t(1)) == 1 for i in range(pks.shape[0])])
+
+    def halfagg_aggregate(self, pks, msgs, sigs):
+        """secp256k1_schnorrsig_aggregate on serialised x-only keys; returns the aggregate bytes (32*(n+1))."""
+        pks = np.ascontiguousarray(pks, np.uint8); msgs = np.ascontiguousarray(msgs, np.uint8); sigs = np.ascontiguousarray(sigs, np.uint8)
+        n = sigs.size // 64
+        out = np.zeros(32 * (n + 1), np.uint8); ln = ctypes.c_size_t(out.size)
+        r = self.lib.ref_halfagg_aggregate(_p(out), ctypes.byref(ln), _p(pks), _p(msgs), _p(sigs), ctypes.c_size_t(n))
+        assert r == 1 and ln.value == out.size
+        return out.tobytes()
+
+    def halfagg_verify(self, pks, msgs, aggsig, n=None):
+        """secp256k1_schnorrsig_aggverify; -1 if a key does not parse"""
+        pks = np.frombuffer(bytes(pks), np.uint8) if isinstance(pks, (bytes, bytearray)) else np.ascontiguousarray(pks, np.uint8)
+        msgs = np.frombuffer(bytes(msgs), np.uint8) if isinstance(msgs, (bytes, bytearray)) else np.ascontiguousarray(msgs, np.uint8)
+        agg = np.frombuffer(bytes(aggsig), np.uint8)
+        if n is None:
+            n = msgs.size // 32
+        return int(self.lib.ref_halfagg_verify(_p(pks) if pks.size else None, _p(msgs) if msgs.size else None, ctypes.c_size_t(n), _p(agg), ctypes.c_size_t(agg.size)))
+
     def make_bppp(self, n, rng, g_len, h_len):
         """n norm-argument proofs over the deterministic generator set; returns the batch-API argument tuple."""
         gens = self.bppp_generators(g_len + h_len)

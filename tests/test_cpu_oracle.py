@@ -171,6 +171,27 @@ def test_emu_msm(emu, ref):
         assert i1 == i2 and r1.tobytes() == out.raw, (n, g, c)
 
 
+def test_emu_halfagg(emu, ref):
+    """device code of halfagg.h (points, schedules, chain, scalars) + the bucket MSM, on the host, against the golden verdicts
+    and against the reference on a 120-signature aggregate (bucket path) with mutations"""
+    for v in _golden("halfagg_vectors.json")["vectors"]:
+        agg = bytes.fromhex(v["aggsig"])
+        r = emu.emu_halfagg_verify(bytes.fromhex(v["pks"]), 0, bytes.fromhex(v["msgs"]), ctypes.c_size_t(v["n"]), agg, ctypes.c_size_t(len(agg)))
+        assert r == v["result"], v["name"]
+    rng = np.random.default_rng(77)
+    n = 120
+    sigs, msgs, pks = ref.make_schnorr(n, rng)
+    agg = ref.halfagg_aggregate(pks, msgs, sigs)
+    for k in range(4):
+        a = bytearray(agg); m = msgs.copy()
+        if k == 1: a[32 * 57 + 3] ^= 1
+        if k == 2: a[-5] ^= 8
+        if k == 3: m[119, 0] ^= 1
+        exp = max(0, ref.halfagg_verify(pks, m, bytes(a), n))
+        assert emu.emu_halfagg_verify(pks.tobytes(), 0, m.tobytes(), ctypes.c_size_t(n), bytes(a), ctypes.c_size_t(len(a))) == exp, k
+        assert exp == (k == 0)
+
+
 def test_emu_bppp(emu, ref):
     g = _golden("bppp_verify_vectors.json")
     gens = bytes.fromhex(g["gens"])

@@ -153,3 +153,30 @@ def test_surjection_vs_reference(zo, ref):
             t2 = tags.copy()
             if k == 3: p = proof; t2[0, 40] ^= 1
             assert zo.zo_surjectionproof_verify(p, ctypes.c_size_t(len(p)), t2.tobytes(), ctypes.c_size_t(n_in), out.tobytes()) == ref.surjection_verify(p, t2, out)
+
+
+def _ha_golden():
+    return [(v["name"], bytes.fromhex(v["pks"]), bytes.fromhex(v["msgs"]), v["n"], bytes.fromhex(v["aggsig"]), v["result"])
+            for v in _golden("halfagg_vectors.json")["vectors"]]
+
+
+def test_golden_halfagg(zo, ref):
+    """spec vectors of modules/schnorrsig_halfagg/tests_impl.h:73-168 + reference-generated aggregates and their mutations"""
+    for name, pks, msgs, n, agg, result in _ha_golden():
+        assert zo.zo_schnorrsig_aggverify(pks, msgs, ctypes.c_size_t(n), agg, ctypes.c_size_t(len(agg))) == result, name
+        assert max(0, ref.halfagg_verify(pks, msgs, agg, n)) == result, name
+
+
+def test_halfagg_vs_reference(zo, ref):
+    rng = np.random.default_rng(55)
+    for n in (1, 4, 11):
+        sigs, msgs, pks = ref.make_schnorr(n, rng)
+        agg = ref.halfagg_aggregate(pks, msgs, sigs)
+        assert zo.zo_schnorrsig_aggverify(pks.tobytes(), msgs.tobytes(), ctypes.c_size_t(n), agg, ctypes.c_size_t(len(agg))) == 1
+        for k in range(6):
+            a = bytearray(agg); m = msgs.copy(); p = pks.copy()
+            if k < 3: a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 3: m[int(rng.integers(0, n)), 7] ^= 2
+            else: p[int(rng.integers(0, n)), int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+            exp = max(0, ref.halfagg_verify(p.tobytes(), m.tobytes(), bytes(a), n))
+            assert zo.zo_schnorrsig_aggverify(p.tobytes(), m.tobytes(), ctypes.c_size_t(n), bytes(a), ctypes.c_size_t(len(a))) == exp

@@ -41,3 +41,7 @@ def test_random_batch(engine, ref):
     res = engine.schnorrsig_verify_batch(sigs, msgs, pks)
     assert np.array_equal(res, exp)
     assert exp.sum() >= n - n // 16 - 2 and exp.sum() < n
+    # the same keys as 64-byte secp256k1_xonly_pubkey objects (pk_format 1); keys that do not parse have no such form
+    good = np.nonzero(ref.xonly_valid(pks[:600]))[0]
+    res1 = engine.schnorrsig_verify_batch(sigs[good], msgs[good], ref.xonly_objects(pks[good]), pk_format=1)
+    assert np.array_equal(res1, exp[good]) and len(good) > 500
