@@ -11,6 +11,7 @@ One JSON line is printed by rank 0.  Also reported: the roofline of the dominant
 own CPU path timed on the host cores of the same box (oracle/_ref, bounded sample).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -212,6 +213,14 @@ def main():
         value = world * n * args.steps / dt
         kms = float(np.mean(kern_ms))
         achieved = PROOF_BYTES_ALGO * n / (kms * 1e-3) / 1e9
+        # memory-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the
+        # committed rocprofv3 measurement of this same command (profiles/, tools/profile_round.sh), scaled to this batch
+        traffic, traffic_src = None, None
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_rp_rings.json")))
+        if pmc:
+            pj = json.load(open(pmc[-1]))
+            traffic = pj["hbm_bytes_per_launch_raw"] * n / 16384.0
+            traffic_src = os.path.relpath(pmc[-1], ROOT)
         out = {
             "metric": "64-bit Borromean rangeproof verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -219,8 +228,9 @@ def main():
             "config": {"workload": "secp256k1_rangeproof_verify, batch of %d 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)" % n,
                        "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)"},
             "roofline": {"bound": "hbm", "kernel": "k_rp_rings", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kms,
-                         "note": "path is integer-VALU bound (SURVEY 8d); see valu_roofline"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, incl. Infinity-Cache hits)",
+                         "traffic_source": traffic_src, "algorithmic_bytes": PROOF_BYTES_ALGO * n, "kernel_ms": kms,
+                         "note": "path is integer-VALU bound (SURVEY 8d); see valu_roofline. traffic >> algorithmic bytes: per-lane odd-multiples tables and register spills, DESIGN.md section 5"},
             "valu_roofline": {"unit": "v_mad_u64_u32 lane-ops/s", "achieved": 4 * MAC64_PER_PROOF * n / (kms * 1e-3), "peak": MAD32_PEAK,
                               "frac": 4 * MAC64_PER_PROOF * n / (kms * 1e-3) / MAD32_PEAK,
                               "note": "algorithmic 6.6e6 MAC64/proof (reference schedule) x 4 mad_u64_u32; peak measured with tools/ubench"},
