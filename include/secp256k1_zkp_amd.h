@@ -116,6 +116,16 @@ S2K_API int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value
                                             const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
                                             size_t extra_commit_len, const void* gen);
 
+/* ---- Pedersen commitment tallies ------------------------------------------------------------------------------------
+ * results[t] = secp256k1_pedersen_verify_tally(ctx, pos_t, pcnt_t, neg_t, ncnt_t)
+ *                                       (include/secp256k1_generator.h:174-196, src/modules/generator/main_impl.h:371-396)
+ * commits33: all commitments of all tallies back to back in serialised form (33 bytes; equivalently the first 33 bytes of each
+ * secp256k1_pedersen_commitment object); tally t owns commitments [tally_off[t], tally_off[t+1]) and the first n_pos[t] of them
+ * are its positive list, the rest its negative list.  A commitment that is not a valid encoding (cannot come out of
+ * secp256k1_pedersen_commitment_parse) makes its tally 0. */
+S2K_API int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off,
+                                                  const uint64_t* n_pos, size_t n_tallies);
+
 /* ---- surjection-proof batch verification -----------------------------------------------------------------------------
  * results[i] = secp256k1_surjectionproof_parse(ctx, &proof, ser_i, len_i) &&
  *              secp256k1_surjectionproof_verify(ctx, &proof, ephemeral_input_tags_i, n_i, &ephemeral_output_tag_i)

@@ -423,3 +423,43 @@ REF_EXPORT int ref_xonly_objects(unsigned char *out64, const unsigned char *pks3
     secp256k1_context_destroy(ctx);
     return ok;
 }
+
+/* ---- Pedersen commitments and tallies (src/modules/generator/main_impl.h:275-396) ------------------------------------ */
+REF_EXPORT int ref_pedersen_commit_many(unsigned char *out33, const unsigned char *blinds32, const uint64_t *values, const unsigned char *gen64, size_t n) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    secp256k1_generator gen; size_t i; int ok = 1;
+    memcpy(&gen, gen64, 64);
+    for (i = 0; i < n; i++) {
+        secp256k1_pedersen_commitment c;
+        if (!secp256k1_pedersen_commit(ctx, &c, blinds32 + 32 * i, values[i], &gen)) { ok = 0; memset(out33 + 33 * i, 0, 33); continue; }
+        secp256k1_pedersen_commitment_serialize(ctx, out33 + 33 * i, &c);
+    }
+    secp256k1_context_destroy(ctx);
+    return ok;
+}
+/* blind_out = sum of the first npositive blinds - sum of the others */
+REF_EXPORT int ref_pedersen_blind_sum(unsigned char *out32, const unsigned char *blinds32, size_t n, size_t npositive) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    const unsigned char **ptr = (const unsigned char**)malloc(sizeof(*ptr) * (n ? n : 1));
+    size_t i; int r;
+    for (i = 0; i < n; i++) ptr[i] = blinds32 + 32 * i;
+    r = secp256k1_pedersen_blind_sum(ctx, out32, ptr, n, npositive);
+    free(ptr);
+    secp256k1_context_destroy(ctx);
+    return r;
+}
+/* tally t = commitments [tally_off[t], tally_off[t+1]) of commits33, the first n_pos[t] on the positive side; -1 if one does not parse */
+REF_EXPORT void ref_pedersen_verify_tally_many(int *results, const unsigned char *commits33, const uint64_t *tally_off, const uint64_t *n_pos, size_t n_tallies) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    size_t t;
+    for (t = 0; t < n_tallies; t++) {
+        const size_t a = (size_t)tally_off[t], cnt = (size_t)(tally_off[t + 1] - tally_off[t]), np = (size_t)n_pos[t];
+        secp256k1_pedersen_commitment *c = (secp256k1_pedersen_commitment*)malloc(sizeof(*c) * (cnt ? cnt : 1));
+        const secp256k1_pedersen_commitment **p = (const secp256k1_pedersen_commitment**)malloc(sizeof(*p) * (cnt ? cnt : 1));
+        size_t i; int ok = 1;
+        for (i = 0; i < cnt; i++) { p[i] = &c[i]; if (!secp256k1_pedersen_commitment_parse(ctx, &c[i], commits33 + 33 * (a + i))) ok = 0; }
+        results[t] = ok ? secp256k1_pedersen_verify_tally(ctx, np ? p : NULL, np, cnt - np ? p + np : NULL, cnt - np) : -1;
+        free(c); free(p);
+    }
+    secp256k1_context_destroy(ctx);
+}

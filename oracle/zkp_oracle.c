@@ -557,6 +557,27 @@ int zo_schnorrsig_aggverify(const unsigned char *pks32, const unsigned char *msg
     return lhs.inf;
 }
 
+/* ========================================================== pedersen tally =============================================== */
+/* secp256k1_pedersen_verify_tally, modules/generator/main_impl.h:371-396: acc = -(sum of the negative list), then add the positive
+ * list, accept iff infinity.  Commitments as 33-byte serialisations, decoded like secp256k1_pedersen_commitment_load (:266-273);
+ * returns -1 for an encoding secp256k1_pedersen_commitment_parse would refuse. */
+int zo_pedersen_verify_tally(const unsigned char *pos33, size_t pcnt, const unsigned char *neg33, size_t ncnt) {
+    gej acc, t; ge add; fe x; size_t i;
+    gej_set_inf(&acc);
+    for (i = 0; i < ncnt; i++) {
+        if ((neg33[33 * i] & 0xFE) != 8 || !fe_set_b32_limit(&x, neg33 + 33 * i + 1) || !ge_set_xquad(&add, &x)) return -1;
+        if (neg33[33 * i] & 1) ge_neg(&add, &add);
+        gej_add_ge(&t, &acc, &add); acc = t;
+    }
+    gej_neg(&t, &acc); acc = t;
+    for (i = 0; i < pcnt; i++) {
+        if ((pos33[33 * i] & 0xFE) != 8 || !fe_set_b32_limit(&x, pos33 + 33 * i + 1) || !ge_set_xquad(&add, &x)) return -1;
+        if (pos33[33 * i] & 1) ge_neg(&add, &add);
+        gej_add_ge(&t, &acc, &add); acc = t;
+    }
+    return acc.inf;
+}
+
 /* ============================================================= bppp ===================================================== */
 static int parse33(ge *p, const unsigned char *in) {                   /* eckey_impl.h:18-22 */
     fe x;

@@ -127,6 +127,22 @@ class Engine:
                                                                  _p(aggsig), aggsig.size), "secp256k1_schnorrsig_aggverify_amd")
         return int(res[0])
 
+    # ---- secp256k1_pedersen_verify_tally (modules/generator/main_impl.h:371-396), batched -------------------------
+    def pedersen_verify_tally_batch(self, tallies):
+        """tallies: list of (positive, negative), each a (k,33) uint8 array (or list of 33-byte strings) of serialised commitments.
+        Returns int32[n]."""
+        parts, off, npos = [], [0], []
+        for pos, neg in tallies:
+            pos = _u8(b"".join(bytes(x) for x in pos) if isinstance(pos, (list, tuple)) else pos).reshape(-1, 33)
+            neg = _u8(b"".join(bytes(x) for x in neg) if isinstance(neg, (list, tuple)) else neg).reshape(-1, 33)
+            parts += [pos, neg]; npos.append(pos.shape[0]); off.append(off[-1] + pos.shape[0] + neg.shape[0])
+        n = len(tallies)
+        data = np.ascontiguousarray(np.concatenate(parts)) if parts and off[-1] else np.zeros((1, 33), np.uint8)
+        off = np.array(off, np.uint64); npos = np.array(npos + [0], np.uint64)
+        res = np.zeros(max(n, 1), np.int32)
+        self._check(self._lib.secp256k1_pedersen_verify_tally_batch(self._h, _p(res), _p(data), _p(off), _p(npos), n), "secp256k1_pedersen_verify_tally_batch")
+        return res[:n]
+
     # ---- secp256k1_rangeproof_verify (modules/rangeproof/main_impl.h:54-71), batched ---------------------------
     @staticmethod
     def pack(items):

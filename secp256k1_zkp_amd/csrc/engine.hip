@@ -12,6 +12,7 @@
 #include "bppp.h"
 #include "surjection.h"
 #include "halfagg.h"
+#include "pedersen.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -1106,6 +1107,82 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
     HIPCHK(hipMemcpyAsync(result, d_res, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Pedersen tallies (pedersen.h): one lane per commitment, then bounded-run partial sums per tally
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pt_load(u32* out28, u32* bad, const unsigned char* commits33, const unsigned long long* tally_off, const unsigned long long* n_pos, size_t n_tallies, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t t = pedersen_find_tally(tally_off, n_tallies, i);
+    ge c; const int ok = pedersen_load(c, commits33 + 33 * i);
+    if (i - tally_off[t] >= n_pos[t]) { fe_neg(c.y, c.y, 1); }          // the negative list (:388)
+    gej j; gej_set_ge(j, c); j.inf = 0;
+    gej_store28(out28 + i * 28, j);
+    if (!ok) bad[t] = 1u;
+}
+__global__ void k_pt_final(int32_t* results, const u32* sums28, const u32* off_last, const u32* bad, size_t n_tallies) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tallies) return;
+    int inf = 1;
+    if (off_last[t + 1] > off_last[t]) inf = (int)sums28[(size_t)off_last[t] * 28 + 27];
+    results[t] = inf && !bad[t];
+}
+extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off,
+                                                     const uint64_t* n_pos, size_t n_tallies) {
+    if (!e) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "null engine");
+    if (n_tallies == 0) return 1;
+    if (!results || !tally_off || !n_pos) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
+    const size_t total = (size_t)tally_off[n_tallies];
+    if (total >= ((size_t)1 << 32)) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "more than 2^32 commitments in one call");
+    for (size_t t = 0; t < n_tallies; t++)
+        if (tally_off[t + 1] < tally_off[t] || n_pos[t] > tally_off[t + 1] - tally_off[t]) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "malformed tally offsets");
+    if (total && !commits33) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
+    // the offset arrays of every partial-sum round are known from the sizes alone: built here, uploaded once
+    const u32 T = 8;
+    std::vector<std::vector<u32>> offs;
+    { std::vector<u32> o(n_tallies + 1); for (size_t t = 0; t <= n_tallies; t++) o[t] = (u32)tally_off[t]; offs.push_back(o); }
+    for (;;) {
+        const std::vector<u32>& in = offs.back();
+        u32 mx = 0; for (size_t t = 0; t < n_tallies; t++) mx = std::max(mx, in[t + 1] - in[t]);
+        if (mx <= 1) break;
+        std::vector<u32> o(n_tallies + 1); o[0] = 0;
+        for (size_t t = 0; t < n_tallies; t++) o[t + 1] = o[t] + (in[t + 1] - in[t] + T - 1) / T;
+        offs.push_back(o);
+    }
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t half = (size_t)offs.size() > 1 ? (size_t)offs[1][n_tallies] : 1;
+    if (!engine_workspace(e, ws_need({33 * total + 64, 8 * (n_tallies + 1), 8 * n_tallies + 8, 4 * n_tallies, 4 * n_tallies + 4, offs.size() * (n_tallies + 1) * 4 + 256 * offs.size(),
+                                      (total + 1) * 28 * 4, (half + 1) * 28 * 4}))) return 0;
+    ws_carver c{e->ws, 0};
+    unsigned char* d_c = c.take<unsigned char>(33 * total + 64); unsigned long long* d_off = c.take<unsigned long long>(n_tallies + 1);
+    unsigned long long* d_np = c.take<unsigned long long>(n_tallies + 1); int32_t* d_res = c.take<int32_t>(n_tallies); u32* d_bad = c.take<u32>(n_tallies + 1);
+    std::vector<u32*> d_offs; for (size_t r = 0; r < offs.size(); r++) d_offs.push_back(c.take<u32>(n_tallies + 1));
+    u32* bufA = c.take<u32>((total + 1) * 28); u32* bufB = c.take<u32>((half + 1) * 28);
+    hipStream_t st = e->stream;
+    if (total) HIPCHK(hipMemcpyAsync(d_c, commits33, 33 * total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, tally_off, 8 * (n_tallies + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_np, n_pos, 8 * n_tallies, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_bad, 0, 4 * (n_tallies + 1), st));
+    for (size_t r = 0; r < offs.size(); r++) HIPCHK(hipMemcpyAsync(d_offs[r], offs[r].data(), 4 * (n_tallies + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
+    if (total) hipLaunchKernelGGL(k_pt_load, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bufA, d_bad, d_c, d_off, d_np, n_tallies, total);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    u32 *pin = bufA, *pout = bufB;
+    for (size_t r = 1; r < offs.size(); r++) {
+        const size_t lanes = offs[r][n_tallies];
+        hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, pout, pin, d_offs[r - 1], d_offs[r], (u32)n_tallies, T);
+        u32* tmp = pin; pin = pout; pout = tmp;
+    }
+    hipLaunchKernelGGL(k_pt_final, dim3((unsigned)((n_tallies + 255) / 256)), dim3(256), 0, st, d_res, pin, d_offs.back(), d_bad, n_tallies);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n_tallies, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }

@@ -179,7 +179,38 @@ def halfagg():
     print("halfagg:", len(vecs), "vectors", sum(v["result"] for v in vecs), "accepted")
 
 
+def pedersen():
+    """The reference has no fixed vectors for secp256k1_pedersen_verify_tally (src/modules/generator/tests_impl.h:239-300 draws random
+    transactions); these are transactions built the same way with oracle/_ref (fixed seed) and the reference's verdicts, plus
+    unbalanced / reordered / duplicated / unparseable variants."""
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tests.refapi import Ref
+    ref = Ref(); rng = np.random.default_rng(2718)
+    cases = []
+    def add(name, pos, neg):
+        res = int(ref.pedersen_verify_tally_many([(pos, neg)])[0])
+        cases.append(dict(name=name, pos=[bytes(x).hex() for x in np.asarray(pos).reshape(-1, 33)], neg=[bytes(x).hex() for x in np.asarray(neg).reshape(-1, 33)], result=res))
+    for k, (ni, no) in enumerate(((1, 1), (1, 2), (2, 2), (3, 5), (8, 9), (1, 17))):
+        a, b = ref.make_balanced_tally(rng, ni, no)
+        add("balanced_%d_%d" % (ni, no), a, b); add("swapped_%d_%d" % (ni, no), b, a)
+        add("missing_output_%d_%d" % (ni, no), a, b[:-1])
+        c = b.copy(); c[0, 0] ^= 1; add("flipped_sign_%d_%d" % (ni, no), a, c)
+        if k == 3:
+            add("both_sides_doubled", np.concatenate([a, a]), np.concatenate([b, b]))
+            add("same_commitment_both_sides", a[:1], a[:1]); add("twice_vs_once", np.concatenate([a[:1], a[:1]]), a[:1])
+            c = b.copy(); c[1, 0] = 2; add("bad_prefix", a, c)
+            c = b.copy(); c[1, 1:] = 0xFF; add("x_overflow", a, c)
+            c = b.copy(); c[1, 1:] = 0; c[1, 33 - 1] = 5; add("x_not_on_curve", a, c)
+    add("empty", np.zeros((0, 33), np.uint8), np.zeros((0, 33), np.uint8))
+    a, b = ref.make_balanced_tally(rng, 2, 2)
+    add("only_positive", a, a[:0]); add("only_negative", a[:0], a)
+    json.dump(dict(source="generated by oracle/_ref (secp256k1_pedersen_commit / _blind_sum / _verify_tally), cf. src/modules/generator/tests_impl.h:193-300; result -1 = a commitment does not parse",
+                   vectors=cases), open(os.path.join(OUT, "pedersen_tally_vectors.json"), "w"), indent=0)
+    print("pedersen tally:", len(cases), "vectors", [c["result"] for c in cases])
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at " + REF)
-    rangeproof(); bppp(); bip340(); surjection(); halfagg()
+    rangeproof(); bppp(); bip340(); surjection(); halfagg(); pedersen()

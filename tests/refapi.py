@@ -112,6 +112,40 @@ class Ref:
         assert self.lib.ref_bppp_generators(_p(out), ctypes.c_size_t(n)) == 1
         return out
 
+    def pedersen_commit(self, blinds, values, gen64=GENERATOR_H):
+        """secp256k1_pedersen_commit per item -> (n,33) serialised commitments"""
+        blinds = np.ascontiguousarray(blinds, np.uint8); values = np.ascontiguousarray(values, np.uint64); n = values.size
+        out = np.zeros((n, 33), np.uint8); g = np.frombuffer(bytes(gen64), np.uint8).copy()
+        assert self.lib.ref_pedersen_commit_many(_p(out), _p(blinds), _p(values), _p(g), ctypes.c_size_t(n)) == 1
+        return out
+
+    def pedersen_blind_sum(self, blinds, npositive):
+        blinds = np.ascontiguousarray(blinds, np.uint8); n = blinds.size // 32
+        out = np.zeros(32, np.uint8)
+        assert self.lib.ref_pedersen_blind_sum(_p(out), _p(blinds), ctypes.c_size_t(n), ctypes.c_size_t(npositive)) == 1
+        return out
+
+    def make_balanced_tally(self, rng, n_in, n_out, gen64=GENERATOR_H):
+        """(inputs (n_in,33), outputs (n_out,33)) with sum(inputs) == sum(outputs), as src/modules/generator/tests_impl.h:239-300 builds them"""
+        vin = rng.integers(0, 2**40, n_in, dtype=np.uint64); tot = int(vin.sum())
+        cuts = np.sort(rng.integers(0, tot + 1, n_out - 1)) if n_out > 1 else np.array([], np.int64)
+        vout = np.diff(np.concatenate([[0], cuts, [tot]])).astype(np.uint64)
+        blinds = rng.integers(0, 256, (n_in + n_out, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F
+        blinds[-1] = self.pedersen_blind_sum(blinds[:-1], n_in)          # sum(in) - sum(other outs)
+        c = self.pedersen_commit(blinds, np.concatenate([vin, vout]), gen64)
+        return c[:n_in].copy(), c[n_in:].copy()
+
+    def pedersen_verify_tally_many(self, tallies):
+        """list of (pos (k,33), neg (m,33)) -> int array; -1 where a commitment does not parse"""
+        parts, off, npos = [], [0], []
+        for pos, neg in tallies:
+            pos = np.ascontiguousarray(pos, np.uint8).reshape(-1, 33); neg = np.ascontiguousarray(neg, np.uint8).reshape(-1, 33)
+            parts += [pos, neg]; npos.append(pos.shape[0]); off.append(off[-1] + pos.shape[0] + neg.shape[0])
+        data = np.ascontiguousarray(np.concatenate(parts)) if off[-1] else np.zeros((1, 33), np.uint8)
+        off = np.array(off, np.uint64); npos = np.array(npos + [0], np.uint64); res = np.zeros(len(tallies), np.int32)
+        self.lib.ref_pedersen_verify_tally_many(_p(res), _p(data), _p(off), _p(npos), ctypes.c_size_t(len(tallies)))
+        return res
+
     def xonly_objects(self, pks):
         """(n,32) serialised x-only keys -> (n,64) secp256k1_xonly_pubkey objects as the reference holds them in memory"""
         pks = np.ascontiguousarray(pks, np.uint8); n = pks.size // 32

@@ -180,3 +180,17 @@ def test_halfagg_vs_reference(zo, ref):
             else: p[int(rng.integers(0, n)), int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
             exp = max(0, ref.halfagg_verify(p.tobytes(), m.tobytes(), bytes(a), n))
             assert zo.zo_schnorrsig_aggverify(p.tobytes(), m.tobytes(), ctypes.c_size_t(n), bytes(a), ctypes.c_size_t(len(a))) == exp
+
+
+def _pt_golden():
+    out = []
+    for v in _golden("pedersen_tally_vectors.json")["vectors"]:
+        out.append((v["name"], np.frombuffer(bytes.fromhex("".join(v["pos"])), np.uint8).reshape(-1, 33), np.frombuffer(bytes.fromhex("".join(v["neg"])), np.uint8).reshape(-1, 33), v["result"]))
+    return out
+
+
+def test_golden_pedersen_tally(zo, ref):
+    for name, pos, neg, result in _pt_golden():
+        got = zo.zo_pedersen_verify_tally(pos.tobytes(), ctypes.c_size_t(pos.shape[0]), neg.tobytes(), ctypes.c_size_t(neg.shape[0]))
+        assert got == result, name
+        assert int(ref.pedersen_verify_tally_many([(pos, neg)])[0]) == result, name
