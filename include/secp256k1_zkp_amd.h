@@ -110,6 +110,18 @@ S2K_API int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, u
 S2K_API int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                   const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                   const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+/* Rewind: verification as above and, for the proofs that verify, recovery of the committed value, the blinding factor and the
+ * embedded message from the nonce -- per item what
+ *   secp256k1_rangeproof_rewind(ctx, blind_out, &value_out, message_out, &outlen, nonce, &min, &max, commit, proof, plen,
+ *                               extra_commit, extra_commit_len, gen)   (include/secp256k1_rangeproof.h:102-130,
+ *                               src/modules/rangeproof/main_impl.h:31-52, rangeproof_impl.h:61-108,339-485,652-680)
+ * returns and writes.  nonces n*32; blind_out n*32; value_out n; message_out n*msg_stride or NULL; outlen n (in: capacity of
+ * item i's message buffer, at most msg_stride; out: bytes recovered) -- required iff message_out is given.  Items with
+ * results[i] == 0 get zeroed blind/value and outlen 0.  Nonces are secrets: they are copied to the GPU. */
+S2K_API int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, unsigned char* blind_out, uint64_t* value_out, unsigned char* message_out,
+                                              uint64_t* outlen, size_t msg_stride, const unsigned char* nonces, uint64_t* min_value, uint64_t* max_value,
+                                              const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                              const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
 /* Single-item form with the reference's argument list (ctx is accepted and ignored: the engine is process-global,
  * lazily created on device $S2K_DEVICE or 0).  commit / gen point at the reference's 64-byte opaque objects. */
 S2K_API int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value, uint64_t* max_value, const void* commit,

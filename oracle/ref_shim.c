@@ -463,3 +463,49 @@ REF_EXPORT void ref_pedersen_verify_tally_many(int *results, const unsigned char
     }
     secp256k1_context_destroy(ctx);
 }
+
+/* ---- rangeproof rewind (src/modules/rangeproof/main_impl.h:31-52, rangeproof_impl.h:364-485) -------------------------- */
+/* proofs with a caller-chosen nonce and embedded message (message i = msgs + msg_len*i, msg_len <= 4096; may be 0) */
+REF_EXPORT int ref_rangeproof_make_many_msg(unsigned char *commits33, unsigned char *proofs, size_t stride, size_t *plens, const unsigned char *blinds32,
+                                            const uint64_t *values, const unsigned char *gens64, const unsigned char *nonces32, const unsigned char *msgs,
+                                            size_t msg_len, uint64_t min_value, int exp, int min_bits, size_t n, int threads) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    long i; int ok = 1;
+    (void)threads;
+#ifdef _OPENMP
+    #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+#endif
+    for (i = 0; i < (long)n; i++) {
+        secp256k1_pedersen_commitment c; secp256k1_generator g; size_t len = stride;
+        memcpy(g.data, gens64 + 64 * i, 64);
+        if (!secp256k1_pedersen_commit(ctx, &c, blinds32 + 32 * i, values[i], &g)) { ok = 0; continue; }
+        secp256k1_pedersen_commitment_serialize(ctx, commits33 + 33 * i, &c);
+        if (!secp256k1_rangeproof_sign(ctx, proofs + stride * i, &len, min_value, &c, blinds32 + 32 * i, nonces32 + 32 * i, exp, min_bits, values[i],
+                                       msg_len ? msgs + msg_len * i : NULL, msg_len, NULL, 0, &g)) { ok = 0; len = 0; }
+        plens[i] = len;
+    }
+    secp256k1_context_destroy(ctx);
+    return ok;
+}
+/* outlens: in = capacity of each message buffer (<= msg_stride), out = recovered length; msg_out may be NULL (then outlens is ignored) */
+REF_EXPORT void ref_rangeproof_rewind_many(int *results, unsigned char *blind_out, uint64_t *value_out, unsigned char *msg_out, uint64_t *outlens, size_t msg_stride,
+                                           const unsigned char *nonces32, uint64_t *min_v, uint64_t *max_v, const unsigned char *commits33, const unsigned char *proofs,
+                                           size_t stride, const size_t *plens, const unsigned char *gens64, size_t n, int threads) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    long i;
+    (void)threads;
+#ifdef _OPENMP
+    #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+#endif
+    for (i = 0; i < (long)n; i++) {
+        secp256k1_pedersen_commitment c; secp256k1_generator g; size_t ol = msg_out ? (size_t)outlens[i] : 0;
+        results[i] = 0;
+        memcpy(g.data, gens64 + 64 * i, 64);
+        if (secp256k1_pedersen_commitment_parse(ctx, &c, commits33 + 33 * i)) {
+            results[i] = secp256k1_rangeproof_rewind(ctx, blind_out + 32 * i, &value_out[i], msg_out ? msg_out + msg_stride * i : NULL, msg_out ? &ol : NULL,
+                                                     nonces32 + 32 * i, &min_v[i], &max_v[i], &c, proofs + stride * i, plens[i], NULL, 0, &g);
+            if (msg_out) outlens[i] = ol;
+        }
+    }
+    secp256k1_context_destroy(ctx);
+}

@@ -405,7 +405,7 @@ static void borromean_hash(unsigned char *out, const unsigned char *m, const uns
 }
 static void ser33(unsigned char *out, const ge *p) { out[0] = 2 | fe_is_odd(&p->y); fe_get_b32(out + 1, &p->x); }    /* eckey_impl.h:38-45 */
 /* borromean_impl.h:53-104 */
-static int borromean_verify(const unsigned char *e0, const sc *s, const gej *pubs, const size_t *rsizes, size_t nrings, const unsigned char *m) {
+static int borromean_verify(sc *evalues, const unsigned char *e0, const sc *s, const gej *pubs, const size_t *rsizes, size_t nrings, const unsigned char *m) {
     sha256 he0; unsigned char tmp[33]; size_t i, j, count = 0; int overflow;
     sha256_init(&he0);
     for (i = 0; i < nrings; i++) {
@@ -415,6 +415,7 @@ static int borromean_verify(const unsigned char *e0, const sc *s, const gej *pub
         for (j = 0; j < rsizes[i]; j++) {
             gej rj; ge ra;
             if (overflow || sc_is_zero(&s[count]) || sc_is_zero(&ens) || pubs[count].inf) return 0;
+            if (evalues) evalues[count] = ens;                                 /* :80-83 */
             ecmult(&rj, &pubs[count], &ens, &s[count]);
             if (rj.inf) return 0;
             ge_set_gej(&ra, &rj); ser33(tmp, &ra);
@@ -455,14 +456,113 @@ static void mul_u64(gej *r, u64 k, const ge *p) {                      /* value 
     int i; gej_set_inf(r);
     for (i = 63; i >= 0; i--) { gej_double(r, r); if ((k >> i) & 1) gej_add_ge(r, r, p); }
 }
-/* rangeproof_impl.h:541-683 (verify only) with main_impl.h:54-71 and generator/main_impl.h:40-49,266-273 */
-int zo_rangeproof_verify(uint64_t *min_value, uint64_t *max_value, const unsigned char *commit33, const unsigned char *proof, size_t plen,
-                         const unsigned char *extra, size_t extra_len, const unsigned char *gen64) {
-    gej accj, pubs[128], base; ge c, commit, genp; sc s[128]; sha256 hm; size_t rsizes[32], offset = 0, rings, npub, i, j; int exp, mantissa, overflow; u64 scale;
+/* ---- HMAC-SHA256 and the RFC 6979 generator (hash_impl.h:211-314) ---- */
+typedef struct { sha256 inner, outer; } hmac256;
+static void hmac_init(hmac256 *h, const unsigned char *key, size_t keylen) {
+    unsigned char rkey[64]; int n;
+    memset(rkey, 0, 64);
+    if (keylen <= 64) memcpy(rkey, key, keylen); else { sha256 t; sha256_init(&t); sha256_write(&t, key, keylen); sha256_final(&t, rkey); }
+    sha256_init(&h->outer); for (n = 0; n < 64; n++) rkey[n] ^= 0x5c; sha256_write(&h->outer, rkey, 64);
+    sha256_init(&h->inner); for (n = 0; n < 64; n++) rkey[n] ^= 0x5c ^ 0x36; sha256_write(&h->inner, rkey, 64);
+}
+static void hmac_final(hmac256 *h, unsigned char *out32) { unsigned char t[32]; sha256_final(&h->inner, t); sha256_write(&h->outer, t, 32); sha256_final(&h->outer, out32); }
+typedef struct { unsigned char v[32], k[32]; int retry; } rfc6979;
+static void rfc6979_init(rfc6979 *r, const unsigned char *key, size_t keylen) {
+    hmac256 h; static const unsigned char zero = 0, one = 1;
+    memset(r->v, 1, 32); memset(r->k, 0, 32);
+    hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); sha256_write(&h.inner, &zero, 1); sha256_write(&h.inner, key, keylen); hmac_final(&h, r->k);
+    hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); hmac_final(&h, r->v);
+    hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); sha256_write(&h.inner, &one, 1); sha256_write(&h.inner, key, keylen); hmac_final(&h, r->k);
+    hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); hmac_final(&h, r->v);
+    r->retry = 0;
+}
+static void rfc6979_gen32(rfc6979 *r, unsigned char *out) {
+    hmac256 h; static const unsigned char zero = 0;
+    if (r->retry) {
+        hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); sha256_write(&h.inner, &zero, 1); hmac_final(&h, r->k);
+        hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); hmac_final(&h, r->v);
+    }
+    hmac_init(&h, r->k, 32); sha256_write(&h.inner, r->v, 32); hmac_final(&h, r->v);
+    memcpy(out, r->v, 32);
+    r->retry = 1;
+}
+/* rangeproof_impl.h:61-108 with message = the zeroed `prep` buffer (as rewind_inner calls it, :385) */
+static void rp_genrand(sc *sec, sc *s, unsigned char *prep, const size_t *rsizes, size_t rings, const unsigned char *nonce, const ge *commit,
+                       const unsigned char *proof, size_t len, const ge *genp) {
+    unsigned char tmp[32], seed[32 + 33 + 33 + 10]; rfc6979 rng; sc acc; int overflow; size_t i, j, npub = 0; int b;
+    memcpy(seed, nonce, 32); ser_point_rp(seed + 32, commit); ser_point_rp(seed + 65, genp); memcpy(seed + 98, proof, len);
+    rfc6979_init(&rng, seed, 98 + len);
+    sc_set_int(&acc, 0);
+    for (i = 0; i < rings; i++) {
+        if (i < rings - 1) {
+            rfc6979_gen32(&rng, tmp);
+            do { rfc6979_gen32(&rng, tmp); sc_set_b32(&sec[i], tmp, &overflow); } while (overflow || sc_is_zero(&sec[i]));
+            sc_add(&acc, &acc, &sec[i]);
+        } else { sc_neg(&acc, &acc); sec[i] = acc; }
+        for (j = 0; j < rsizes[i]; j++) {
+            rfc6979_gen32(&rng, tmp);
+            for (b = 0; b < 32; b++) { tmp[b] ^= prep[(i * 4 + j) * 32 + b]; prep[(i * 4 + j) * 32 + b] = tmp[b]; }
+            sc_set_b32(&s[npub], tmp, &overflow);
+            npub++;
+        }
+    }
+}
+static void rp_recover_x(sc *x, const sc *k, const sc *e, const sc *s) { sc t; sc_neg(x, s); sc_add(x, x, k); sc_inverse(&t, e); sc_mul(x, x, &t); }   /* :339-346 */
+/* rangeproof_impl.h:364-485 */
+static int rp_rewind_inner(sc *blind, u64 *v, unsigned char *m, size_t *mlen, const sc *ev, const sc *s, const size_t *rsizes, size_t rings,
+                           const unsigned char *nonce, const ge *commit, const unsigned char *proof, size_t len, const ge *genp) {
+    sc s_orig[128], sec[32], stmp; unsigned char prep[4096], tmp[32]; u64 value = 0; size_t offset, i, j, skip1, skip2, npub; int b;
+    memset(prep, 0, 4096); memset(s_orig, 0, sizeof(s_orig));
+    rp_genrand(sec, s_orig, prep, rsizes, rings, nonce, commit, proof, len, genp);
+    *v = UINT64_MAX; sc_set_int(blind, 0);
+    if (rings == 1 && rsizes[0] == 1) { rp_recover_x(blind, &s_orig[0], &ev[0], &s[0]); *v = 0; if (mlen) *mlen = 0; return 1; }
+    npub = (rings - 1) << 2;
+    for (j = 0; j < 2; j++) {
+        size_t idx = npub + rsizes[rings - 1] - 1 - j;
+        sc_get_b32(tmp, &s[idx]);
+        for (b = 0; b < 32; b++) tmp[b] ^= prep[idx * 32 + b];
+        if ((tmp[0] & 128) && memcmp(&tmp[16], &tmp[24], 8) == 0 && memcmp(&tmp[8], &tmp[16], 8) == 0) {
+            value = 0; for (i = 0; i < 8; i++) value = (value << 8) + tmp[24 + i];
+            *v = value; memcpy(&prep[idx * 32], tmp, 32);
+            break;
+        }
+    }
+    if (j > 1) { if (mlen) *mlen = 0; return 0; }
+    skip1 = rsizes[rings - 1] - 1 - j;
+    skip2 = (value >> ((rings - 1) << 1)) & 3;
+    if (skip1 == skip2) { if (mlen) *mlen = 0; return 0; }
+    if (skip2 >= rsizes[rings - 1]) { if (mlen) *mlen = 0; return 0; }       /* the reference indexes past the ring here (unspecified stack contents) */
+    skip1 += (rings - 1) << 2; skip2 += (rings - 1) << 2;
+    rp_recover_x(&stmp, &s_orig[skip2], &ev[skip2], &s[skip2]);
+    sc_neg(&sec[rings - 1], &sec[rings - 1]);
+    sc_add(blind, &stmp, &sec[rings - 1]);
+    if (!m || !mlen || *mlen == 0) { if (mlen) *mlen = 0; return 1; }
+    offset = 0; npub = 0;
+    for (i = 0; i < rings; i++) {
+        size_t idx = (value >> (i << 1)) & 3;
+        for (j = 0; j < rsizes[i]; j++) {
+            if (npub == skip1 || npub == skip2) { npub++; continue; }
+            if (idx == j) { sc t; sc_mul(&t, &sec[i], &ev[npub]); sc_add(&stmp, &s[npub], &t); }       /* recover_k :349-356 */
+            else stmp = s[npub];
+            sc_get_b32(tmp, &stmp);
+            for (b = 0; b < 32; b++) tmp[b] ^= prep[npub * 32 + b];
+            for (b = 0; b < 32 && offset < *mlen; b++) { m[offset] = tmp[b]; offset++; }
+            npub++;
+        }
+    }
+    *mlen = offset;
+    return 1;
+}
+/* rangeproof_impl.h:541-683 with main_impl.h:31-71 and generator/main_impl.h:40-49,266-273; nonce == NULL: verification only */
+static int rp_verify_impl(unsigned char *blindout, uint64_t *value_out, unsigned char *message_out, size_t *outlen, const unsigned char *nonce,
+                          uint64_t *min_value, uint64_t *max_value, const unsigned char *commit33, const unsigned char *proof, size_t plen,
+                          const unsigned char *extra, size_t extra_len, const unsigned char *gen64) {
+    gej accj, pubs[128], base; ge c, commit, genp; sc s[128], evalues[128]; sha256 hm; size_t rsizes[32], offset = 0, offset_post_header, rings, npub, i, j; int exp, mantissa, overflow, ret; u64 scale;
     unsigned char signs[31], m[33]; const unsigned char *e0;
     { fe x; fe_set_b32_mod(&x, commit33 + 1); ge_set_xquad(&commit, &x); if (commit33[0] & 1) ge_neg(&commit, &commit); }
     ge_from_b64(&genp, gen64, 0);
     if (!rp_getheader(&offset, &exp, &mantissa, &scale, min_value, max_value, proof, plen)) return 0;
+    offset_post_header = offset;
     rings = 1; rsizes[0] = 1; npub = 1;
     if (mantissa != 0) {
         rings = mantissa >> 1;
@@ -504,7 +604,28 @@ int zo_rangeproof_verify(uint64_t *min_value, uint64_t *max_value, const unsigne
     if (offset != plen) return 0;
     if (extra) sha256_write(&hm, extra, extra_len);
     sha256_final(&hm, m);
-    return borromean_verify(e0, s, pubs, rsizes, rings, m);
+    ret = borromean_verify(nonce ? evalues : NULL, e0, s, pubs, rsizes, rings, m);
+    if (ret && nonce) {                                                 /* :652-680 */
+        sc blind; u64 vv; gej t1, t2; sc svv;
+        if (!rp_rewind_inner(&blind, &vv, message_out, outlen, evalues, s, rsizes, rings, nonce, &commit, proof, offset_post_header, &genp)) return 0;
+        vv = (vv * scale) + *min_value;
+        { gej gj; gej_set_ge(&gj, &genp); memset(&svv, 0, sizeof(svv)); sc_set_int(&svv, vv); ecmult(&t1, &gj, &svv, &blind); }   /* blind*G + vv*gen (pedersen_ecmult) */
+        if (t1.inf) return 0;
+        gej_neg(&t2, &t1); gej_add_ge(&t1, &t2, &commit);
+        if (!t1.inf) return 0;
+        if (blindout) sc_get_b32(blindout, &blind);
+        if (value_out) *value_out = vv;
+    }
+    return ret;
+}
+int zo_rangeproof_verify(uint64_t *min_value, uint64_t *max_value, const unsigned char *commit33, const unsigned char *proof, size_t plen,
+                         const unsigned char *extra, size_t extra_len, const unsigned char *gen64) {
+    return rp_verify_impl(NULL, NULL, NULL, NULL, NULL, min_value, max_value, commit33, proof, plen, extra, extra_len, gen64);
+}
+int zo_rangeproof_rewind(unsigned char *blind_out, uint64_t *value_out, unsigned char *message_out, size_t *outlen, const unsigned char *nonce32,
+                         uint64_t *min_value, uint64_t *max_value, const unsigned char *commit33, const unsigned char *proof, size_t plen,
+                         const unsigned char *extra, size_t extra_len, const unsigned char *gen64) {
+    return rp_verify_impl(blind_out, value_out, message_out, outlen, nonce32, min_value, max_value, commit33, proof, plen, extra, extra_len, gen64);
 }
 
 /* ============================================================ schnorr =================================================== */
@@ -678,7 +799,7 @@ int zo_surjectionproof_verify(const unsigned char *proof, size_t plen, const uns
     for (i = 0; i <= n_tags; i++) { const unsigned char *t = i < n_tags ? in_tags64 + 64 * i : out_tag64; t33[0] = 2 + (t[63] & 1); memcpy(t33 + 1, t, 32); sha256_write(&h, t33, 33); }
     sha256_final(&h, m);
     rsizes[0] = n_used;
-    return borromean_verify(data, s, pubs, rsizes, 1, m);
+    return borromean_verify(NULL, data, s, pubs, rsizes, 1, m);
 }
 
 /* ======================================================= byte-level exports ============================================= */

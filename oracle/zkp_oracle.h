@@ -21,6 +21,10 @@ ZO_API void zo_rangeproof_verify_many(int *results, uint64_t *min_v, uint64_t *m
                                       const size_t *plens, const unsigned char *gens64, size_t n, int threads);
 ZO_API int zo_schnorrsig_verify(const unsigned char *sig64, const unsigned char *msg, size_t msglen, const unsigned char *pk32);
 /* secp256k1_schnorrsig_aggverify (modules/schnorrsig_halfagg/main_impl.h:108-198); keys as 32-byte x-only serialisations */
+/* secp256k1_rangeproof_rewind (modules/rangeproof/main_impl.h:31-52, rangeproof_impl.h:61-108,339-485,652-680) */
+ZO_API int zo_rangeproof_rewind(unsigned char *blind_out, uint64_t *value_out, unsigned char *message_out, size_t *outlen, const unsigned char *nonce32,
+                                uint64_t *min_value, uint64_t *max_value, const unsigned char *commit33, const unsigned char *proof, size_t plen,
+                                const unsigned char *extra, size_t extra_len, const unsigned char *gen64);
 /* secp256k1_pedersen_verify_tally (modules/generator/main_impl.h:371-396) on 33-byte serialised commitments; -1 = unparseable */
 ZO_API int zo_pedersen_verify_tally(const unsigned char *pos33, size_t pcnt, const unsigned char *neg33, size_t ncnt);
 ZO_API int zo_schnorrsig_aggverify(const unsigned char *pks32, const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "secp256k1_pedersen_verify_tally_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_rewind_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "secp256k1_surjectionproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
     "secp256k1_surjectionproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),

@@ -167,6 +167,24 @@ class Engine:
                                                                  _p(edata), _p(eoff), _p(gens64), n), "secp256k1_rangeproof_verify_batch")
         return res, mn, mx
 
+    def rangeproof_rewind_batch(self, commits33, proofs, gens64, nonces, msg_capacity=4096, extra=None):
+        """secp256k1_rangeproof_rewind per item.  Returns (results, blinds (n,32), values uint64[n], messages list[bytes], min, max)."""
+        data, off = proofs if isinstance(proofs, tuple) else self.pack(list(proofs))
+        n = off.size - 1
+        commits33 = _u8(commits33); gens64 = _u8(gens64); nonces = _u8(nonces)
+        edata = eoff = None
+        if extra is not None:
+            edata, eoff = extra if isinstance(extra, tuple) else self.pack(list(extra))
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        blind = np.zeros((n, 32), np.uint8); val = np.zeros(n, np.uint64)
+        msg = np.zeros((n, max(msg_capacity, 1)), np.uint8) if msg_capacity else None
+        ol = np.full(n, msg_capacity, np.uint64)
+        self._check(self._lib.secp256k1_rangeproof_rewind_batch(self._h, _p(res), _p(blind), _p(val), _p(msg), _p(ol) if msg_capacity else None, msg_capacity,
+                                                                 _p(nonces), _p(mn), _p(mx), _p(commits33), _p(data), _p(off), _p(edata), _p(eoff), _p(gens64), n),
+                    "secp256k1_rangeproof_rewind_batch")
+        msgs = [msg[i, :int(ol[i])].tobytes() if (msg_capacity and res[i]) else b"" for i in range(n)]
+        return res, blind, val, msgs, mn, mx
+
     def rangeproof_verify_batch_dev(self, results, min_value, max_value, commits33, proofs, proof_off, gens64, n, extra=None, extra_off=None,
                                     stream=None):
         self._check(self._lib.secp256k1_rangeproof_verify_batch_dev(self._h, stream, _dp(results), _dp(min_value), _dp(max_value), _dp(commits33),

@@ -7,6 +7,7 @@
 #include "gtable.h"
 #include "sha256.h"
 #include "rangeproof.h"
+#include "rangeproof_rewind.h"
 #include "schnorr.h"
 #include "msm.h"
 #include "bppp.h"
@@ -295,7 +296,7 @@ k_rp_sum(rp_ws ws, size_t n) {
 #define S2K_RINGS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     int live = p < n;
@@ -305,13 +306,64 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
     const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm);
+            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr);
 }
 __global__ void __launch_bounds__(64)
 k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     results[p] = rp_final(ws.rec[p], ws.ring_out + p * RP_MAX_RINGS * 36, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
+}
+
+// rewinding (rangeproof_rewind.h): one lane per proof that verified
+struct rp_rewind_args {
+    u32* ev; u32* prep; u32* secs;                  // scratch, one chunk: [m][128][8], [m][128][8], [m][32][8] words
+    unsigned char* blind_out; uint64_t* value_out; unsigned char* msg_out; uint64_t* outlen; size_t msg_stride; const unsigned char* nonces;
+};
+__global__ void __launch_bounds__(256, 2)
+k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_value, const unsigned char* proofs, const uint64_t* proof_off,
+            const unsigned char* gens64, const u32* gtab, u32* ptab, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int inrange = t < n;
+    const size_t p = inrange ? t : 0;
+    int ok = inrange && results[p];
+    scalar blind; u64 value = 0, mlen = 0; sc_set_zero(blind);
+    const unsigned char* proof = proofs + proof_off[p];
+    if (ok) {
+        mlen = (ra.msg_out && ra.outlen) ? ra.outlen[p] : 0;
+        if (mlen > ra.msg_stride) mlen = ra.msg_stride;
+        ok = rp_rewind(blind, value, ra.msg_out ? ra.msg_out + p * ra.msg_stride : nullptr, &mlen, ws.rec[p], proof, ra.nonces + 32 * p, gens64 + 64 * p,
+                       ra.ev + p * 1024, ra.prep + p * 1024, ra.secs + p * 256);
+    }
+    // the commitment must be blind*G + (value*scale + min_value)*gen  (rangeproof_impl.h:662-672)
+    u64 vv = 0;
+    if (ok) {
+        u32 off; int exp, mant; u64 scale, mn, mx;
+        rp_getheader(off, exp, mant, scale, &mn, &mx, proof, proof_off[p + 1] - proof_off[p]);
+        vv = value * scale + min_value[p];
+    }
+    gej A; scalar sv;
+    { ge g; fe_set_b32_mod(g.x, gens64 + 64 * p); fe_set_b32_mod(g.y, gens64 + 64 * p + 32); fe_norm_weak(g.x); fe_norm_weak(g.y); gej_set_ge(A, g); }
+    sc_set_u64(sv, vv);
+    if (!ok) { sc_set_zero(sv); sc_set_zero(blind); }
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    gej R; ecmult_lane(R, A, sv, blind, 1, gtab, lm);
+    ge a; ge_set_gej(a, R);
+    if (ok) {
+        fe cx, cy, d;
+        for (int i = 0; i < 9; i++) { cx.n[i] = ws.rec[p].commit[i]; cy.n[i] = ws.rec[p].commit[9 + i]; }
+        ok &= !R.inf;
+        fe_neg(d, a.x, 1); fe_add(d, cx); ok &= fe_normalizes_to_zero(d);
+        fe_neg(d, a.y, 1); fe_add(d, cy); ok &= fe_normalizes_to_zero(d);
+    }
+    if (inrange) {
+        results[p] = ok;
+        if (!ok) { sc_set_zero(blind); vv = 0; mlen = 0; }
+        sc_get_b32(ra.blind_out + 32 * p, blind);
+        ra.value_out[p] = vv;
+        if (ra.outlen) ra.outlen[p] = mlen;
+    }
 }
 
 static size_t rp_ws_bytes(size_t n) {
@@ -329,7 +381,7 @@ static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
 #define RP_CHUNK (e->max_lanes / RP_MAX_RINGS)     /* proofs per launch group */
 static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
-                     const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+                     const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr) {
     if (!engine_ptab(e, ((std::min(n, RP_CHUNK) * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
     // the scratch records `w` hold one chunk; chunks run back to back on the stream and reuse them
@@ -341,9 +393,17 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, m);
         hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);
         if (p0 == 0) HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m);
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr);
         if (p0 == 0) HIPCHK(hipEventRecord(e->ev[3], st));
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
+        if (rewind) {
+            rp_rewind_args ra = *rewind;                      // scratch is per chunk, the caller's arrays are per batch
+            ra.blind_out += 32 * p0; ra.value_out += p0; ra.nonces += 32 * p0;
+            if (ra.msg_out) ra.msg_out += ra.msg_stride * p0;
+            if (ra.outlen) ra.outlen += p0;
+            hipLaunchKernelGGL(k_rp_rewind, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, ra, results + p0, min_value + p0, proofs, proof_off + p0,
+                               gens64 + 64 * p0, e->gtab, e->ptab, m);
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
@@ -388,6 +448,51 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+// rewind: verification + recovery (rangeproof_rewind.h); host buffers
+extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, unsigned char* blind_out, uint64_t* value_out, unsigned char* message_out,
+                                                 uint64_t* outlen, size_t msg_stride, const unsigned char* nonces, uint64_t* min_value, uint64_t* max_value,
+                                                 const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                 const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_rewind_batch", "null engine");
+    if (n == 0) return 1;
+    if (!results || !blind_out || !value_out || !nonces || !min_value || !max_value || !commits33 || !proofs || !proof_off || !gens64 || (message_out && !outlen))
+        return s2k_fail("secp256k1_rangeproof_rewind_batch", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
+    const size_t nw = std::min(n, RP_CHUNK), mbytes = message_out ? msg_stride * n : 0;
+    const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n, 32 * n, 32 * n, 8 * n, 8 * n, mbytes + 64,
+                               nw * 4096, nw * 4096, nw * 1024});
+    if (!engine_workspace(e, rp_ws_bytes(nw) + io)) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
+    int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
+    unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
+    uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
+    unsigned char* d_gen = c.take<unsigned char>(64 * n);
+    rp_rewind_args ra;
+    ra.nonces = c.take<unsigned char>(32 * n); ra.blind_out = c.take<unsigned char>(32 * n); ra.value_out = c.take<uint64_t>(n);
+    ra.outlen = c.take<uint64_t>(n); ra.msg_out = message_out ? c.take<unsigned char>(mbytes + 64) : nullptr; ra.msg_stride = msg_stride;
+    ra.ev = c.take<u32>(nw * 1024); ra.prep = c.take<u32>(nw * 1024); ra.secs = c.take<u32>(nw * 256);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(d_com, commits33, 33 * n, hipMemcpyHostToDevice, st));
+    if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_off, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    if (ebytes) { HIPCHK(hipMemcpyAsync(d_ex, extra, ebytes, hipMemcpyHostToDevice, st)); }
+    if (extra && extra_off) HIPCHK(hipMemcpyAsync(d_eoff, extra_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_gen, gens64, 64 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)ra.nonces, nonces, 32 * n, hipMemcpyHostToDevice, st));
+    if (message_out) { HIPCHK(hipMemcpyAsync(ra.outlen, outlen, 8 * n, hipMemcpyHostToDevice, st)); HIPCHK(hipMemsetAsync(ra.msg_out, 0, mbytes, st)); }
+    else HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
+    if (!rp_launch(e, st, w, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, &ra)) return 0;
+    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(blind_out, ra.blind_out, 32 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(value_out, ra.value_out, 8 * n, hipMemcpyDeviceToHost, st));
+    if (message_out) { HIPCHK(hipMemcpyAsync(message_out, ra.msg_out, mbytes, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(outlen, ra.outlen, 8 * n, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }

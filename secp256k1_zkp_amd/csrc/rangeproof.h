@@ -272,8 +272,10 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
     for (int i = 0; i < 8; i++) out[i] = st[i];
 }
 
+// ev_out (optional): the challenge e of each ring position, 4 x 8 big-endian words per ring -- the reference's `evalues`
+// (borromean_impl.h:80-83), which only rewinding needs (rangeproof_rewind.h)
 S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
-                    const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm) {
+                    const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm, u32* ev_out = nullptr) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
     u32 e[8];
@@ -296,6 +298,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
     for (u32 j = 0; j < 4; j++) {
         const int step_live = ok & (j < rsize);
         scalar ens, s; int ov_e, ov_s = 0;
+        if (ev_out && live) { for (int i = 0; i < 8; i++) ev_out[8 * j + i] = e[i]; }
         rp_words_to_scalar(ens, ov_e, e);
         sc_set_zero(s);
         if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);

@@ -49,6 +49,22 @@ def rangeproof():
         ("repro_2_large_min", repro["vector_2"], repro["commit_2"], 1, I64 - 1, I64),
     ]
     data = [dict(name=n, proof=p.hex(), commit33=cm.hex(), result=r, min_value=str(mn), max_value=str(mx)) for n, p, cm, r, mn, mx in vecs]
+    # what the same tests assert about secp256k1_rangeproof_rewind: (nonce, blind, value, recovered length, message) --
+    # tests_impl.h:666-687, 737-757, 795-810 (nonce = the commitment bytes) and :843-880, 1241-1246, 1295-1300, 1341-1346
+    # (vector_nonce / vector_blind, message = 0xFF bytes)
+    glob = {n: v for n, v, _ in c_arrays(text[b:c])}
+    MAXMSG = int(re.search(r"define SECP256K1_RANGEPROOF_MAX_MESSAGE_LEN\s+(\d+)", open(os.path.join(REF, "include/secp256k1_rangeproof.h")).read()).group(1))
+    msg2 = re.search(r'message_2\[\] = "([^"]*)";', text).group(1).encode() + b"\0"      # a C string literal: sizeof() includes the NUL
+    rew = [
+        (fixed["commit_1"][:32], fixed["blind_1"], 86, b"\0" * 448),
+        (fixed["commit_2"][:32], fixed["blind_2"], 11, msg2 + b"\0" * (192 - len(msg2))),
+        (fixed["nonce_3"], fixed["blind_3"], U64, b""),
+        (glob["vector_nonce"], glob["vector_blind"], U64, b"\xff" * MAXMSG),
+        (glob["vector_nonce"], glob["vector_blind"], 13, b"\xff" * 128),
+        (glob["vector_nonce"], glob["vector_blind"], I64, b""),
+    ]
+    for d, (nonce, blind, value, msg) in zip(data, rew):
+        d["rewind"] = dict(nonce=nonce.hex(), blind=blind.hex(), value=str(value), capacity=MAXMSG, message=msg.hex())      # capacity: the tests' buffer size
     json.dump(dict(source="src/modules/rangeproof/tests_impl.h:589-812,883-1349", generator="secp256k1_generator_h", vectors=data),
               open(os.path.join(OUT, "rangeproof_vectors.json"), "w"), indent=0)
     print("rangeproof:", [(d["name"], len(d["proof"]) // 2) for d in data])

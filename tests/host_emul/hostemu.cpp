@@ -7,6 +7,7 @@
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
+#include "../../secp256k1_zkp_amd/csrc/rangeproof_rewind.h"
 #include "../../secp256k1_zkp_amd/csrc/schnorr.h"
 #include "../../secp256k1_zkp_amd/csrc/msm.h"
 #include "../../secp256k1_zkp_amd/csrc/bppp.h"
@@ -141,6 +142,38 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
     rp_sum(rec, pub0.data(), lift_ok);
     for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm);
     return rp_final(rec, ring_out, ring_ok, proof);
+}
+
+// verification with the challenges kept, then rangeproof_rewind.h and the commitment check of k_rp_rewind (engine.hip)
+int emu_rangeproof_rewind(unsigned char* blind_out, unsigned long long* value_out, unsigned char* msg_out, unsigned long long* outlen, const unsigned char* nonce32,
+                          unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
+                          const unsigned char* gen64) {
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), ev(128 * 8, 0), prep(128 * 8, 0), secs(32 * 8, 0);
+    unsigned char lift_ok[32] = {0}, ring_out[32 * 36] = {0}, ring_ok[32] = {0};
+    u64 mn, mx;
+    rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, nullptr, 0, gen64);
+    *min_value = mn; *max_value = mx;
+    if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
+    rp_sum(rec, pub0.data(), lift_ok);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, ev.data() + 32 * i);
+    if (!rp_final(rec, ring_out, ring_ok, proof)) return 0;
+    scalar blind; u64 value = 0, mlen = (msg_out && outlen) ? *outlen : 0;
+    if (!rp_rewind(blind, value, msg_out, &mlen, rec, proof, nonce32, gen64, ev.data(), prep.data(), secs.data())) { if (outlen) *outlen = 0; return 0; }
+    u32 off; int exp, mant; u64 scale, a, b;
+    rp_getheader(off, exp, mant, scale, &a, &b, proof, plen);
+    const u64 vv = value * scale + mn;
+    gej A, R; ge g; scalar sv;
+    fe_set_b32_mod(g.x, gen64); fe_set_b32_mod(g.y, gen64 + 32); fe_norm_weak(g.x); fe_norm_weak(g.y); gej_set_ge(A, g);
+    sc_set_u64(sv, vv);
+    ecmult_lane(R, A, sv, blind, 1, gtab_host(), g_lm);
+    if (R.inf) return 0;
+    ge af; ge_set_gej(af, R);
+    fe cx, cy, d;
+    for (int i = 0; i < 9; i++) { cx.n[i] = rec.commit[i]; cy.n[i] = rec.commit[9 + i]; }
+    fe_neg(d, af.x, 1); fe_add(d, cx); if (!fe_normalizes_to_zero(d)) return 0;
+    fe_neg(d, af.y, 1); fe_add(d, cy); if (!fe_normalizes_to_zero(d)) return 0;
+    sc_get_b32(blind_out, blind); *value_out = vv; if (outlen) *outlen = mlen;
+    return 1;
 }
 
 int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, size_t msglen, const unsigned char* pk, int pk_format) {

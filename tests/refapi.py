@@ -77,6 +77,42 @@ class Ref:
         plist = [proofs[i, :int(plens[i])].tobytes() for i in range(n)]
         return commits, plist, gens64, values
 
+    def make_rangeproofs_msg(self, n, rng, msg_len=0, min_bits=64, exp=0, min_value=0, values=None, threads=8):
+        """proofs with random nonces and embedded random messages; returns (commits, proofs, gens, values, blinds, nonces, msgs)"""
+        blinds = rng.integers(0, 256, (n, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F
+        if values is None:
+            hi = 2**63 if min_bits >= 63 else 2**max(min_bits, 1)
+            values = rng.integers(0, hi, n, dtype=np.uint64) + np.uint64(min_value)
+        values = np.ascontiguousarray(values, np.uint64)
+        gens64 = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64).copy()
+        nonces = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        msgs = rng.integers(0, 256, (n, max(msg_len, 1)), dtype=np.uint8)
+        stride = 5134
+        commits = np.zeros((n, 33), np.uint8); proofs = np.zeros((n, stride), np.uint8); plens = np.zeros(n, np.uint64)
+        ok = self.lib.ref_rangeproof_make_many_msg(_p(commits), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(blinds), _p(values), _p(gens64), _p(nonces),
+                                                   _p(msgs), ctypes.c_size_t(msg_len), ctypes.c_uint64(min_value), ctypes.c_int(exp), ctypes.c_int(min_bits),
+                                                   ctypes.c_size_t(n), ctypes.c_int(threads))
+        assert ok == 1
+        plist = [proofs[i, :int(plens[i])].tobytes() for i in range(n)]
+        return commits, plist, gens64, values, blinds, nonces, msgs[:, :msg_len]
+
+    def rangeproof_rewind_many(self, commits33, plist, gens64, nonces, msg_capacity=4096, threads=1):
+        """secp256k1_rangeproof_rewind per item -> (results, blinds (n,32), values, messages list, min, max)"""
+        n = len(plist)
+        stride = max(max((len(p) for p in plist), default=1), 1)
+        proofs = np.zeros((n, stride), np.uint8)
+        for i, p in enumerate(plist):
+            proofs[i, :len(p)] = np.frombuffer(p, np.uint8)
+        plens = np.array([len(p) for p in plist], np.uint64)
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        blind = np.zeros((n, 32), np.uint8); val = np.zeros(n, np.uint64)
+        ms = max(msg_capacity, 1); msg = np.zeros((n, ms), np.uint8); ol = np.full(n, msg_capacity, np.uint64)
+        commits33 = np.ascontiguousarray(commits33, np.uint8); gens64 = np.ascontiguousarray(gens64, np.uint8); nonces = np.ascontiguousarray(nonces, np.uint8)
+        self.lib.ref_rangeproof_rewind_many(_p(res), _p(blind), _p(val), _p(msg) if msg_capacity else None, _p(ol), ctypes.c_size_t(ms), _p(nonces), _p(mn), _p(mx),
+                                            _p(commits33), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(gens64), ctypes.c_size_t(n), ctypes.c_int(threads))
+        msgs = [msg[i, :int(ol[i])].tobytes() if (res[i] and msg_capacity) else b"" for i in range(n)]
+        return res, blind, val, msgs, mn, mx
+
     def rangeproof_verify_many(self, commits33, plist, gens64, threads=1):
         n = len(plist)
         stride = max(max((len(p) for p in plist), default=1), 1)

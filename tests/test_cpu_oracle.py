@@ -171,6 +171,35 @@ def test_emu_msm(emu, ref):
         assert i1 == i2 and r1.tobytes() == out.raw, (n, g, c)
 
 
+def _emu_rewind(emu, commit33, proof, gen64, nonce, capacity):
+    bl = ctypes.create_string_buffer(32); val = ctypes.c_ulonglong(0); msg = ctypes.create_string_buffer(4096); ol = ctypes.c_ulonglong(capacity)
+    mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0)
+    r = emu.emu_rangeproof_rewind(bl, ctypes.byref(val), msg if capacity else None, ctypes.byref(ol) if capacity else None, nonce, ctypes.byref(mn), ctypes.byref(mx),
+                                  commit33, proof, ctypes.c_size_t(len(proof)), gen64)
+    return r, bl.raw, val.value, msg.raw[:ol.value] if (r and capacity) else b""
+
+
+def test_emu_rangeproof_rewind(emu, ref):
+    """device code of rangeproof_rewind.h (HMAC-DRBG replay, value / blind / message recovery, commitment check) on the host: the
+    reference tests' own rewind expectations, then reference-signed proofs of several shapes with right and wrong nonces"""
+    from tests.refapi import GENERATOR_H
+    for v in _golden("rangeproof_vectors.json")["vectors"]:
+        rw = v["rewind"]
+        r, bl, val, msg = _emu_rewind(emu, bytes.fromhex(v["commit33"]), bytes.fromhex(v["proof"]), GENERATOR_H, bytes.fromhex(rw["nonce"]), rw["capacity"])
+        assert r == 1 and bl.hex() == rw["blind"] and val == int(rw["value"]) and msg.hex() == rw["message"], v["name"]
+    rng = np.random.default_rng(809)
+    for kw in (dict(msg_len=64, min_bits=12), dict(msg_len=0, min_bits=0, exp=-1, values=np.array([3, 4], np.uint64)), dict(msg_len=10, min_bits=3, exp=1, min_value=5)):
+        c, p, g, v, b, nn, m = ref.make_rangeproofs_msg(2, rng, **kw)
+        nn[1, 31] ^= 0x80
+        res, bl, val, msgs, mn, mx = ref.rangeproof_rewind_many(c, p, g, nn, msg_capacity=300)
+        for i in range(2):
+            got = _emu_rewind(emu, c[i].tobytes(), p[i], g[i].tobytes(), nn[i].tobytes(), 300)
+            assert got[0] == res[i]
+            if res[i]:
+                assert got[1] == bl[i].tobytes() and got[2] == int(val[i]) and got[3] == msgs[i]
+        assert res[0] == 1 and res[1] == 0
+
+
 def test_emu_halfagg(emu, ref):
     """device code of halfagg.h (points, schedules, chain, scalars) + the bucket MSM, on the host, against the golden verdicts
     and against the reference on a 120-signature aggregate (bucket path) with mutations"""

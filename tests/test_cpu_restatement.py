@@ -194,3 +194,38 @@ def test_golden_pedersen_tally(zo, ref):
         got = zo.zo_pedersen_verify_tally(pos.tobytes(), ctypes.c_size_t(pos.shape[0]), neg.tobytes(), ctypes.c_size_t(neg.shape[0]))
         assert got == result, name
         assert int(ref.pedersen_verify_tally_many([(pos, neg)])[0]) == result, name
+
+
+def _zo_rewind(zo, commit33, proof, gen64, nonce, capacity):
+    bl = ctypes.create_string_buffer(32); val = ctypes.c_uint64(0); msg = ctypes.create_string_buffer(4096); ol = ctypes.c_size_t(capacity)
+    mn = ctypes.c_uint64(0); mx = ctypes.c_uint64(0)
+    r = zo.zo_rangeproof_rewind(bl, ctypes.byref(val), msg if capacity else None, ctypes.byref(ol) if capacity else None, nonce, ctypes.byref(mn), ctypes.byref(mx),
+                                commit33, proof, ctypes.c_size_t(len(proof)), None, ctypes.c_size_t(0), gen64)
+    return r, bl.raw, val.value, msg.raw[:ol.value] if (r and capacity) else b"", mn.value, mx.value
+
+
+def test_golden_rangeproof_rewind(zo):
+    """what src/modules/rangeproof/tests_impl.h:666-687,737-757,795-810,843-880,1241-1346 assert about secp256k1_rangeproof_rewind"""
+    for v in _golden("rangeproof_vectors.json")["vectors"]:
+        rw = v["rewind"]
+        r, bl, val, msg, mn, mx = _zo_rewind(zo, bytes.fromhex(v["commit33"]), bytes.fromhex(v["proof"]), GENERATOR_H, bytes.fromhex(rw["nonce"]), rw["capacity"])
+        assert r == 1 and bl.hex() == rw["blind"] and val == int(rw["value"]) and msg.hex() == rw["message"], v["name"]
+        assert mn == int(v["min_value"]) and mx == int(v["max_value"])
+        bad = bytearray(bytes.fromhex(rw["nonce"])); bad[0] ^= 1
+        assert _zo_rewind(zo, bytes.fromhex(v["commit33"]), bytes.fromhex(v["proof"]), GENERATOR_H, bytes(bad), rw["capacity"])[0] == 0, v["name"]
+
+
+def test_rangeproof_rewind_vs_reference(zo, ref):
+    rng = np.random.default_rng(808)
+    for kw in (dict(msg_len=70, min_bits=16), dict(msg_len=0, min_bits=0, exp=-1, values=np.array([9, 10], np.uint64)), dict(msg_len=33, min_bits=5, exp=2, min_value=17),
+               dict(msg_len=200, min_bits=7)):
+        c, p, g, v, b, nn, m = ref.make_rangeproofs_msg(2, rng, **kw)
+        nn2 = nn.copy(); nn2[1, 5] ^= 1                                   # wrong nonce on the second one
+        for cap in (4096, 50, 0):
+            res, bl, val, msgs, mn, mx = ref.rangeproof_rewind_many(c, p, g, nn2, msg_capacity=cap)
+            for i in range(2):
+                got = _zo_rewind(zo, c[i].tobytes(), p[i], g[i].tobytes(), nn2[i].tobytes(), cap)
+                assert got[0] == res[i]
+                if res[i]:
+                    assert got[1] == bl[i].tobytes() and got[2] == int(val[i]) and got[3] == msgs[i]
+            assert res[0] == 1 and res[1] == 0

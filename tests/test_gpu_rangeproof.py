@@ -102,3 +102,38 @@ def test_single_item_wrapper(engine, ref):
     bad = bytearray(proofs[0]); bad[100] ^= 1
     ok = lib.secp256k1_rangeproof_verify_amd(None, ctypes.byref(mn), ctypes.byref(mx), opaque, bytes(bad), len(bad), None, 0, gens[0].tobytes())
     assert ok == 0
+
+
+def test_rewind_fixed_vectors(engine):
+    """the rewind expectations of src/modules/rangeproof/tests_impl.h (blind, value, recovered message) on the GPU"""
+    vecs = _golden()
+    n = len(vecs)
+    commits = np.stack([np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8) for v in vecs])
+    proofs = [bytes.fromhex(v["proof"]) for v in vecs]
+    gens = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64)
+    nonces = np.stack([np.frombuffer(bytes.fromhex(v["rewind"]["nonce"]), np.uint8) for v in vecs])
+    res, bl, val, msgs, mn, mx = engine.rangeproof_rewind_batch(commits, proofs, gens, nonces, msg_capacity=3968)
+    for i, v in enumerate(vecs):
+        rw = v["rewind"]
+        assert res[i] == 1 and bl[i].tobytes().hex() == rw["blind"] and int(val[i]) == int(rw["value"]) and msgs[i].hex() == rw["message"], v["name"]
+        assert int(mn[i]) == int(v["min_value"]) and int(mx[i]) == int(v["max_value"])
+
+
+def test_rewind_batch_vs_reference(engine, ref):
+    rng = np.random.default_rng(4242)
+    C, P, G, N = [], [], [], []
+    for kw in (dict(msg_len=100, min_bits=64), dict(msg_len=3968, min_bits=64), dict(msg_len=0, min_bits=0, exp=-1, values=np.arange(20, 26, dtype=np.uint64)),
+               dict(msg_len=40, min_bits=5, exp=2, min_value=17), dict(msg_len=64, min_bits=13), dict(msg_len=0, min_bits=1), dict(msg_len=1, min_bits=3), dict(msg_len=7, min_bits=32, exp=3)):
+        c, p, g, v, b, nn, m = ref.make_rangeproofs_msg(6, rng, **kw)
+        nn[4, 3] ^= 0x10                                               # wrong nonce
+        q = bytearray(p[5]); q[len(q) // 2] ^= 1; p[5] = bytes(q)       # proof that does not verify
+        C.append(c); P += p; G.append(g); N.append(nn)
+    C = np.concatenate(C); G = np.concatenate(G); N = np.concatenate(N)
+    for cap in (4096, 100, 0):
+        e_res, e_bl, e_val, e_msgs, e_mn, e_mx = ref.rangeproof_rewind_many(C, P, G, N, msg_capacity=cap, threads=8)
+        res, bl, val, msgs, mn, mx = engine.rangeproof_rewind_batch(C, P, G, N, msg_capacity=cap)
+        assert np.array_equal(res, e_res)
+        ok = e_res == 1
+        assert np.array_equal(bl[ok], e_bl[ok]) and np.array_equal(val[ok], e_val[ok]) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
+        assert [m for m, o in zip(msgs, ok) if o] == [m for m, o in zip(e_msgs, ok) if o]
+        assert 0 < ok.sum() < len(P) and not bl[~ok].any() and not val[~ok].any()

@@ -81,3 +81,20 @@ def test_surjection_and_bppp_split(small_engine, ref):
     exp = ref.bppp_verify_many(pr, trs, rhos, gens, gl, cvs, commits)
     assert np.array_equal(small_engine.bppp_norm_product_verify_batch(pr, trs, rhos, gens, gl, cvs, commits), exp)
     assert 0 < exp.sum() < 13
+
+
+def test_rewind_split(small_engine, ref):
+    """rewinding 45 proofs with 16 proofs per launch: the scratch (challenges, pads, ring nonces) is per launch, the outputs per batch"""
+    rng = np.random.default_rng(14)
+    C, P, G, N = [], [], [], []
+    for kw in (dict(msg_len=50, min_bits=32), dict(msg_len=0, min_bits=0, exp=-1, values=np.arange(15, dtype=np.uint64)), dict(msg_len=9, min_bits=6, exp=1, min_value=3)):
+        c, p, g, v, b, nn, m = ref.make_rangeproofs_msg(15, rng, **kw)
+        C.append(c); P += p; G.append(g); N.append(nn)
+    C = np.concatenate(C); G = np.concatenate(G); N = np.concatenate(N)
+    order = rng.permutation(len(P)); C, G, N, P = C[order], G[order], N[order], [P[i] for i in order]
+    N[[3, 16, 31]] ^= 1
+    e = ref.rangeproof_rewind_many(C, P, G, N, msg_capacity=200, threads=8)
+    r = small_engine.rangeproof_rewind_batch(C, P, G, N, msg_capacity=200)
+    ok = e[0] == 1
+    assert np.array_equal(r[0], e[0]) and ok.sum() == len(P) - 3
+    assert np.array_equal(r[1][ok], e[1][ok]) and np.array_equal(r[2][ok], e[2][ok]) and [m for m, o in zip(r[3], ok) if o] == [m for m, o in zip(e[3], ok) if o]
