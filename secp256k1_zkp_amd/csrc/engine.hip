@@ -158,30 +158,33 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
     e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0;
+    e->stream = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
+#define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
     if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
-    HIPCHK_NULL(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIPCHK_NULL(hipEventCreate(&e->ev[i]));
-    HIPCHK_NULL(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
-    HIPCHK_NULL(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
-    HIPCHK_NULL(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
+    S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) S2K_CREATE_CHK(hipEventCreate(&e->ev[i]));
+    S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
+    S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
+    S2K_CREATE_CHK(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
     hipLaunchKernelGGL(k_gtab_entries, dim3(S2K_GTAB_WINDOWS * 65536 / 256), dim3(256), 0, e->stream, e->gtab);
-    HIPCHK_NULL(hipGetLastError());
-    HIPCHK_NULL(hipStreamSynchronize(e->stream));
+    S2K_CREATE_CHK(hipGetLastError());
+    S2K_CREATE_CHK(hipStreamSynchronize(e->stream));
+#undef S2K_CREATE_CHK
     return e;
 }
 extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    if (e->stream) hipStreamSynchronize(e->stream);
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
     if (e->gtab) hipFree(e->gtab);
     if (e->host_flags) hipHostFree(e->host_flags);
-    for (int i = 0; i < 4; i++) hipEventDestroy(e->ev[i]);
-    hipStreamDestroy(e->stream);
+    for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
 extern "C" int s2k_engine_sync(s2k_engine* e) {
@@ -945,26 +948,33 @@ extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy,
 extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
                                 const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
     if (!e) return s2k_fail("s2k_ecmult_multi", "null engine");
-    unsigned char *d_g = nullptr, *d_sc = nullptr, *d_pt = nullptr, *d_inf = nullptr, *d_r = nullptr; int32_t* d_ri = nullptr;
+    if (!r_xy || !r_inf || (n && (!sc || !pt_xy))) return s2k_fail("s2k_ecmult_multi", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
-    // inputs live outside the engine workspace (which the MSM passes re-carve)
-    HIPCHK(hipMalloc((void**)&d_sc, 32 * n + 64)); HIPCHK(hipMalloc((void**)&d_pt, 64 * n + 64)); HIPCHK(hipMalloc((void**)&d_inf, n + 64));
-    HIPCHK(hipMalloc((void**)&d_g, 64)); HIPCHK(hipMalloc((void**)&d_r, 64)); HIPCHK(hipMalloc((void**)&d_ri, 16));
-    int ok = 0;
-    do {
-        if (n && hipMemcpy(d_sc, sc, 32 * n, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (n && hipMemcpy(d_pt, pt_xy, 64 * n, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (n && pt_inf && hipMemcpy(d_inf, pt_inf, n, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (g_sc && hipMemcpy(d_g, g_sc, 32, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (!s2k_ecmult_multi_dev(e, nullptr, d_r, d_ri, g_sc ? d_g : nullptr, d_sc, d_pt, pt_inf ? d_inf : nullptr, n)) break;
-        if (hipStreamSynchronize(e->stream) != hipSuccess) break;
-        if (hipMemcpy(r_xy, d_r, 64, hipMemcpyDeviceToHost) != hipSuccess) break;
-        if (hipMemcpy(r_inf, d_ri, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
-        ok = 1;
-    } while (0);
-    hipFree(d_sc); hipFree(d_pt); hipFree(d_inf); hipFree(d_g); hipFree(d_r); hipFree(d_ri);
-    if (!ok && g_last_error.empty()) s2k_fail("s2k_ecmult_multi", "HIP copy failed");
-    return ok;
+    const size_t nt = n + (g_sc ? 1 : 0);
+    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    // the staged inputs come first in the workspace, the MSM passes carve what follows
+    if (!engine_workspace(e, ws_need({32 * n + 64, 64 * n + 64, n + 64, 64, 64, 16}) + msm_ws_bytes(nt + 1, pl))) return 0;
+    ws_carver c{e->ws, 0};
+    unsigned char* d_sc = c.take<unsigned char>(32 * n + 64); unsigned char* d_pt = c.take<unsigned char>(64 * n + 64); unsigned char* d_inf = c.take<unsigned char>(n + 64);
+    unsigned char* d_g = c.take<unsigned char>(64); unsigned char* d_r = c.take<unsigned char>(64); int32_t* d_ri = c.take<int32_t>(4);
+    hipStream_t st = e->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(d_sc, sc, 32 * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_pt, pt_xy, 64 * n, hipMemcpyHostToDevice, st));
+        if (pt_inf) HIPCHK(hipMemcpyAsync(d_inf, pt_inf, n, hipMemcpyHostToDevice, st));
+    }
+    if (g_sc) HIPCHK(hipMemcpyAsync(d_g, g_sc, 32, hipMemcpyHostToDevice, st));
+    u32* res = nullptr;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    if (!msm_launch(e, st, c, &res, g_sc ? d_g : nullptr, d_sc, d_pt, pt_inf ? d_inf : nullptr, n)) return 0;
+    hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, d_r, d_ri, res);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    HIPCHK(hipMemcpyAsync(r_xy, d_r, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r_inf, d_ri, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1292,6 +1302,11 @@ extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* res
     return 1;
 }
 
-// ---- not yet implemented (filled in below as the round progresses) -----------------------------------------------
-#define S2K_TODO(name) return s2k_fail(name, "not implemented yet")
-extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) { if (!e) return 0; std::lock_guard<std::recursive_mutex> lock(e->mu); HIPCHK(hipSetDevice(e->device)); return engine_workspace(e, n_items * 16384); }
+// pre-size the workspace for batches of n_items rangeproofs (optional: every call grows it on demand)
+extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) {
+    if (!e) return s2k_fail("s2k_engine_reserve", "null engine");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t nw = std::min(n_items, RP_CHUNK);
+    return engine_workspace(e, rp_ws_bytes(nw) + n_items * 5400) && engine_ptab(e, nw * RP_MAX_RINGS);
+}
