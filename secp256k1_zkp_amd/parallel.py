@@ -56,12 +56,28 @@ def gather_results(local, n_total, group=None):
 
 
 class EngineBackend:
-    """adapter: Engine (HIP) -> the backend interface of msm_sharded; tensors live in HBM of the engine's GPU."""
+    """adapter: Engine (HIP) -> the backend interface of msm_sharded; tensors live in HBM of the engine's GPU.
+
+    Stream discipline: the engine's own stream is created non-blocking, i.e. it does NOT order itself against torch's default
+    stream, and the collectives (RCCL) order themselves against torch's *current* stream only.  So the engine work is put on a
+    dedicated torch stream that first waits for the current stream (inputs ready) and that the current stream then waits for
+    (the partial is ready before the all-gather reads it).  Passing stream 0 to a *_dev entry point means "the engine's stream",
+    never torch's default stream."""
 
     def __init__(self, engine):
         import torch
         self.engine = engine
         self.dev = torch.device("cuda", engine.device)
+        self.stream = torch.cuda.Stream(device=self.dev)
+
+    def _enter(self):
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        return self.stream.cuda_stream
+
+    def _leave(self):
+        import torch
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
 
     def msm_partial(self, sc, pt_xy, g_sc, pt_inf):
         import torch
@@ -69,12 +85,18 @@ class EngineBackend:
         if sc.numel() == 0 and g_sc is None:
             out[27] = 1
             return out
-        self.engine.ecmult_multi_partial_dev(out, sc.contiguous(), pt_xy.contiguous(), g_sc, pt_inf, stream=torch.cuda.current_stream().cuda_stream)
+        sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
+        h = self._enter()
+        self.engine.ecmult_multi_partial_dev(out, sc, pt_xy, g_sc, pt_inf, stream=h)
+        self._leave()
         return out
 
     def gej_sum(self, parts):
         import torch
         r = torch.zeros(64, dtype=torch.uint8, device=self.dev); inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.engine.gej_sum_dev(r, inf, parts.contiguous(), parts.shape[0], stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+        parts = parts.contiguous()
+        h = self._enter()
+        self.engine.gej_sum_dev(r, inf, parts, parts.shape[0], stream=h)
+        self._leave()
+        torch.cuda.current_stream(self.dev).synchronize()
         return r.cpu().numpy(), int(inf.item())
