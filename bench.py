@@ -149,7 +149,8 @@ def main():
     d_commits = torch.tensor(commits).to(dev); d_gens = torch.tensor(np.ascontiguousarray(gens)).to(dev)
     d_proofs = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
     d_res = torch.zeros(n, dtype=torch.int32, device=dev); d_min = torch.zeros(n, dtype=torch.int64, device=dev); d_max = torch.zeros(n, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None                         # the engine's own stream (HIP events for the roofline are recorded on it)
+    torch.cuda.synchronize()              # ...which is not ordered against torch's streams: inputs must be resident first
 
     def step():
         eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_commits, d_proofs, d_off, d_gens, n, stream=stream)
@@ -189,7 +190,9 @@ def main():
         ks = torch.tensor(rng.integers(0, 256, (nm, 32), dtype=np.uint8)).to(dev)
         gpts = torch.tensor(np.frombuffer(G_XY, np.uint8).copy()).to(dev).repeat(nm, 1)
         pts = torch.zeros(nm, 64, dtype=torch.uint8, device=dev); pinf = torch.zeros(nm, dtype=torch.int32, device=dev)
-        eng.ecmult_batch_dev(pts, pinf, gpts, torch.zeros(nm, 32, dtype=torch.uint8, device=dev), ks, stream=stream)   # P_i = k_i*G
+        zero_na = torch.zeros(nm, 32, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()          # the engine's stream is not ordered against torch's: inputs must be complete first
+        eng.ecmult_batch_dev(pts, pinf, gpts, zero_na, ks, stream=stream)   # P_i = k_i*G
         scs = torch.tensor(rng.integers(0, 256, (nm, 32), dtype=np.uint8)).to(dev)
         torch.cuda.synchronize()
         be = parallel.EngineBackend(eng)

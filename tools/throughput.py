@@ -17,6 +17,7 @@ from tests.refapi import Ref, G_XY  # noqa: E402
 
 
 def timed(fn, reps=3):
+    torch.cuda.synchronize()              # the engine's stream is not ordered against torch's: inputs must be complete
     fn(); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
