@@ -273,3 +273,13 @@ def test_abi_symbols_and_loud_failure():
         with pytest.raises(S2KError):
             Engine(0)
         assert "HIP" in _native.last_error() or "device" in _native.last_error()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/secp256k1_zkp_amd.h must compile as C (c89 with the usual extensions off) and examples/ must compile against it"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "secp256k1_zkp_amd.h"\nint main(void) { return sizeof(s2k_engine*) == 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "examples", "rangeproof_verify.c"),
+                    "-o", str(tmp_path / "e.o")], check=True)
