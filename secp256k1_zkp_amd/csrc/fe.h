@@ -228,29 +228,30 @@ S2K_HD void fe_mul(fe& r, const fe& a_in, const fe& b_in) {
     u64 c = 0, d = 0; u32 u = 0, uprev = 0;
 #pragma unroll
     for (int k = 0; k < FE_LIMBS; k++) {
-        if (k < 8) {
+        // column 9+k (high chain d, 8-k products) and column k (low chain c, k+1 products), issued alternately: the two
+        // accumulators are independent, so each v_mad_u64_u32 has the other chain's between itself and its successor
 #pragma unroll
-            for (int i = 0; i < FE_LIMBS; i++) {
-                const int j = 9 + k - i;
-                if (j < 0 || j >= FE_LIMBS) continue;
+        for (int t = 0; t < FE_LIMBS; t++) {
+            if (k < 8 && k + 1 + t < FE_LIMBS) {
+                const int i = k + 1 + t, j = 9 + k - i;
                 S2K_CHECK(d + (u64)a[i] * b[j] >= d);
-                d += (u64)a[i] * b[j];
+                d += (u64)a[i] * b[j]; S2K_CHAIN(d);
             }
+            if (t <= k) {
+                const int i = t, j = k - t;
+                S2K_CHECK(c + (u64)a[i] * b[j] >= c);
+                c += (u64)a[i] * b[j]; S2K_CHAIN(c);
+            }
+        }
+        if (k < 8) {
             u = (u32)d & FE_M; d >>= FE_BITS;
         } else {
             S2K_CHECK((d >> 32) == 0);
             u = (u32)d;                           // what is left of the high chain (< 7*2^29)
         }
-#pragma unroll
-        for (int i = 0; i < FE_LIMBS; i++) {
-            const int j = k - i;
-            if (j < 0 || j >= FE_LIMBS) continue;
-            S2K_CHECK(c + (u64)a[i] * b[j] >= c);
-            c += (u64)a[i] * b[j];
-        }
         S2K_CHECK(c + (u64)u * 31264u >= c);
-        c += (u64)u * 31264u;
-        if (k > 0) c += (u64)uprev * k256;
+        c += (u64)u * 31264u; S2K_CHAIN(c);
+        if (k > 0) { c += (u64)uprev * k256; S2K_CHAIN(c); }
         uprev = u;
         r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
     }
@@ -269,30 +270,34 @@ S2K_HD void fe_sqr(fe& r, const fe& a_in) {
     u64 c = 0, d = 0; u32 u = 0, uprev = 0;
 #pragma unroll
     for (int k = 0; k < FE_LIMBS; k++) {
-        if (k < 8) {
+        // as in fe_mul: the products of column 9+k (chain d) and of column k (chain c) are issued alternately
 #pragma unroll
-            for (int i = 0; i < FE_LIMBS; i++) {
-                const int j = 9 + k - i;
-                if (j < 0 || j >= FE_LIMBS || i > j) continue;
-                const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
-                S2K_CHECK(d + pr >= d);
-                d += pr;
+        for (int t = 0; t < FE_LIMBS; t++) {
+            if (k < 8) {
+                const int i = k + 1 + t, j = 9 + k - i;              // i + j = 9 + k, i <= j
+                if (i < FE_LIMBS && i <= j) {
+                    const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
+                    S2K_CHECK(d + pr >= d);
+                    d += pr; S2K_CHAIN(d);
+                }
             }
+            {
+                const int i = t, j = k - t;                          // i + j = k, i <= j
+                if (j >= 0 && i <= j) {
+                    const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
+                    S2K_CHECK(c + pr >= c);
+                    c += pr; S2K_CHAIN(c);
+                }
+            }
+        }
+        if (k < 8) {
             u = (u32)d & FE_M; d >>= FE_BITS;
         } else {
             S2K_CHECK((d >> 32) == 0);
             u = (u32)d;
         }
-#pragma unroll
-        for (int i = 0; i < FE_LIMBS; i++) {
-            const int j = k - i;
-            if (j < 0 || j >= FE_LIMBS || i > j) continue;
-            const u64 pr = (i == j) ? (u64)a[i] * a[i] : (u64)a2[i] * a[j];
-            S2K_CHECK(c + pr >= c);
-            c += pr;
-        }
-        c += (u64)u * 31264u;
-        if (k > 0) c += (u64)uprev * k256;
+        c += (u64)u * 31264u; S2K_CHAIN(c);
+        if (k > 0) { c += (u64)uprev * k256; S2K_CHAIN(c); }
         uprev = u;
         r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
     }
