@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the GPU verifiers against the unmodified reference (oracle/_ref): large batches of valid proofs of mixed
+shapes with aggressive mutations (header bytes, sign bits, lengths, scalars at the group order, trailing / missing bytes).
+Not part of the test suite (it needs minutes of reference CPU time); run on a GPU box:  python tools/fuzz_parity.py [seed] [n]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from secp256k1_zkp_amd import Engine  # noqa: E402
+from tests.refapi import Ref, N  # noqa: E402
+
+
+def mutate(p, rng, k):
+    q = bytearray(p)
+    if not q:
+        return bytes(q)
+    if k == 0:   q[int(rng.integers(0, min(len(q), 12)))] ^= 1 << int(rng.integers(0, 8))          # header / sign bytes
+    elif k == 1: q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8))                   # anywhere
+    elif k == 2: q = q[:int(rng.integers(0, len(q)))]                                               # truncated
+    elif k == 3: q += bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))         # trailing bytes
+    elif k == 4: o = len(q) - 32 * int(rng.integers(1, max(2, min(8, len(q) // 32)))); q[o:o + 32] = N.to_bytes(32, "big")   # a scalar == n
+    elif k == 5: o = len(q) - 32 * int(rng.integers(1, max(2, min(8, len(q) // 32)))); q[o:o + 32] = bytes(32)              # a scalar == 0
+    elif k == 6: q[0] = int(rng.integers(0, 256))                                                   # random first header byte
+    elif k == 7: q[1] = int(rng.integers(0, 256))
+    return bytes(q)
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    rng = np.random.default_rng(seed); ref = Ref(); eng = Engine(0)
+    # ---- rangeproofs
+    C, P, G = [], [], []
+    shapes = [(64, 0, 0), (32, 0, 0), (5, 2, 17), (1, 0, 0), (13, 3, 1000), (63, 0, 5), (7, 18, 0), (2, 0, 0), (3, 1, 9), (0, -1, 0)]
+    per = max(1, n // len(shapes))
+    for (mb, exp, mv) in shapes:
+        vals = rng.integers(0, 2**max(mb, 1) if mb < 63 else 2**62, per, dtype=np.uint64) + np.uint64(mv) if mb else rng.integers(0, 2**40, per, dtype=np.uint64)
+        c, p, g, _ = ref.make_rangeproofs(per, rng, min_bits=mb, exp=exp, min_value=mv, values=vals, threads=16)
+        C.append(c); P += p; G.append(g)
+    C = np.concatenate(C); G = np.concatenate(G)
+    for i in range(len(P)):
+        if i % 4: P[i] = mutate(P[i], rng, int(rng.integers(0, 8)))
+        if i % 16 == 5: C[i, int(rng.integers(0, 33))] ^= 1 << int(rng.integers(0, 8))
+        if i % 16 == 9: G[i, int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+    e = ref.rangeproof_verify_many(C, P, G, threads=16)
+    r = eng.rangeproof_verify_batch(C, P, G)
+    # a commitment that secp256k1_pedersen_commitment_parse refuses never reaches secp256k1_rangeproof_verify in the reference
+    # (there is no object to pass); for those only the verdict 0 is compared, not the header-derived min/max
+    parses = np.array([int(ref.pedersen_verify_tally_many([(C[i:i + 1], C[i:i + 1])])[0]) >= 0 for i in range(len(P))])
+    bad = np.nonzero((e[0] != r[0]) | (parses & ((e[1] != r[1]) | (e[2] != r[2]))))[0]
+    print("rangeproof: %d items, %d accepted, %d unparseable commitments, mismatches: %d" % (len(P), int(e[0].sum()), int((~parses).sum()), len(bad)), bad[:10])
+    for i in bad[:5]:
+        print("   item", i, "ref", e[0][i], e[1][i], e[2][i], "gpu", r[0][i], r[1][i], r[2][i], "len", len(P[i]), "hdr", P[i][:11].hex())
+    # ---- BIP-340
+    sigs, msgs, pks = ref.make_schnorr(4 * n, rng, threads=16)
+    for i in range(4 * n):
+        k = i % 8
+        if k == 1: sigs[i, int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 2: pks[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 3: msgs[i, int(rng.integers(0, 32))] ^= 1
+        elif k == 4: sigs[i, 32:] = np.frombuffer(N.to_bytes(32, "big"), np.uint8)
+        elif k == 5: sigs[i, :32] = rng.integers(0, 256, 32, dtype=np.uint8)
+        elif k == 6: pks[i] = rng.integers(0, 256, 32, dtype=np.uint8)
+    e = ref.schnorr_verify_many(sigs, msgs, pks, threads=16)
+    r = eng.schnorrsig_verify_batch(sigs, msgs, pks)
+    print("bip340: %d items, %d accepted, mismatches: %d" % (4 * n, int(e.sum()), int((e != r).sum())))
+    # ---- surjection proofs
+    proofs, tags, outs = [], [], []
+    base = [ref.make_surjection(rng, ni, nu) for (ni, nu) in ((1, 1), (2, 1), (3, 2), (3, 3), (5, 3), (8, 8), (17, 4), (40, 9))]
+    for i in range(n):
+        p, t, o = base[i % len(base)]
+        t = t.copy(); o = o.copy()
+        if i % 3 == 1: p = mutate(p, rng, int(rng.integers(0, 6)))
+        if i % 7 == 2: t[int(rng.integers(0, t.shape[0])), int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        if i % 11 == 3: o[int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        proofs.append(p); tags.append(t); outs.append(o)
+    e = np.array([ref.surjection_verify(p, t, o) for p, t, o in zip(proofs, tags, outs)], np.int32)
+    r = eng.surjectionproof_verify_batch(proofs, tags, np.stack(outs))
+    print("surjection: %d items, %d accepted, mismatches: %d" % (n, int(e.sum()), int((e != r).sum())))
+    # ---- BP++ norm arguments
+    for (gl, hl) in ((64, 8), (16, 16), (4, 32)):
+        m = max(16, n // 16)
+        pr, trs, rhos, gens, g_len, cvs, commits = ref.make_bppp(m, rng, gl, hl)
+        pr = pr.copy(); rhos = rhos.copy(); cvs = cvs.copy(); commits = commits.copy(); trs = trs.copy()
+        for i in range(m):
+            k = i % 6
+            if k == 1: pr[i, int(rng.integers(0, pr.shape[1]))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 2: rhos[i, int(rng.integers(0, 32))] ^= 1
+            elif k == 3: cvs[i, int(rng.integers(0, cvs.shape[1])), int(rng.integers(0, 32))] ^= 1
+            elif k == 4: commits[i, int(rng.integers(0, 33))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 5: pr[i, 65 * int(rng.integers(0, (pr.shape[1] - 64) // 65))] = int(rng.integers(0, 8))          # sign byte of an (X, R) pair
+        e = ref.bppp_verify_many(pr, trs, rhos, gens, g_len, cvs, commits)
+        r = eng.bppp_norm_product_verify_batch(pr, trs, rhos, gens, g_len, cvs, commits)
+        print("bppp %d/%d: %d items, %d accepted, mismatches: %d" % (gl, hl, m, int(e.sum()), int((e != r).sum())))
+
+
+if __name__ == "__main__":
+    main()
