@@ -97,5 +97,70 @@ def main():
         print("bppp %d/%d: %d items, %d accepted, mismatches: %d" % (gl, hl, m, int(e.sum()), int((e != r).sum())))
 
 
+def more(seed, n):
+    """MSM with colliding points (P+P and P-P inside buckets), rewinding of mutated proofs / wrong nonces, tallies, half-aggregates"""
+    rng = np.random.default_rng(seed + 1000); ref = Ref(); eng = Engine(0)
+    P = 2**256 - 2**32 - 977
+    pts = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(3)])
+    neg = pts.copy()
+    for i in range(3):
+        neg[i, 32:] = np.frombuffer(((P - int.from_bytes(pts[i, 32:].tobytes(), "big")) % P).to_bytes(32, "big"), np.uint8)
+    pool = np.concatenate([pts, neg])
+    bad = 0
+    for m in (300, 2000, 20000):
+        sel = pool[rng.integers(0, 6, m)]
+        sc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        sc[rng.integers(0, m, m // 8)] = sc[0]                       # repeated scalars on repeated points
+        sc[rng.integers(0, m, m // 16), :24] = 0                     # short scalars
+        g = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        e_xy, e_inf = ref.ecmult_multi(sc, sel, g, None)
+        r_xy, r_inf = eng.ecmult_multi(sc, sel, g, None)
+        bad += int(e_inf != r_inf or not np.array_equal(e_xy, r_xy))
+    print("msm with colliding points: mismatches:", bad)
+    # rewind
+    C, PR, G, NN = [], [], [], []
+    for kw in (dict(msg_len=100, min_bits=64), dict(msg_len=0, min_bits=0, exp=-1, values=rng.integers(0, 2**50, n // 8, dtype=np.uint64)), dict(msg_len=33, min_bits=9, exp=1, min_value=3),
+               dict(msg_len=500, min_bits=32)):
+        c, p, g, v, b, nn, msg = ref.make_rangeproofs_msg(n // 8, rng, threads=16, **kw)
+        C.append(c); PR += p; G.append(g); NN.append(nn)
+    C = np.concatenate(C); G = np.concatenate(G); NN = np.concatenate(NN)
+    for i in range(len(PR)):
+        if i % 5 == 1: NN[i, int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        if i % 5 == 2: PR[i] = mutate(PR[i], rng, int(rng.integers(0, 8)))
+    e = ref.rangeproof_rewind_many(C, PR, G, NN, msg_capacity=600, threads=16)
+    r = eng.rangeproof_rewind_batch(C, PR, G, NN, msg_capacity=600)
+    ok = e[0] == 1
+    mism = int((e[0] != r[0]).sum()) + int((e[1][ok] != r[1][ok]).any(axis=1).sum()) + int((e[2][ok] != r[2][ok]).sum()) + sum(1 for a, b, o in zip(e[3], r[3], ok) if o and a != b)
+    print("rewind: %d items, %d rewound, mismatches: %d" % (len(PR), int(ok.sum()), mism))
+    # tallies
+    tallies = []
+    for i in range(n // 4):
+        a, b = ref.make_balanced_tally(rng, int(rng.integers(1, 6)), int(rng.integers(1, 6)))
+        k = i % 6
+        if k == 1: b = b[:-1]
+        elif k == 2: a = a.copy(); a[0, int(rng.integers(0, 33))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 3: a, b = b, a
+        elif k == 4: a = np.concatenate([a, b[:1]]); b = np.concatenate([b, b[:1]])
+        tallies.append((a, b))
+    e = np.maximum(ref.pedersen_verify_tally_many(tallies), 0)
+    r = eng.pedersen_verify_tally_batch(tallies)
+    print("tallies: %d items, %d balanced, mismatches: %d" % (len(tallies), int(e.sum()), int((e != r).sum())))
+    # half-aggregates
+    mism = 0; acc = 0
+    for t in range(24):
+        m = int(rng.integers(1, 300))
+        sigs, msgs, pks = ref.make_schnorr(m, rng, threads=8)
+        agg = bytearray(ref.halfagg_aggregate(pks, msgs, sigs))
+        k = t % 4
+        if k == 1: agg[int(rng.integers(0, len(agg)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 2: msgs[int(rng.integers(0, m)), 3] ^= 1
+        elif k == 3: pks[int(rng.integers(0, m)), int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+        ee = max(0, ref.halfagg_verify(pks, msgs, bytes(agg), m)); rr = eng.schnorrsig_aggverify(pks, msgs, bytes(agg), n=m)
+        mism += int(ee != rr); acc += ee
+    print("half-aggregates: 24 items, %d accepted, mismatches: %d" % (acc, mism))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "more":
+        more(int(sys.argv[1]), int(sys.argv[2])); sys.exit(0)
     main()
