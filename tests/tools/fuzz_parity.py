@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU verifiers against the unmodified reference (oracle/_ref): large batches of valid proofs of mixed
 shapes with aggressive mutations (header bytes, sign bits, lengths, scalars at the group order, trailing / missing bytes).
-Not part of the test suite (it needs minutes of reference CPU time); run on a GPU box:  python tools/fuzz_parity.py [seed] [n]"""
+Not part of the test suite (it needs minutes of reference CPU time); run on a GPU box:  python tests/tools/fuzz_parity.py [seed] [n]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from secp256k1_zkp_amd import Engine  # noqa: E402
 from tests.refapi import Ref, N  # noqa: E402
