@@ -50,6 +50,8 @@ struct s2k_engine {
     u32* ptab;                 // per-lane odd-multiples tables (S2K_PTAB_WORDS words per lane), grown on demand
     size_t ptab_lanes;
     hipEvent_t ev[4];          // [0],[1] whole call; [2],[3] dominant kernel
+    hipStream_t stream2;       // side stream for kernels that can run next to the main sequence
+    hipEvent_t ev_fork, ev_join;
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
     u32* host_flags;           // pinned, 64 bytes: device -> host flags of the MSM binning pass
@@ -158,12 +160,15 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
     e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0;
-    e->stream = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
+    e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
     if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) S2K_CREATE_CHK(hipEventCreate(&e->ev[i]));
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
     S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
@@ -184,6 +189,9 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->gtab) hipFree(e->gtab);
     if (e->host_flags) hipHostFree(e->host_flags);
     for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -268,17 +276,22 @@ extern "C" int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
 // ------------------------------------------------------------------------------------------------------------
 // Borromean rangeproof batch verification (rangeproof.h): five kernels on one stream
 // ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint64_t mn, mx;
+    rp_header(ws.rec[p], &mn, &mx, proofs + proof_off[p], proof_off[p + 1] - proof_off[p]);
+    min_value[p] = mn; max_value[p] = mx;
+}
 __global__ void __launch_bounds__(64)
-k_rp_prologue(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* commits33, const unsigned char* proofs,
+k_rp_prologue(rp_ws ws, const uint64_t* min_value, const unsigned char* commits33, const unsigned char* proofs,
               const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint64_t o0 = proof_off[p], o1 = proof_off[p + 1];
     const unsigned char* ex = nullptr; uint64_t exlen = 0;
     if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
-    uint64_t mn, mx;
-    rp_prologue(ws.rec[p], ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, &mn, &mx, commits33 + 33 * p, proofs + o0, o1 - o0, ex, exlen, gens64 + 64 * p);
-    min_value[p] = mn; max_value[p] = mx;
+    rp_prologue_points(ws.rec[p], ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, min_value[p], commits33 + 33 * p, proofs + proof_off[p], ex, exlen, gens64 + 64 * p);
 }
 __global__ void __launch_bounds__(256)
 k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
@@ -286,7 +299,7 @@ k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size
     const size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     if (p >= n) return;
     const rp_rec& rec = ws.rec[p];
-    if (!rec.ok || ring + 1 >= rec.rings) return;
+    if (!(rec.hdr & 1u) || ring + 1 >= rec.rings) return;          // needs the header only: runs next to k_rp_prologue
     rp_lift(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring);
 }
 __global__ void __launch_bounds__(64)
@@ -391,9 +404,15 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
         const size_t m = std::min(n - p0, RP_CHUNK);
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
-        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value + p0, max_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
+        hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, min_value + p0, max_value + p0, proofs, proof_off + p0, m);
+        // fork: the per-proof point work (one lane per proof, latency bound) and the per-ring lifts (throughput bound) are independent
+        HIPCHK(hipEventRecord(e->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
+        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
                            extra_off ? extra_off + p0 : nullptr, gens64 + 64 * p0, m);
-        hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, m);
+        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
         hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);
         if (p0 == 0) HIPCHK(hipEventRecord(e->ev[2], st));
         hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr);

@@ -30,7 +30,7 @@ struct rp_rec {
     u32 off_pts;
     u32 off_e0;
     u32 off_s;
-    u32 pad;
+    u32 hdr;           // bit 0: header and structure parsed (K0a); bits 8..15: exp + 1
     u32 m[8];          // message hash, big-endian words
     u32 commit[18];    // commitment, affine limbs (x, y)
     u32 accj[RP_GEJ_WORDS];   // min_value * H (infinity when min_value == 0)
@@ -93,15 +93,14 @@ S2K_HD int rp_getheader(u32& offset, int& exp, int& mantissa, u64& scale, u64* m
     return 1;
 }
 
-// One lane per proof.  cf. rangeproof_impl.h:541-608 and pub_expand :20-51.
-S2K_HD void rp_prologue(rp_rec& rec, u32* bases /*[32][28]*/, u64* min_value, u64* max_value, const unsigned char* commit33,
-                        const unsigned char* proof, u64 plen, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
-    rec.ok = 0; rec.rings = 0; rec.last_rsize = 0;
+// K0a: header and structure (rangeproof_impl.h:541-608 up to the point where curve arithmetic starts).  Cheap; K1 (lift) only
+// needs this part, so the expensive part below (K0b) can run next to K1.
+S2K_HD void rp_header(rp_rec& rec, u64* min_value, u64* max_value, const unsigned char* proof, u64 plen) {
+    rec.ok = 0; rec.rings = 0; rec.last_rsize = 0; rec.hdr = 0;
     rec.off_signs = 0; rec.off_pts = 0; rec.off_e0 = 0; rec.off_s = 0;
     *min_value = 0; *max_value = 0;
     u32 offset; int exp, mantissa; u64 scale;
     if (!rp_getheader(offset, exp, mantissa, scale, min_value, max_value, proof, plen)) return;
-    const u32 off_hdr = offset;
     u32 rings = 1, npub = 1, last_rsize = 1;
     if (mantissa != 0) {
         rings = (u32)mantissa >> 1; npub = rings * 4; last_rsize = 4;
@@ -118,7 +117,15 @@ S2K_HD void rp_prologue(rp_rec& rec, u32* bases /*[32][28]*/, u64* min_value, u6
     rec.off_e0 = offset + 32 * (rings - 1);
     rec.off_s = rec.off_e0 + 32;
     if ((u64)rec.off_s + (u64)32 * npub != plen) return;        // "Extra data found, reject" (:643-646); too-short was caught above
-
+    rec.hdr = 1u | ((u32)(exp + 1) << 8);
+}
+// K0b: commitment / generator load, message hash, min_value*H, ring bases (:588-651, pub_expand :20-51).  One lane per proof.
+S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value_in, const unsigned char* commit33,
+                               const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+    if (!(rec.hdr & 1u)) return;
+    const u32 rings = rec.rings, off_hdr = rec.off_signs;
+    const int exp = (int)((rec.hdr >> 8) & 0xFFu) - 1;
+    const u64 mv_in = min_value_in; const u64* min_value = &mv_in;
     // commitment: x = b32 mod p, y = sqrt(x^3+7), negated when bit 0 of the prefix is set (generator/main_impl.h:266-273)
     ge c;
     {
@@ -188,6 +195,13 @@ S2K_HD void rp_prologue(rp_rec& rec, u32* bases /*[32][28]*/, u64* min_value, u6
         }
     }
     rec.ok = 1;
+}
+
+// both halves back to back (host emulation, tests)
+S2K_HD void rp_prologue(rp_rec& rec, u32* bases, u64* min_value, u64* max_value, const unsigned char* commit33,
+                        const unsigned char* proof, u64 plen, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+    rp_header(rec, min_value, max_value, proof, plen);
+    rp_prologue_points(rec, bases, *min_value, commit33, proof, extra, extra_len, gen64);
 }
 
 // ---- K1: lift the ring commitments (rangeproof_impl.h:609-626) ------------------------------------------------
