@@ -24,6 +24,7 @@ void emu_fe_mul(unsigned char* r, const unsigned char* a, const unsigned char* b
 void emu_fe_sqr(unsigned char* r, const unsigned char* a) { fe x, z; fe_from_b32(x, a); fe_sqr(z, x); fe_to_b32(r, z); }
 void emu_fe_add(unsigned char* r, const unsigned char* a, const unsigned char* b) { fe x, y; fe_from_b32(x, a); fe_from_b32(y, b); fe_add(x, y); fe_to_b32(r, x); }
 void emu_fe_negate(unsigned char* r, const unsigned char* a) { fe x, y; fe_from_b32(x, a); fe_neg(y, x, 1); fe_to_b32(r, y); }
+void emu_fe_inv_fermat(unsigned char* r, const unsigned char* a) { fe x, z; fe_from_b32(x, a); fe_inv_fermat(z, x); fe_to_b32(r, z); }
 void emu_fe_inv(unsigned char* r, const unsigned char* a) { fe x, z; fe_from_b32(x, a); fe_inv(z, x); fe_to_b32(r, z); }
 int emu_fe_sqrt(unsigned char* r, const unsigned char* a) { fe x, z; fe_from_b32(x, a); int ok = fe_sqrt(z, x); fe_to_b32(r, z); return ok; }
 void emu_fe_half(unsigned char* r, const unsigned char* a) { fe x; fe_from_b32(x, a); fe_half(x); fe_to_b32(r, x); }
