@@ -94,7 +94,7 @@ S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
 // r = a + b, both Jacobian.  12M + 4S (cf. secp256k1_gej_add_var, group_impl.h:534-596).  Complete: handles
 // infinity, a == b (by doubling -- this function is only used in cold prologue/epilogue code) and a == -b.
 // Inputs magnitudes up to (5,3,1).
-S2K_HD_NOINLINE void gej_add_var(gej& r, const gej& a, const gej& b) {
+S2K_HD void gej_add_var(gej& r, const gej& a, const gej& b) {
     fe z22, z12, u1, u2, s1, s2, h, i, h2, h3, t, i2;
     fe_sqr(z22, b.z); fe_sqr(z12, a.z);
     fe_mul(u1, a.x, z22); fe_mul(u2, b.x, z12);
