@@ -25,11 +25,14 @@
 #include "scalar.h"
 
 // ---- generator table ---------------------------------------------------------------------------------
-// gtab[((w << 16) + v) * 18 .. +18) = affine (x limbs[9], y limbs[9]) of  v * 65536^w * G ,  v = 1..65535, w = 0..15.
-#define S2K_GTAB_BITS 16
-#define S2K_GTAB_WINDOWS 16
+// gtab[((w << B) + v) * 18 .. +18) = affine (x limbs[9], y limbs[9]) of  v * 2^(B w) * G ,  v = 1..2^B-1, w = 0..W-1, with
+// B = S2K_GTAB_BITS and W = ceil(256 / B).  B = 20: 13 windows, 981 MB of the 288 GB (the host emulation builds B = 12).
+#ifndef S2K_GTAB_BITS
+#define S2K_GTAB_BITS 20
+#endif
+#define S2K_GTAB_WINDOWS ((256 + S2K_GTAB_BITS - 1) / S2K_GTAB_BITS)
 #define S2K_GTAB_ENTRY_WORDS 18
-#define S2K_GTAB_WORDS ((size_t)S2K_GTAB_WINDOWS * 65536 * S2K_GTAB_ENTRY_WORDS)
+#define S2K_GTAB_WORDS (((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) * S2K_GTAB_ENTRY_WORDS)
 
 S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
     const u32* p = gtab + ((size_t)(window << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
@@ -118,7 +121,7 @@ S2K_HD void ptab_fetch(ge& o, const u32* ptab, u32 v, int half, int sign_flip) {
 // spill around every point operation; in LDS it costs one ds_read per addition.  Word-major layout (word k of lane t at
 // [k * S2K_DIG_STRIDE + t]) keeps the accesses bank-conflict free.
 //   words 0..8 : 4-bit digit of addition a (2 <= a < 66) in nibble a & 7 of word a >> 3
-//   words 9..16: ng, 16-bit window g of the generator phase in half g & 1 of word 9 + (g >> 1)
+//   words 9..16: ng (little-endian words); window g of the generator phase is bits [B g, B g + B)
 #define S2K_DIG_WORDS 17
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) u32* s2k_lds_ptr;
@@ -215,7 +218,9 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         }                                                                                                           \
         else if (_i < S2K_ADDS_TOTAL) {                                                                             \
             const int _g = _i - S2K_ADD_G0;                                                                         \
-            const u32 _v = (dig[(9 + (_g >> 1)) * S2K_DIG_STRIDE] >> ((_g & 1) * 16)) & 0xFFFFu;                    \
+            const int _b = _g * S2K_GTAB_BITS, _w = _b >> 5;                                                        \
+            const u64 _pair = (u64)dig[(9 + _w) * S2K_DIG_STRIDE] | ((u64)(_w + 1 < 8 ? dig[(10 + _w) * S2K_DIG_STRIDE] : 0u) << 32); \
+            const u32 _v = (u32)(_pair >> (_b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);                                 \
             if (_v) { gtab_load(dst, gtab, (u32)_g, _v); dst_valid = 1; }                                           \
         }                                                                                                           \
     } while (0)

@@ -112,8 +112,10 @@ __global__ void k_gtab_base(u32* gtab) {
 __global__ void __launch_bounds__(256)
 k_gtab_entries(u32* gtab) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 w = t >> S2K_GTAB_BITS, v = t & 0xFFFFu;
-    if (w < S2K_GTAB_WINDOWS && v >= 2) gtab_build_entry(gtab, w, v);
+    const u32 w = t >> S2K_GTAB_BITS, v = t & ((1u << S2K_GTAB_BITS) - 1u);
+    // the top window only ever sees the bits that are left of a 256-bit scalar
+    const u32 top_bits = 256 - S2K_GTAB_BITS * (S2K_GTAB_WINDOWS - 1);
+    if (w < S2K_GTAB_WINDOWS && v >= 2 && (w + 1 < S2K_GTAB_WINDOWS || v < (1u << top_bits))) gtab_build_entry(gtab, w, v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -121,7 +123,10 @@ k_gtab_entries(u32* gtab) {
 // one multiplication per lane; inputs are gathered with byte loads (160 B per lane against ~1.5 M cycles of
 // arithmetic -- the loads are noise), the result is converted to affine and serialised in the same kernel.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
+#ifndef S2K_EB_WAVES
+#define S2K_EB_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, S2K_EB_WAVES)
 k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, const unsigned char* __restrict__ a_xy,
                const unsigned char* __restrict__ a_inf, const unsigned char* __restrict__ na, const unsigned char* __restrict__ ng,
                const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n) {
@@ -174,7 +179,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
     S2K_CREATE_CHK(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
-    hipLaunchKernelGGL(k_gtab_entries, dim3(S2K_GTAB_WINDOWS * 65536 / 256), dim3(256), 0, e->stream, e->gtab);
+    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, e->stream, e->gtab);
     S2K_CREATE_CHK(hipGetLastError());
     S2K_CREATE_CHK(hipStreamSynchronize(e->stream));
 #undef S2K_CREATE_CHK

@@ -2,10 +2,11 @@
 //
 // Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
 // src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine with
-// 288 GB of HBM that would rather gather 72 bytes than execute 16 doublings: entry (w, v) = v * 65536^w * G for every
-// 16-bit value of every one of the 16 windows of a scalar, in the engine's own 9x29 limb format (18 words, affine), so
-// ng*G is 16 mixed additions and zero doublings.  16 x 65535 entries x 72 B = 75.5 MB (Infinity-Cache resident).
-// The table is *computed on the device* when an engine is created (two kernels, a few ms), never shipped as data.
+// 288 GB of HBM that would rather gather 72 bytes than execute doublings: entry (w, v) = v * 2^(B w) * G for every B-bit
+// value of every window of a scalar (B = S2K_GTAB_BITS = 20: 13 windows), in the engine's own 9x29 limb format (18 words,
+// affine), so ng*G is 13 mixed additions and zero doublings.  13 x 2^20 entries x 72 B = 981 MB; the gathers are issued one
+// addition ahead, so their HBM latency is covered.  The table is *computed on the device* when an engine is created (two
+// kernels, ~30 ms), never shipped as data.
 #pragma once
 #include "ecmult.h"
 
@@ -19,7 +20,7 @@ S2K_HD void gtab_store(u32* gtab, u32 w, u32 v, const ge& a) {
     u32* p = gtab + ((size_t)(w << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
     for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
 }
-// step 1 (one thread per window w): base[w] = 65536^w * G, affine, stored as entry (w, 1).
+// step 1 (one thread per window w): base[w] = 2^(B w) * G, affine, stored as entry (w, 1).
 S2K_HD void gtab_build_base(u32* gtab, u32 w) {
     ge g; ge_set_generator(g);
     gej j; gej_set_ge(j, g);
@@ -27,7 +28,7 @@ S2K_HD void gtab_build_base(u32* gtab, u32 w) {
     ge a; ge_set_gej(a, j);
     gtab_store(gtab, w, 1, a);
 }
-// step 2 (one thread per (w, v), v = 2..65535): entry = v * base[w] by left-to-right double-and-add.
+// step 2 (one thread per (w, v), v = 2..2^B-1): entry = v * base[w] by left-to-right double-and-add.
 S2K_HD void gtab_build_entry(u32* gtab, u32 w, u32 v) {
     ge base; gtab_load(base, gtab, w, 1);
     gej acc; gej_set_infinity(acc);

@@ -84,25 +84,25 @@ static std::vector<u32> g_gtab;
 static u32 g_ptab[S2K_PTAB_WORDS];
 static u32 g_dig[S2K_DIG_WORDS];
 static const lane_mem g_lm{g_ptab, g_dig};
-// Host-only construction of the 16-bit window table: same entries as gtable.h's device kernels, but built by running
+// Host-only construction of the window table (this library is compiled with -DS2K_GTAB_BITS=12 to keep it small): same entries as gtable.h's device kernels, but built by running
 // sums + Montgomery batch inversion so that a CPU test does not spend a minute on a million inversions.
 static const u32* gtab_host() {
     if (g_gtab.empty()) {
         g_gtab.assign(S2K_GTAB_WORDS, 0);
-        std::vector<gej> acc(65536); std::vector<fe> pre(65536);
+        const u32 NV = 1u << S2K_GTAB_BITS; std::vector<gej> acc(NV); std::vector<fe> pre(NV);
         for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
             gtab_build_base(g_gtab.data(), w);
             ge base; gtab_load(base, g_gtab.data(), w, 1);
             gej_set_ge(acc[1], base);
-            for (u32 v = 2; v < 65536; v++) {
+            for (u32 v = 2; v < NV; v++) {
                 gej t; int f = gej_add_ge(t, acc[v - 1], base);
                 if (f == GEJ_ADD_NEEDS_DOUBLE) { gej u; gej_double(u, t); t = u; }
                 fe_norm_weak(t.y); acc[v] = t;
             }
             fe run; fe_set_int(run, 1);
-            for (u32 v = 1; v < 65536; v++) { pre[v] = run; fe_mul(run, run, acc[v].z); }
+            for (u32 v = 1; v < NV; v++) { pre[v] = run; fe_mul(run, run, acc[v].z); }
             fe inv; fe_inv(inv, run);
-            for (u32 v = 65535; v >= 2; v--) {
+            for (u32 v = NV - 1; v >= 2; v--) {
                 fe zi, zi2, zi3; fe_mul(zi, inv, pre[v]); fe_mul(inv, inv, acc[v].z);
                 fe_sqr(zi2, zi); fe_mul(zi3, zi2, zi);
                 ge a; fe_mul(a.x, acc[v].x, zi2); fe_mul(a.y, acc[v].y, zi3); fe_normalize(a.x); fe_normalize(a.y);

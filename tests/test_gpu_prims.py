@@ -127,16 +127,24 @@ def test_sha256(prims):
         assert got[i].tobytes() == hashlib.sha256(m[i].tobytes()).digest()
 
 
+def _gtab_bits():
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "secp256k1_zkp_amd", "csrc", "ecmult.h")).read()
+    return int(re.search(r"#define S2K_GTAB_BITS (\d+)", src).group(1))
+
+
 def test_generator_table(prims, ref):
-    """entries (w, v) of the device-built 16-bit window table equal v*65536^w*G computed by the reference's ecmult
-    (role of test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample."""
+    """entries (w, v) of the device-built window table equal v*2^(B w)*G computed by the reference's ecmult (role of
+    test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample."""
     rng = np.random.default_rng(16)
-    idx = [(w, v) for w in range(16) for v in (1, 2, 3, 255, 256, 257, 32767, 32768, 65534, 65535)]
-    idx += [(int(rng.integers(0, 16)), int(rng.integers(1, 65536))) for _ in range(4000)]
+    B = _gtab_bits(); W = (256 + B - 1) // B; top = 256 - B * (W - 1)
+    nv = lambda w: (1 << B) if w + 1 < W else (1 << top)
+    idx = [(w, v) for w in range(W) for v in (1, 2, 3, 255, 256, 257, nv(w) // 2 - 1, nv(w) // 2, nv(w) - 2, nv(w) - 1)]
+    idx += [(w, int(rng.integers(1, nv(w)))) for w in rng.integers(0, W, 4000)]
     n = len(idx)
-    sel = np.array([(w << 16) | v for (w, v) in idx], np.uint32)
+    sel = np.array([(int(w) << B) | v for (w, v) in idx], np.uint32)
     got, _ = prims(11, n, 64, sel.view(np.uint8))
-    ng = np.stack([np.frombuffer(_b(v << (16 * w)), np.uint8) for (w, v) in idx])
+    ng = np.stack([np.frombuffer(_b(v << (B * int(w))), np.uint8) for (w, v) in idx])
     g = np.frombuffer(G_XY * n, np.uint8).reshape(-1, 64)
     exp, inf = ref.ecmult_batch(g, np.zeros((n, 32), np.uint8), ng)
     assert not inf.any()
