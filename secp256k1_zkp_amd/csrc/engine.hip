@@ -289,14 +289,25 @@ k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned c
     rp_header(ws.rec[p], &mn, &mx, proofs + proof_off[p], proof_off[p + 1] - proof_off[p]);
     min_value[p] = mn; max_value[p] = mx;
 }
-__global__ void __launch_bounds__(64)
+// three waves per 64 proofs: wave 0 commitment + min_value*H, wave 1 generator flag + message hash, wave 2 ring bases
+__global__ void __launch_bounds__(192)
 k_rp_prologue(rp_ws ws, const uint64_t* min_value, const unsigned char* commits33, const unsigned char* proofs,
               const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const unsigned char* ex = nullptr; uint64_t exlen = 0;
-    if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
-    rp_prologue_points(ws.rec[p], ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, min_value[p], commits33 + 33 * p, proofs + proof_off[p], ex, exlen, gens64 + 64 * p);
+    // few, latency-bound waves that share the SIMDs with the throughput-bound lift kernel: ask the arbiter to issue them first
+    __builtin_amdgcn_s_setprio(3);
+    const u32 role = threadIdx.x >> 6;
+    const size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (p < n) {
+        rp_rec& rec = ws.rec[p];
+        if (role == 0) rp_pp_commit(rec, min_value[p], commits33 + 33 * p, gens64 + 64 * p);
+        else if (role == 1) {
+            const unsigned char* ex = nullptr; uint64_t exlen = 0;
+            if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
+            rp_pp_hash(rec, commits33 + 33 * p, proofs + proof_off[p], ex, exlen, gens64 + 64 * p);
+        } else rp_pp_bases(rec, ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, gens64 + 64 * p);
+    }
+    __syncthreads();
+    if (p < n && role == 0 && (ws.rec[p].hdr & 1u)) ws.rec[p].ok = 1;
 }
 __global__ void __launch_bounds__(256)
 k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
@@ -415,7 +426,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
         HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
         HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(64), 0, st, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
+        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(192), 0, st, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
                            extra_off ? extra_off + p0 : nullptr, gens64 + 64 * p0, m);
         HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
         hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);

@@ -119,14 +119,17 @@ S2K_HD void rp_header(rp_rec& rec, u64* min_value, u64* max_value, const unsigne
     if ((u64)rec.off_s + (u64)32 * npub != plen) return;        // "Extra data found, reject" (:643-646); too-short was caught above
     rec.hdr = 1u | ((u32)(exp + 1) << 8);
 }
-// K0b: commitment / generator load, message hash, min_value*H, ring bases (:588-651, pub_expand :20-51).  One lane per proof.
-S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value_in, const unsigned char* commit33,
-                               const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+// K0b: the per-proof point work (:588-651, pub_expand :20-51) in three independent parts, so that the kernel can give each part
+// its own wave (one lane per proof in each): A commitment load + min_value*H, B generator flag + message hash, C ring bases.
+S2K_HD void rp_load_generator(ge& g, const unsigned char* gen64) {                  // generator/main_impl.h:40-49
+    fe_set_b32_mod(g.x, gen64); fe_set_b32_mod(g.y, gen64 + 32);
+    fe_normalize(g.x); fe_normalize(g.y);
+}
+// A: commitment: x = b32 mod p, y = sqrt(x^3+7), negated when bit 0 of the prefix is set (generator/main_impl.h:266-273);
+//    accj = min_value * H (pedersen_ecmult_small, generator/pedersen_impl.h:33-38): plain double-and-add, the same group
+//    element as the reference's ecmult_const
+S2K_HD void rp_pp_commit(rp_rec& rec, u64 min_value, const unsigned char* commit33, const unsigned char* gen64) {
     if (!(rec.hdr & 1u)) return;
-    const u32 rings = rec.rings, off_hdr = rec.off_signs;
-    const int exp = (int)((rec.hdr >> 8) & 0xFFu) - 1;
-    const u64 mv_in = min_value_in; const u64* min_value = &mv_in;
-    // commitment: x = b32 mod p, y = sqrt(x^3+7), negated when bit 0 of the prefix is set (generator/main_impl.h:266-273)
     ge c;
     {
         fe x; fe_set_b32_mod(x, commit33 + 1);
@@ -135,65 +138,73 @@ S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_val
         if (commit33[0] & 1) { fe_neg(c.y, c.y, 1); fe_normalize(c.y); }
     }
     for (int i = 0; i < 9; i++) { rec.commit[i] = c.x.n[i]; rec.commit[9 + i] = c.y.n[i]; }
-    // generator (generator/main_impl.h:40-49)
-    ge g;
-    fe_set_b32_mod(g.x, gen64); fe_set_b32_mod(g.y, gen64 + 32);
-    fe_normalize(g.x); fe_normalize(g.y);
-
-    // m = SHA256( ser(commit) || ser(gen) || proof[0..off_hdr) || (sign_i || x_i)_{i<rings-1} || extra )   (:588-651)
-    // ser(point) = [ !is_square(y) ] || x   (rangeproof_serialize_point :53-59)
-    {
-        sha256_stream h; sha256_stream_init(h);
-        unsigned char buf[32];
-        // y of the commitment is the square root (a square) unless negated; y == 0 cannot occur for x^3+7 = 0 has no
-        // solution with a square... keep the exact rule: is_square(0) = 1.
-        int cy_zero = fe_is_zero_normalized(c.y);
-        sha256_stream_put(h, (unsigned char)((commit33[0] & 1) && !cy_zero ? 1 : 0));
-        fe_get_b32(buf, c.x); sha256_stream_write(h, buf, 32);
-        fe r; const int gsq = fe_sqrt(r, g.y);
-        sha256_stream_put(h, (unsigned char)(!gsq));
-        fe_get_b32(buf, g.x); sha256_stream_write(h, buf, 32);
-        sha256_stream_write(h, proof, off_hdr);
-        for (u32 i = 0; i + 1 < rings; i++) {
-            const unsigned char sign = (proof[rec.off_signs + (i >> 3)] & (1u << (i & 7))) != 0;
-            sha256_stream_put(h, sign);
-            sha256_stream_write(h, proof + rec.off_pts + 32 * i, 32);
-        }
-        if (extra) sha256_stream_write(h, extra, (size_t)extra_len);
-        unsigned char m[32];
-        sha256_stream_finalize(h, m);
-        for (int i = 0; i < 8; i++) rec.m[i] = s2k_load_be32(m + 4 * i);
-    }
-    // accj = min_value * H  (pedersen_ecmult_small, generator/pedersen_impl.h:33-38): plain double-and-add, the
-    // result is the same group element as the reference's ecmult_const.
-    {
-        gej acc; gej_set_infinity(acc);
-        const u64 mv = *min_value;
-        if (mv) {
-            for (int bit = 63; bit >= 0; bit--) {
-                gej t; gej_double(t, acc); acc = t;
-                if ((mv >> bit) & 1) {
-                    const int f = gej_add_ge(t, acc, g); acc = t;
-                    if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
-                }
+    gej acc; gej_set_infinity(acc);
+    if (min_value) {
+        ge g; rp_load_generator(g, gen64);
+        for (int bit = 63; bit >= 0; bit--) {
+            gej t; gej_double(t, acc); acc = t;
+            if ((min_value >> bit) & 1) {
+                const int f = gej_add_ge(t, acc, g); acc = t;
+                if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
             }
         }
-        gej_store28_h(rec.accj, acc);
     }
-    // ring bases: base_0 = -(10^exp) H, base_{i+1} = 4 base_i   (pub_expand, rangeproof_impl.h:20-51)
-    {
-        gej base; ge ng; ng.x = g.x; fe_neg(ng.y, g.y, 1); fe_norm_weak(ng.y);
-        gej_set_ge(base, ng);
-        for (int e = 0; e < exp; e++) {          // multiplication by 10 = 8x + 2x
-            gej t2, t8, s;
-            gej_double(t2, base); gej_double(t8, t2); gej_double(s, t8);
-            gej_add_var(base, s, t2);
-        }
-        for (u32 i = 0; i < rings; i++) {
-            gej_store28_h(bases + RP_GEJ_WORDS * i, base);
-            if (i + 1 < rings) { gej t; gej_double(t, base); gej_double(base, t); }
-        }
+    gej_store28_h(rec.accj, acc);
+}
+// B: m = SHA256( ser(commit) || ser(gen) || proof[0..off_hdr) || (sign_i || x_i)_{i<rings-1} || extra )   (:588-651)
+//    ser(point) = [ !is_square(y) ] || x   (rangeproof_serialize_point :53-59)
+S2K_HD void rp_pp_hash(rp_rec& rec, const unsigned char* commit33, const unsigned char* proof, const unsigned char* extra, u64 extra_len,
+                       const unsigned char* gen64) {
+    if (!(rec.hdr & 1u)) return;
+    const u32 rings = rec.rings, off_hdr = rec.off_signs;
+    ge g; rp_load_generator(g, gen64);
+    sha256_stream h; sha256_stream_init(h);
+    unsigned char buf[32];
+    // the commitment's y is sqrt(x^3+7) (a square) unless the prefix bit negates it; is_square(0) = 1, and y = 0 would need
+    // x^3 + 7 = 0 (checked here without the square root; no such x exists on a curve of odd order, but the rule is kept exact)
+    fe cx; fe_set_b32_mod(cx, commit33 + 1); fe_normalize(cx);
+    fe rhs; ge_curve_rhs(rhs, cx);
+    const int cy_zero = fe_normalizes_to_zero(rhs);
+    sha256_stream_put(h, (unsigned char)((commit33[0] & 1) && !cy_zero ? 1 : 0));
+    fe_get_b32(buf, cx); sha256_stream_write(h, buf, 32);
+    fe r; const int gsq = fe_sqrt(r, g.y);
+    sha256_stream_put(h, (unsigned char)(!gsq));
+    fe_get_b32(buf, g.x); sha256_stream_write(h, buf, 32);
+    sha256_stream_write(h, proof, off_hdr);
+    for (u32 i = 0; i + 1 < rings; i++) {
+        const unsigned char sign = (proof[rec.off_signs + (i >> 3)] & (1u << (i & 7))) != 0;
+        sha256_stream_put(h, sign);
+        sha256_stream_write(h, proof + rec.off_pts + 32 * i, 32);
     }
+    if (extra) sha256_stream_write(h, extra, (size_t)extra_len);
+    unsigned char m[32];
+    sha256_stream_finalize(h, m);
+    for (int i = 0; i < 8; i++) rec.m[i] = s2k_load_be32(m + 4 * i);
+}
+// C: ring bases: base_0 = -(10^exp) H, base_{i+1} = 4 base_i   (pub_expand, rangeproof_impl.h:20-51)
+S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsigned char* gen64) {
+    if (!(rec.hdr & 1u)) return;
+    const u32 rings = rec.rings;
+    const int exp = (int)((rec.hdr >> 8) & 0xFFu) - 1;
+    ge g; rp_load_generator(g, gen64);
+    gej base; ge ng; ng.x = g.x; fe_neg(ng.y, g.y, 1); fe_norm_weak(ng.y);
+    gej_set_ge(base, ng);
+    for (int e = 0; e < exp; e++) {          // multiplication by 10 = 8x + 2x
+        gej t2, t8, s;
+        gej_double(t2, base); gej_double(t8, t2); gej_double(s, t8);
+        gej_add_var(base, s, t2);
+    }
+    for (u32 i = 0; i < rings; i++) {
+        gej_store28_h(bases + RP_GEJ_WORDS * i, base);
+        if (i + 1 < rings) { gej t; gej_double(t, base); gej_double(base, t); }
+    }
+}
+S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value, const unsigned char* commit33,
+                               const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+    if (!(rec.hdr & 1u)) return;
+    rp_pp_commit(rec, min_value, commit33, gen64);
+    rp_pp_hash(rec, commit33, proof, extra, extra_len, gen64);
+    rp_pp_bases(rec, bases, gen64);
     rec.ok = 1;
 }
 
