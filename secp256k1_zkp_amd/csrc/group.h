@@ -35,15 +35,14 @@ S2K_HD void ge_neg(ge& r, const ge& a) { r.x = a.x; fe_neg(r.y, a.y, 1); fe_norm
 S2K_HD void gej_double(gej& r, const gej& a) {
     fe x = a.x, y = a.y, l, s, t;
     fe_norm_weak(x); fe_norm_weak(y);
-    fe_mul(r.z, y, a.z);                       // Z3 = Y*Z            (1)
-    fe_sqr(s, y);                              // S = Y^2             (1)
-    fe_sqr(l, x);                              // X^2                 (1)
+    // the seven products go out as three lockstep pairs (fe_dual) and one single
+    fe_mul_sqr(r.z, y, a.z, s, y);             // Z3 = Y*Z, S = Y^2    (1, 1)
+    fe_mul_sqr(t, x, s, l, x);                 // X*S, X^2             (1, 1)
+    fe_neg(t, t, 1);                           // T = -X*S             (2)
     fe_mul_int(l, 3); fe_half(l);              // L = 3/2 X^2         (<= 2.5)
     fe_norm_weak(l);                           //                     (1)
-    fe_mul(t, x, s); fe_neg(t, t, 1);          // T = -X*S            (2)
-    fe_sqr(r.x, l);                            // L^2                 (1)
+    fe_sqr2(r.x, l, s, s);                     // L^2, S^2            (1, 1)
     fe_add(r.x, t); fe_add(r.x, t);            // X3 = L^2 + 2T       (5)
-    fe_sqr(s, s);                              // S^2                 (1)
     fe_add(t, r.x);                            // X3 + T              (7)
     fe_mul(r.y, t, l);                         // L*(X3+T)            (1)   7*1 <= 7
     fe_add(r.y, s);                            //                     (2)
@@ -57,17 +56,15 @@ S2K_HD void gej_double(gej& r, const gej& a) {
 S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
     fe z12, u2, s2, h, i, h2, h3, t, i2;
     fe_sqr(z12, a.z);
-    fe_mul(u2, b.x, z12);
-    fe_mul(s2, b.y, z12); fe_mul(s2, s2, a.z);
+    fe_mul2(u2, b.x, z12, s2, b.y, z12);       // lockstep pairs of independent products (fe_dual)
     fe_neg(h, a.x, 5); fe_add(h, u2);          // h = u2 - X1         (7)
+    fe_norm_seq(h);                            // exact limbs: needed for the zero test, and magnitude 1 for the products
+    fe zz; fe_mul2(s2, s2, a.z, zz, a.z, h);   // s2 = Y2*Z1^3, Z3 = Z1*h
     fe_neg(i, a.y, 3); fe_add(i, s2);          // i = s2 - Y1         (5)
-    fe_norm_seq(h); fe_norm_seq(i);            // exact limbs: needed for the zero tests, and magnitude 1 for the products
+    fe_norm_seq(i);
     const int hz = fe_seq_is_zero(h), iz = fe_seq_is_zero(i);
-    fe_sqr(i2, i);
-    fe_sqr(h2, h);
-    fe_mul(h3, h, h2);
-    fe_mul(t, a.x, h2);                        // t = X1*h2           (6*1)
-    fe zz; fe_mul(zz, a.z, h);                 // Z3 = Z1*h
+    fe_sqr2(i2, i, h2, h);
+    fe_mul2(h3, h, h2, t, a.x, h2);            // h^3, t = X1*h2      (6*1)
     if (zr) *zr = h;                           // Z3 / Z1, for global-Z table construction
     fe x3, y3, tn;
     fe_neg(x3, h3, 1);                         // -h3                 (2)
@@ -75,8 +72,7 @@ S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
     fe_add(x3, tn); fe_add(x3, tn); fe_add(x3, i2);   // X3 = i2 - h3 - 2t   (7)
     fe_norm_weak(x3);                          //                     (1)
     fe_neg(tn, x3, 1); fe_add(tn, t);          // t - X3              (3)
-    fe_mul(y3, tn, i);                         // i*(t - X3)          (1)
-    fe_mul(h3, h3, a.y);                       // Y1*h3               (5*1)
+    fe_mul2(y3, tn, i, h3, h3, a.y);           // i*(t - X3), Y1*h3   (3*1, 1*5... <= 7)
     fe_neg(h3, h3, 1);
     fe_add(y3, h3);                            // Y3                  (3)
     // case resolution (per lane, no branches)
