@@ -92,10 +92,12 @@ S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
 // Inputs magnitudes up to (5,3,1).
 S2K_HD void gej_add_var(gej& r, const gej& a, const gej& b) {
     fe z22, z12, u1, u2, s1, s2, h, i, h2, h3, t, i2;
-    fe_sqr(z22, b.z); fe_sqr(z12, a.z);
-    fe_mul(u1, a.x, z22); fe_mul(u2, b.x, z12);
-    fe_mul(s1, a.y, z22); fe_mul(s1, s1, b.z);
-    fe_mul(s2, b.y, z12); fe_mul(s2, s2, a.z);
+    // all 16 products as lockstep pairs (fe_dual): this function runs in single-wave, latency-bound tails where the
+    // dependent-MAC wait states are fully exposed
+    fe_sqr2(z22, b.z, z12, a.z);
+    fe_mul2(u1, a.x, z22, u2, b.x, z12);
+    fe_mul2(s1, a.y, z22, s2, b.y, z12);
+    fe_mul2(s1, s1, b.z, s2, s2, a.z);
     fe_neg(h, u1, 1); fe_add(h, u2);
     fe_neg(i, s1, 1); fe_add(i, s2);
     fe_norm_seq(h); fe_norm_seq(i);
@@ -104,16 +106,17 @@ S2K_HD void gej_add_var(gej& r, const gej& a, const gej& b) {
     if ((!a.inf) & (!b.inf) & hz & iz) {
         gej_double(res, a);
     } else {
-        fe_sqr(i2, i); fe_sqr(h2, h); fe_mul(h3, h, h2);
-        fe_mul(t, u1, h2);
-        fe_mul(res.z, a.z, b.z); fe_mul(res.z, res.z, h);
+        fe zz;
+        fe_mul_sqr(zz, a.z, b.z, h2, h);
+        fe_mul_sqr(res.z, zz, h, i2, i);
+        fe_mul2(h3, h, h2, t, u1, h2);
         fe x3, tn;
         fe_neg(x3, h3, 1); fe_neg(tn, t, 1);
         fe_add(x3, tn); fe_add(x3, tn); fe_add(x3, i2);
         fe_norm_weak(x3);
         fe_neg(tn, x3, 1); fe_add(tn, t);
-        fe_mul(res.y, tn, i);
-        fe_mul(h3, h3, s1); fe_neg(h3, h3, 1);
+        fe_mul2(res.y, tn, i, h3, h3, s1);
+        fe_neg(h3, h3, 1);
         fe_add(res.y, h3);
         res.x = x3;
         res.inf = hz & (!iz);
