@@ -338,13 +338,13 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
     const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-            ws.ring_out + (p * RP_MAX_RINGS + ring) * 36, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr);
+            ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr);
 }
 __global__ void __launch_bounds__(64)
 k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    results[p] = rp_final(ws.rec[p], ws.ring_out + p * RP_MAX_RINGS * 36, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
+    results[p] = rp_final(ws.rec[p], ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
 }
 
 // rewinding (rangeproof_rewind.h): one lane per proof that verified
@@ -399,14 +399,14 @@ k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_v
 }
 
 static size_t rp_ws_bytes(size_t n) {
-    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_MAX_RINGS * 36, n * RP_MAX_RINGS});
+    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_RING_OUT_BYTES, n * RP_MAX_RINGS});
 }
 static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
     w.rec = c.take<rp_rec>(n);
     w.bases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.pub0 = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.lift_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
-    w.ring_out = c.take<unsigned char>(n * RP_MAX_RINGS * 36);
+    w.ring_out = c.take<unsigned char>(n * RP_RING_OUT_BYTES);
     w.ring_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
 }
 // launches the five stages; `w` must already point into device memory

@@ -21,6 +21,7 @@
 
 #define RP_MAX_RINGS 32
 #define RP_GEJ_WORDS 28
+#define RP_RING_OUT_BYTES (RP_MAX_RINGS * 33 + 32)      /* 1088 = 17 SHA-256 blocks for a full-size proof */
 
 struct rp_rec {
     u32 ok;            // structural checks passed (K0); cleared by later stages on failure
@@ -41,7 +42,7 @@ struct rp_ws {           // device pointers into the engine workspace
     u32* bases;          // [n][32][28]
     u32* pub0;           // [n][32][28]
     unsigned char* lift_ok;   // [n][32]
-    unsigned char* ring_out;  // [n][32][36]
+    unsigned char* ring_out;  // [n][RP_RING_OUT_BYTES]: the rings' 33-byte outputs back to back, then room for m
     unsigned char* ring_ok;   // [n][32]
 };
 
@@ -299,7 +300,7 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
 
 // ev_out (optional): the challenge e of each ring position, 4 x 8 big-endian words per ring -- the reference's `evalues`
 // (borromean_impl.h:80-83), which only rewinding needs (rangeproof_rewind.h)
-S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out36, unsigned char* ring_ok,
+S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
                     const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm, u32* ev_out = nullptr) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
@@ -357,25 +358,40 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
         }
     }
     if (live) {
-        ring_out36[0] = (unsigned char)outp;
-        for (int i = 0; i < 8; i++) s2k_store_be32(ring_out36 + 1 + 4 * i, outx[i]);
+        ring_out33[0] = (unsigned char)outp;
+        for (int i = 0; i < 8; i++) s2k_store_be32(ring_out33 + 1 + 4 * i, outx[i]);
         *ring_ok = (unsigned char)ok;
     }
 }
 
 // ---- K4: close the loop (borromean_impl.h:100-103) ---------------------------------------------------------------------
-S2K_HD int rp_final(const rp_rec& rec, const unsigned char* ring_out /*[32][36]*/, const unsigned char* ring_ok, const unsigned char* proof) {
+S2K_HD int rp_final(const rp_rec& rec, unsigned char* ring_out /*[RP_RING_OUT_BYTES], 4-byte aligned*/, const unsigned char* ring_ok, const unsigned char* proof) {
     if (!rec.ok) return 0;
     int ok = 1;
-    sha256_stream h; sha256_stream_init(h);
-    for (u32 i = 0; i < rec.rings; i++) {
-        ok &= ring_ok[i];
-        sha256_stream_write(h, ring_out + 36 * i, 33);
+    for (u32 i = 0; i < rec.rings; i++) ok &= ring_ok[i];
+    // e0' = SHA256( r_0 | ... | r_{rings-1} | m ): the ring outputs already lie back to back, m is appended and the buffer is
+    // hashed a block (16 aligned words) at a time
+    const u32 len = 33 * rec.rings + 32;
+    for (int i = 0; i < 8; i++) s2k_store_be32(ring_out + 33 * rec.rings + 4 * i, rec.m[i]);
+    u32 st[8]; sha256_init(st);
+    u32 off = 0;
+    for (; off + 64 <= len; off += 64) {
+        u32 w[16];
+        for (int i = 0; i < 16; i++) w[i] = s2k_load_be32(ring_out + off + 4 * i);
+        sha256_compress(st, w);
     }
-    unsigned char mb[32], d[32];
-    for (int i = 0; i < 8; i++) s2k_store_be32(mb + 4 * i, rec.m[i]);
-    sha256_stream_write(h, mb, 32);
-    sha256_stream_finalize(h, d);
+    {
+        u32 w[16];
+        for (int i = 0; i < 16; i++) w[i] = 0;
+        const u32 rem = len - off;                                   // < 64
+        for (u32 k = 0; k < rem; k++) w[k >> 2] |= (u32)ring_out[off + k] << (24 - 8 * (k & 3));
+        w[rem >> 2] |= 0x80u << (24 - 8 * (rem & 3));
+        if (rem >= 56) { sha256_compress(st, w); for (int i = 0; i < 16; i++) w[i] = 0; }
+        w[15] = len * 8;
+        sha256_compress(st, w);
+    }
+    unsigned char d[32];
+    for (int i = 0; i < 8; i++) s2k_store_be32(d + 4 * i, st[i]);
     int diff = 0;
     for (int i = 0; i < 32; i++) diff |= d[i] ^ proof[rec.off_e0 + i];
     return ok & (diff == 0);

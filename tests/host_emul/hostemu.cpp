@@ -135,13 +135,13 @@ void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
 // the five rangeproof stages of rangeproof.h run back to back for one proof
 int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
                           const unsigned char* extra, size_t extra_len, const unsigned char* gen64) {
-    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0); unsigned char lift_ok[32] = {0}, ring_out[32 * 36] = {0}, ring_ok[32] = {0};
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0); unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
     u64 mn, mx;
     rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, extra_len ? extra : nullptr, extra_len, gen64);
     *min_value = mn; *max_value = mx;
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
-    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm);
     return rp_final(rec, ring_out, ring_ok, proof);
 }
 
@@ -150,13 +150,13 @@ int emu_rangeproof_rewind(unsigned char* blind_out, unsigned long long* value_ou
                           unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
                           const unsigned char* gen64) {
     rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), ev(128 * 8, 0), prep(128 * 8, 0), secs(32 * 8, 0);
-    unsigned char lift_ok[32] = {0}, ring_out[32 * 36] = {0}, ring_ok[32] = {0};
+    unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
     u64 mn, mx;
     rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, nullptr, 0, gen64);
     *min_value = mn; *max_value = mx;
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
-    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 36 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, ev.data() + 32 * i);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, ev.data() + 32 * i);
     if (!rp_final(rec, ring_out, ring_ok, proof)) return 0;
     scalar blind; u64 value = 0, mlen = (msg_out && outlen) ? *outlen : 0;
     if (!rp_rewind(blind, value, msg_out, &mlen, rec, proof, nonce32, gen64, ev.data(), prep.data(), secs.data())) { if (outlen) *outlen = 0; return 0; }
