@@ -8,7 +8,11 @@
 // and accepts iff res1 == res2.  Here both are folded into ONE sum  res2 - res1  that must be the point at infinity,
 // and a batch of proofs becomes a flat list of (proof, term) lanes:
 //   bp_prologue  1 lane / proof : transcript challenges, the scalar vectors s_g, s_h, v  (scalar.h) -> per-term scalars
-//   bp_term      1 lane / term  : fetch / decompress the term's point, full double-and-add (ecmult.h)
+//   bp_term      1 lane / term  : fetch / decompress the term's point, full double-and-add (ecmult.h) -- for the few points that
+//                                 come from the proof; the generators G_i / H_j are the same for every proof of a deployment, so
+//                                 the engine keeps a fixed-base table per generator set in HBM (16 windows x 65536 multiples x
+//                                 72 B = 75.5 MB per generator, 5.4 GB for 64 + 8 generators, built once on the device) and a
+//                                 generator term is 16 table additions with no doubling (bp_term_fixed)
 //   gej_reduce   segmented tree sum over each proof's terms, then  result = ok && sum == infinity
 #pragma once
 #include "ecmult.h"
@@ -165,4 +169,56 @@ S2K_HD int bp_term(gej& out, const bp_shape& sh, u32 t, const u32* term_sc, cons
     if (!live) { sc_set_zero(k); sc_set_zero(g); gej_set_infinity(A); }
     ecmult_lane(out, A, k, g, has_g, gtab, lm);
     return ok;
+}
+
+// ---- fixed-base tables for a generator set -------------------------------------------------------------------------------
+#define BP_TAB_BITS 16
+#define BP_TAB_WINDOWS 16
+S2K_HD size_t bp_tab_words(size_t n_gens) { return ((n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS) * 18; }
+S2K_HD u32* bp_tab_entry(u32* tab, u32 gen, u32 w, u32 v) { return tab + ((((size_t)gen * BP_TAB_WINDOWS + w) << BP_TAB_BITS) + v) * 18; }
+// entry (gen, w, 1) = 2^(16 w) * P_gen
+S2K_HD void bp_tab_build_base(u32* tab, const u32* gens18, u32 gen, u32 w) {
+    ge p; for (int i = 0; i < 9; i++) { p.x.n[i] = gens18[18 * gen + i]; p.y.n[i] = gens18[18 * gen + 9 + i]; }
+    gej j; gej_set_ge(j, p);
+    for (u32 i = 0; i < BP_TAB_BITS * w; i++) { gej t; gej_double(t, j); j = t; }
+    ge a; ge_set_gej(a, j);
+    u32* e = bp_tab_entry(tab, gen, w, 1);
+    for (int i = 0; i < 9; i++) { e[i] = a.x.n[i]; e[9 + i] = a.y.n[i]; }
+}
+// entry (gen, w, v) = v * entry (gen, w, 1), v >= 2
+S2K_HD void bp_tab_build_entry(u32* tab, u32 gen, u32 w, u32 v) {
+    ge base; { const u32* e = bp_tab_entry(tab, gen, w, 1); for (int i = 0; i < 9; i++) { base.x.n[i] = e[i]; base.y.n[i] = e[9 + i]; } }
+    gej acc; gej_set_infinity(acc);
+    for (int bit = BP_TAB_BITS - 1; bit >= 0; bit--) {
+        gej t; gej_double(t, acc); acc = t;
+        if ((v >> bit) & 1u) {
+            const int f = gej_add_ge(t, acc, base); acc = t;
+            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+        }
+    }
+    ge a; ge_set_gej(a, acc);
+    u32* e = bp_tab_entry(tab, gen, w, v);
+    for (int i = 0; i < 9; i++) { e[i] = a.x.n[i]; e[9 + i] = a.y.n[i]; }
+}
+// k * P_gen as 16 table additions (k: 8 little-endian words); the next operand is fetched while the current one is added
+S2K_HD void bp_term_fixed(gej& out, const u32* tab, u32 gen, const u32* k8) {
+    gej acc; gej_set_infinity(acc);
+    ge cur, nxt; u32 vcur, vnxt;
+    fe_set_zero(cur.x); fe_set_zero(cur.y);
+    vcur = k8[0] & 0xFFFFu;
+    { const u32* e = bp_tab_entry((u32*)tab, gen, 0, vcur); for (int i = 0; i < 9; i++) { cur.x.n[i] = e[i]; cur.y.n[i] = e[9 + i]; } }
+    for (u32 w = 0; w < BP_TAB_WINDOWS; w++) {
+        vnxt = 0; nxt = cur;
+        if (w + 1 < BP_TAB_WINDOWS) {
+            vnxt = (k8[(w + 1) >> 1] >> (16 * ((w + 1) & 1))) & 0xFFFFu;
+            const u32* e = bp_tab_entry((u32*)tab, gen, w + 1, vnxt);
+            for (int i = 0; i < 9; i++) { nxt.x.n[i] = e[i]; nxt.y.n[i] = e[9 + i]; }
+        }
+        if (vcur) {
+            gej t; const int f = gej_add_ge(t, acc, cur); acc = t;
+            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+        }
+        cur = nxt; vcur = vnxt;
+    }
+    out = acc;
 }

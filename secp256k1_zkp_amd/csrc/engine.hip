@@ -56,6 +56,8 @@ struct s2k_engine {
     size_t max_lanes;          // lanes per launch (multiple of 256)
     u32* host_flags;           // pinned, 64 bytes: device -> host flags of the MSM binning pass
     int msm_fallback;          // the most recent bucket MSM took the exact-sort fallback
+    std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
+    u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
     std::recursive_mutex mu;
 };
 
@@ -164,7 +166,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0; e->bp_tab = nullptr;
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
@@ -192,6 +194,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
     if (e->gtab) hipFree(e->gtab);
+    if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
     for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -1030,18 +1033,41 @@ k_bp_prologue(u32* term_sc, int* proof_ok, bp_shape sh, const unsigned char* pro
     if (p >= n) return;
     proof_ok[p] = bp_prologue(term_sc + p * sh.n_terms * 8, sh, proofs + p * proof_len, transcripts + p * 104, rho + 32 * p, c_vec + p * sh.h_len * 32);
 }
+// terms t0 .. t0 + tcount - 1 of every proof, one lane each (full double-and-add)
 __global__ void __launch_bounds__(256, 2)
 k_bp_terms(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* gens18, const unsigned char* proofs,
-           size_t proof_len, const unsigned char* commits33, const u32* gtab, u32* ptab, size_t n) {
+           size_t proof_len, const unsigned char* commits33, const u32* gtab, u32* ptab, size_t n, u32 t0, u32 tcount) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t p = t / sh.n_terms; const u32 ti = (u32)(t % sh.n_terms);
-    int live = p < n;
+    size_t p = t / tcount; const u32 ti = t0 + (u32)(t % tcount);
+    const int inrange = p < n;
+    int live = inrange;
     if (!live) p = 0;
     live &= proof_ok[p];
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
     const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     gej o; const int ok = bp_term(o, sh, ti, term_sc + p * sh.n_terms * 8, gens18, proofs + p * proof_len, commits33 + 33 * p, live, gtab, lm);
-    if (t < n * sh.n_terms) { gej_store28(out28 + t * 28, o); term_ok[t] = (unsigned char)ok; }
+    if (inrange) { gej_store28(out28 + (p * sh.n_terms + ti) * 28, o); term_ok[p * sh.n_terms + ti] = (unsigned char)ok; }
+}
+// generator terms 0 .. n_gens - 1 of every proof through the generator set's fixed-base table
+__global__ void __launch_bounds__(256, 2)
+k_bp_terms_fixed(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* tab, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t p = t / sh.n_gens; const u32 ti = (u32)(t % sh.n_gens);
+    if (p >= n) return;
+    gej o; gej_set_infinity(o);
+    if (proof_ok[p]) bp_term_fixed(o, tab, ti, term_sc + (p * sh.n_terms + ti) * 8);
+    gej_store28(out28 + (p * sh.n_terms + ti) * 28, o); term_ok[p * sh.n_terms + ti] = 1;
+}
+__global__ void k_bp_tab_base(u32* tab, const u32* gens18, u32 n_gens) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_gens * BP_TAB_WINDOWS) bp_tab_build_base(tab, gens18, t / BP_TAB_WINDOWS, t % BP_TAB_WINDOWS);
+}
+__global__ void __launch_bounds__(256)
+k_bp_tab_entries(u32* tab, size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const u32 v = (u32)(t & 0xFFFFu); const size_t gw = t >> BP_TAB_BITS;
+    if (v >= 2) bp_tab_build_entry(tab, (u32)(gw / BP_TAB_WINDOWS), (u32)(gw % BP_TAB_WINDOWS), v);
 }
 __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1095,9 +1121,30 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     HIPCHK(hipMemcpyAsync(gens_ok, &one, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
+    // fixed-base table of this generator set: built on first use, kept for the following calls (a deployment has one set).
+    // Sets too large for the table (> 256 generators = 19 GB) take the general path.
+    int fixed = n_gens <= 256;
+    if (fixed && (e->bp_key.size() != 33 * n_gens || memcmp(e->bp_key.data(), gens33, 33 * n_gens) != 0)) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (e->bp_tab) { hipFree(e->bp_tab); e->bp_tab = nullptr; }
+        e->bp_key.clear();
+        if (hipMalloc((void**)&e->bp_tab, bp_tab_words(n_gens) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); e->bp_tab = nullptr; fixed = 0; }
+        else {
+            const size_t total = (n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS;
+            hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
+            hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
+            HIPCHK(hipGetLastError());
+            e->bp_key.assign(gens33, gens33 + 33 * n_gens);
+        }
+    }
     hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm, e->gtab, e->ptab, n);
+    {
+        const u32 t0 = fixed ? (u32)n_gens : 0u, tcount = (u32)T - t0;
+        if (fixed) hipLaunchKernelGGL(k_bp_terms_fixed, dim3((unsigned)((n * n_gens + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, e->bp_tab, n);
+        hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((n * tcount + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm,
+                           e->gtab, e->ptab, n, t0, tcount);
+    }
     HIPCHK(hipEventRecord(e->ev[3], st));
     const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);
     hipLaunchKernelGGL(k_bp_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_res, sums, proof_ok, term_ok, gens_ok, (u32)T, n);
