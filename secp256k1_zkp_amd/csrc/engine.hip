@@ -65,7 +65,7 @@ struct s2k_engine {
 static int engine_ptab(s2k_engine* e, size_t lanes) {
     lanes = (lanes + 255) & ~size_t(255);
     if (lanes <= e->ptab_lanes) return 1;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipDeviceSynchronize());                 // earlier launches (possibly on a caller's stream) may still use the old arena
     if (e->ptab) HIPCHK(hipFree(e->ptab));
     e->ptab = nullptr; e->ptab_lanes = 0;
     HIPCHK(hipMalloc((void**)&e->ptab, lanes * S2K_PTAB_WORDS * sizeof(u32)));
@@ -77,7 +77,7 @@ static int engine_ptab(s2k_engine* e, size_t lanes) {
 // (engine field max_lanes; default 2^20, $S2K_MAX_LANES overrides it -- the tests use a small value to exercise the split)
 static int engine_workspace(s2k_engine* e, size_t bytes) {
     if (bytes <= e->ws_bytes) return 1;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipDeviceSynchronize());                 // earlier launches (possibly on a caller's stream) may still use the old workspace
     if (e->ws) HIPCHK(hipFree(e->ws));
     e->ws = nullptr; e->ws_bytes = 0;
     bytes = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
