@@ -157,7 +157,9 @@ S2K_API int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* stre
  * All items share the generator set (gens33: n_gens compressed points, G_i first then H_i, as
  * secp256k1_bppp_generators_serialize writes them), g_len, c_vec_len and proof_len.  transcripts: n * 104 bytes, each the
  * SHA-256 state {uint32 s[8]; uint8 buf[64]; uint64 bytes} of the parent protocol (src/hash.h); rho n*32; c_vec
- * n*c_vec_len*32; commits n*33 (33 zero bytes = infinity, secp256k1.c:895). */
+ * n*c_vec_len*32; commits n*33 (33 zero bytes = infinity, secp256k1.c:895).
+ * The engine keeps a fixed-base table for the most recent generator set (75.5 MB per generator, built on the first call with that
+ * set and reused while gens33 stays byte-identical); sets of more than 256 generators take the table-free path. */
 S2K_API int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
                                                      const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
                                                      size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
