@@ -45,3 +45,23 @@ def test_random_proofs(engine, ref, g_len, h_len, n):
     res = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits)
     assert np.array_equal(res, exp)
     assert exp[0] == 1 and exp.sum() < n
+
+
+def test_generator_set_cache_switching(engine, ref):
+    """the fixed-base table is keyed by the serialised generator set: alternating between two sets (and a shape change with the same
+    prefix of generators) must rebuild it each time and never reuse stale entries"""
+    rng = np.random.default_rng(404)
+    a = ref.make_bppp(6, rng, 8, 2)
+    b = ref.make_bppp(6, rng, 4, 4)            # different shape, its own generators
+    for args in (a, b, a, b, a):
+        proofs, trs, rhos, gens, gl, cvs, commits = args
+        proofs = proofs.copy(); proofs[1, 7] ^= 1
+        exp = ref.bppp_verify_many(proofs, trs, rhos, gens, gl, cvs, commits)
+        res = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits)
+        assert np.array_equal(res, exp) and exp.sum() == 5
+    # same length, one generator replaced by another valid point: every proof must now fail, and verify again with the original set
+    proofs, trs, rhos, gens, gl, cvs, commits = a
+    g2 = gens.copy(); g2[3] = g2[4]              # gens: (n_gens, 33) serialised points
+    assert not engine.bppp_norm_product_verify_batch(proofs, trs, rhos, g2, gl, cvs, commits).any()
+    assert not ref.bppp_verify_many(proofs, trs, rhos, g2, gl, cvs, commits).any()
+    assert engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits).all()
