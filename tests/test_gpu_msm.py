@@ -113,3 +113,29 @@ def test_sharded_path_single_rank(engine, ref):
     p1 = be.msm_partial(torch.tensor(sc[h:]).cuda(), torch.tensor(pts[h:]).cuda(), None, None)
     xy, inf = be.gej_sum(torch.stack([p0, p1]))
     assert inf == einf and np.array_equal(xy, exp)
+
+
+def test_msm_config5_2p20(engine, ref):
+    """BASELINE config 5 at full size: one 2^20-term MSM, points k_i*G (made on the GPU by the batch double multiplication, which
+    has its own parity tests), against the reference's secp256k1_ecmult_multi_var (Pippenger, ~6 s on one core), with and without
+    the generator term; plus the size-independent cross-check sum_i s_i*(k_i*G) == (sum_i s_i*k_i)*G."""
+    rng = np.random.default_rng(2020)
+    n = 1 << 20
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    g = np.frombuffer(G_XY * n, np.uint8).reshape(n, 64)
+    pts, inf = engine.ecmult_batch(g, np.zeros((n, 32), np.uint8), ks, None)
+    assert not inf.any()
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    gs = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    exp, einf = ref.ecmult_multi(sc, pts, gs, None)
+    got, ginf = engine.ecmult_multi(sc, pts, gs, None)
+    assert ginf == einf == 0 and np.array_equal(got, exp)
+    assert not engine.last_msm_fallback()
+    # (sum s_i k_i) * G by plain integer arithmetic
+    tot = 0
+    for i in range(0, n, 4096):
+        a = [int.from_bytes(sc[j].tobytes(), "big") for j in range(i, i + 4096)]; b = [int.from_bytes(ks[j].tobytes(), "big") for j in range(i, i + 4096)]
+        tot = (tot + sum(x * y for x, y in zip(a, b))) % N
+    tot = (tot + int.from_bytes(gs, "big")) % N
+    one, oinf = ref.ecmult_batch(np.frombuffer(G_XY, np.uint8).reshape(1, 64), np.zeros((1, 32), np.uint8), np.frombuffer(tot.to_bytes(32, "big"), np.uint8).reshape(1, 32))
+    assert np.array_equal(got, one[0])

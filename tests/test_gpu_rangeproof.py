@@ -137,3 +137,22 @@ def test_rewind_batch_vs_reference(engine, ref):
         assert np.array_equal(bl[ok], e_bl[ok]) and np.array_equal(val[ok], e_val[ok]) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
         assert [m for m, o in zip(msgs, ok) if o] == [m for m, o in zip(e_msgs, ok) if o]
         assert 0 < ok.sum() < len(P) and not bl[~ok].any() and not val[~ok].any()
+
+
+def test_config3_full_size(engine, ref):
+    """BASELINE config 3 at full size: 2^14 unique 64-bit proofs (5 126 bytes, 32 rings x 4) plus the negative set: single-bit flips,
+    a trailing byte, a truncation"""
+    rng = np.random.default_rng(314)
+    n = 1 << 14
+    commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=16)
+    assert all(len(p) == 5126 for p in proofs)
+    for i in range(0, n, 37):
+        k = (i // 37) % 3
+        if k == 0: q = bytearray(proofs[i]); q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8)); proofs[i] = bytes(q)
+        elif k == 1: proofs[i] = proofs[i] + b"\x00"
+        else: proofs[i] = proofs[i][:-1]
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(commits, proofs, gens, threads=16)
+    res, mn, mx = engine.rangeproof_verify_batch(commits, proofs, gens)
+    assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
+    assert e_res.sum() == n - len(range(0, n, 37))
+    assert int(mx[1]) == 2**64 - 1

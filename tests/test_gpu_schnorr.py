@@ -45,3 +45,16 @@ def test_random_batch(engine, ref):
     good = np.nonzero(ref.xonly_valid(pks[:600]))[0]
     res1 = engine.schnorrsig_verify_batch(sigs[good], msgs[good], ref.xonly_objects(pks[good]), pk_format=1)
     assert np.array_equal(res1, exp[good]) and len(good) > 500
+
+
+def test_config2_full_size(engine, ref):
+    """BASELINE config 2 at full size: 2^16 signatures, a fixed pseudo-random 1/256 corrupted (one bit of s or r)"""
+    rng = np.random.default_rng(216)
+    n = 1 << 16
+    sigs, msgs, pks = ref.make_schnorr(n, rng, threads=16)
+    bad = rng.choice(n, n // 256, replace=False)
+    for k, i in enumerate(bad):
+        sigs[i, (32 if k & 1 else 0) + int(rng.integers(0, 32))] ^= 1 << int(rng.integers(0, 8))
+    exp = ref.schnorr_verify_many(sigs, msgs, pks, threads=16)
+    res = engine.schnorrsig_verify_batch(sigs, msgs, pks)
+    assert np.array_equal(res, exp) and exp.sum() == n - n // 256
