@@ -65,3 +65,23 @@ def test_generator_set_cache_switching(engine, ref):
     assert not engine.bppp_norm_product_verify_batch(proofs, trs, rhos, g2, gl, cvs, commits).any()
     assert not ref.bppp_verify_many(proofs, trs, rhos, g2, gl, cvs, commits).any()
     assert engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits).all()
+
+
+def test_config4_full_size(engine, ref):
+    """BASELINE config 4 at full size: 2^12 norm-argument proofs over 64 + 8 generators (256 distinct proofs, replicated), every 19th
+    one corrupted in the proof bytes, rho, c_vec or the commitment"""
+    rng = np.random.default_rng(412)
+    base = ref.make_bppp(256, rng, 64, 8)
+    reps = 16; n = 256 * reps
+    proofs = np.concatenate([base[0]] * reps); trs = np.concatenate([base[1]] * reps); rhos = np.concatenate([base[2]] * reps)
+    cvs = np.concatenate([base[5]] * reps); commits = np.concatenate([base[6]] * reps)
+    for i in range(0, n, 19):
+        k = (i // 19) % 4
+        if k == 0: proofs[i, int(rng.integers(0, proofs.shape[1]))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1: rhos[i, int(rng.integers(0, 32))] ^= 1
+        elif k == 2: cvs[i, int(rng.integers(0, 8)), 31] ^= 1
+        else: commits[i, int(rng.integers(1, 33))] ^= 1
+    exp = ref.bppp_verify_many(proofs, trs, rhos, base[3], base[4], cvs, commits)
+    res = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, base[3], base[4], cvs, commits)
+    assert np.array_equal(res, exp)
+    assert exp.sum() == n - len(range(0, n, 19))
