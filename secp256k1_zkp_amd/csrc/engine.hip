@@ -622,8 +622,9 @@ k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned cha
     msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
                   isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg);
 }
-// Binning: workgroup (chunk, window).  Two sweeps over the chunk's half-scalar records: count into the LDS histogram, reserve
-// each bucket's slots with one global atomic, then hand the slots out with LDS atomics and write the references.
+// Binning: workgroup (chunk, window).  One sweep over the chunk's half-scalar records: the LDS histogram gives every digit its
+// rank inside the workgroup, one global atomic per non-empty bucket reserves the workgroup's slots, then the references are
+// written from the (bucket, rank) pairs kept in registers.
 // refs layout: bucket k owns refs[k*cap .. k*cap + cap); gcnt[k] ends up as the bucket's full size even when it overflows.
 // The top window only has 128 - c*(windows-1) live bits (both GLV halves are below 2^128, scalar_impl.h:183-285), so its
 // few buckets are proportionally fuller: they get their own capacity.  Bucket k = w*nb + b starts at msm_region(k).
@@ -641,36 +642,42 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) s_cnt[b] = 0;
     msm_wconst wc; msm_window_const(wc, w, pl.c);
     __syncthreads();
-    for (size_t t = t0 + tid; t < t1; t += MSM_BIN_THREADS) {
-        u32 h[MSM_HALF_WORDS];
-        const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+    // sweep: digit of every half-scalar of the chunk, rank inside the workgroup from the LDS histogram; the (bucket, rank, sign)
+    // of the at most 8 terms x 2 halves a thread owns stay in registers (chunk <= 8 * MSM_BIN_THREADS)
+    u32 kv[8][2];
 #pragma unroll
-        for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+    for (int it = 0; it < 8; it++) {
+        kv[it][0] = 0; kv[it][1] = 0;
+        const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
+        if (t < t1) {
+            u32 h[MSM_HALF_WORDS];
+            const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
-            if (key) atomicAdd(&s_cnt[key >> 1], 1u);
+            for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
+                if (key) { const u32 bkt = key >> 1, rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank; }
+            }
         }
     }
     __syncthreads();
     for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) {
         const u32 c = s_cnt[b];
-        s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;
+        s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;          // one global atomic per non-empty (workgroup, bucket)
     }
     __syncthreads();
     int over = 0;
-    for (size_t t = t0 + tid; t < t1; t += MSM_BIN_THREADS) {
-        u32 h[MSM_HALF_WORDS];
-        const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+    const int top = (w + 1 == pl.windows);
 #pragma unroll
-        for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+    for (int it = 0; it < 8; it++) {
+        const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const u32 key = msm_key_at(h, half, 0, wc, pl);
-            if (key) {
-                const u32 b = key >> 1, slot = atomicAdd(&s_cnt[b], 1u);
-                const int top = (w + 1 == pl.windows);
-                if (slot < (top ? L.cap_top : L.cap) && (!top || b < L.top_used)) refs[msm_region(L, pl, w, b) + slot] = (u32)(t << 2) | ((u32)half << 1) | (key & 1u);
+            const u32 k = kv[it][half];
+            if (k) {
+                const u32 bkt = (k >> 16) & 0x1FFFu, slot = s_cnt[bkt] + (k & 0xFFFFu);
+                if (slot < (top ? L.cap_top : L.cap) && (!top || bkt < L.top_used)) refs[msm_region(L, pl, w, bkt) + slot] = (u32)(t << 2) | ((u32)half << 1) | (k >> 31);
                 else over = 1;
             }
         }
