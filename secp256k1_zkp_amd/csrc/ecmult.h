@@ -10,10 +10,11 @@
 //                    4 doublings + 2 additions per digit position for all 64 lanes.  The 8 odd multiples {1..15}P
 //                    (+ their beta*x for lambda*P) are built once per multiplication with one common Z -- the reference's
 //                    isomorphic-curve / global-Z trick (ecmult_impl.h:73-115, group_impl.h:289-320) -- and parked in a
-//                    per-lane 896-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
+//                    per-lane 1152-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
 //                    addition ahead so the ~1-2 us of latency hides under the previous ~4 us of arithmetic.
-//   generator:       no doublings at all: ng is cut into 16 x 16-bit windows, each indexing a precomputed
-//                    (window, value) -> affine multiple table (gtable.h, 75 MB in HBM), 16 mixed additions.
+//   generator:       no doublings at all: ng is cut into 13 windows of 20 bits (S2K_GTAB_BITS), each indexing a precomputed
+//                    (window, value) -> affine multiple table (gtable.h, 981 MB in HBM), 13 mixed additions.
+//   digits:          both digit streams live in LDS (lane_mem), not in registers.
 //   control:         one loop whose body contains exactly ONE doubling site and ONE mixed-add site, driven by a
 //                    per-lane micro-program counter.  The only data-dependent *arithmetic* case (P + P inside an add)
 //                    becomes "take the operand and double it on the next trip", so exceptional inputs cost one extra
