@@ -21,6 +21,7 @@
 // Bit-exactness is defined on the canonical 32-byte encodings (fe_get_b32 after fe_normalize), never on limbs.
 #pragma once
 #include "s2k_common.h"
+#include "modinv.h"
 
 #define FE_LIMBS 9
 #define FE_BITS 29
@@ -404,120 +405,11 @@ S2K_HD void fe_inv_fermat(fe& r, const fe& a) {
     fe_sqrn_mul(r, t, 2, a);
 }
 
-// ---- modular inverse by division steps ("safegcd", Bernstein-Yang 2019; the reference's secp256k1_modinv32, src/modinv32_impl.h,
-// behind secp256k1_fe_inv / fe_inv_var, field_5x52_impl.h:481-522) ----------------------------------------------------------
-// Fixed 20 x 30 = 600 division steps (>= the 590 that suffice for a 256-bit modulus), branch-free, so every lane of a wave
-// runs the same instructions.  Operands are 9 signed limbs of 30 bits; each batch of 30 steps works on the low words only and
-// yields a 2x2 transition matrix that is then applied to (f, g) exactly and to (d, e) modulo p.  About 17 000 32-bit
-// instructions against ~40 000 issue slots for the Fermat chain above.  Same value: a^-1 mod p, and 0 for a = 0.
-struct s30 { int32_t v[9]; };
-#define S30_M ((int32_t)0x3FFFFFFF)
-// p = 65536*2^240 - 4*2^30 - 977 in signed limbs; p^-1 mod 2^30
-#define S30_P0 (-977)
-#define S30_P1 (-4)
-#define S30_P8 (65536)
-#define S30_PINV 0x2DDACACFu
-
-S2K_HD int32_t s30_divsteps_30(int32_t zeta, u32 f0, u32 g0, int32_t t[4]) {
-    u32 u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
-#pragma unroll 5
-    for (int i = 0; i < 30; i++) {
-        u32 c1 = (u32)(zeta >> 31);                      // all ones when zeta < 0
-        const u32 c2 = 0u - (g & 1u);                    // all ones when g is odd
-        const u32 x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;     // -f, -u, -v when zeta < 0
-        g += x & c2; q += y & c2; r += z & c2;
-        c1 &= c2;                                        // swap (f, g) <- (g, g - f) only when zeta < 0 and g odd
-        zeta = (zeta ^ (int32_t)c1) - 1;
-        f += g & c1; u += q & c1; v += r & c1;
-        g >>= 1; u <<= 1; v <<= 1;
-    }
-    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
-    return zeta;
-}
-// (f, g) <- t * (f, g) / 2^30   (exact)
-S2K_HD void s30_update_fg(s30& f, s30& g, const int32_t t[4]) {
-    const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
-    int64_t cf = u * f.v[0] + v * g.v[0], cg = q * f.v[0] + r * g.v[0];
-    cf >>= 30; cg >>= 30;
-#pragma unroll
-    for (int i = 1; i < 9; i++) {
-        cf += u * f.v[i] + v * g.v[i];
-        cg += q * f.v[i] + r * g.v[i];
-        f.v[i - 1] = (int32_t)cf & S30_M; cf >>= 30;
-        g.v[i - 1] = (int32_t)cg & S30_M; cg >>= 30;
-    }
-    f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
-}
-// (d, e) <- t * (d, e) / 2^30 mod p, both kept in (-2p, p)
-S2K_HD void s30_update_de(s30& d, s30& e, const int32_t t[4]) {
-    const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
-    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
-    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);              // add p to a negative d / e before multiplying
-    int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0], ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
-    md -= (int32_t)((S30_PINV * (u32)cd + (u32)md) & (u32)S30_M);            // multiples of p that clear the low 30 bits
-    me -= (int32_t)((S30_PINV * (u32)ce + (u32)me) & (u32)S30_M);
-    cd += (int64_t)S30_P0 * md; ce += (int64_t)S30_P0 * me;
-    cd >>= 30; ce >>= 30;
-#pragma unroll
-    for (int i = 1; i < 9; i++) {
-        cd += (int64_t)u * d.v[i] + (int64_t)v * e.v[i];
-        ce += (int64_t)q * d.v[i] + (int64_t)r * e.v[i];
-        if (i == 1) { cd += (int64_t)S30_P1 * md; ce += (int64_t)S30_P1 * me; }
-        if (i == 8) { cd += (int64_t)S30_P8 * md; ce += (int64_t)S30_P8 * me; }
-        d.v[i - 1] = (int32_t)cd & S30_M; cd >>= 30;
-        e.v[i - 1] = (int32_t)ce & S30_M; ce >>= 30;
-    }
-    d.v[8] = (int32_t)cd; e.v[8] = (int32_t)ce;
-}
-// d in (-2p, p), negated when sign < 0, brought to [0, p)
-S2K_HD void s30_normalize(s30& r, int32_t sign) {
-    const int32_t pm[9] = {S30_P0, S30_P1, 0, 0, 0, 0, 0, 0, S30_P8};
-    int32_t add = r.v[8] >> 31;
-    const int32_t neg = sign >> 31;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { r.v[i] += pm[i] & add; r.v[i] = (r.v[i] ^ neg) - neg; }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { r.v[i + 1] += r.v[i] >> 30; r.v[i] &= S30_M; }
-    add = r.v[8] >> 31;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] += pm[i] & add;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { r.v[i + 1] += r.v[i] >> 30; r.v[i] &= S30_M; }
-}
-// r = a^-1 mod p (0 for a = 0).  Same value as secp256k1_fe_inv_var.  Input magnitude <= 2.
+// r = a^-1 mod p (0 for a = 0) by division steps (modinv.h).  Same value as secp256k1_fe_inv_var.  Input magnitude <= 2.
 S2K_HD void fe_inv(fe& r, const fe& a) {
     fe an = a; fe_normalize(an);
-    u32 w[8]; fe_to_words(w, an);
-    s30 f, g, d, e;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const int bit = 30 * i, idx = bit >> 5, sh = bit & 31;
-        u64 v = w[idx];
-        if (idx + 1 < 8) v |= (u64)w[idx + 1] << 32;
-        g.v[i] = (int32_t)((u32)(v >> sh) & (u32)S30_M);
-        d.v[i] = 0; e.v[i] = 0; f.v[i] = 0;
-    }
-    f.v[0] = S30_P0; f.v[1] = S30_P1; f.v[8] = S30_P8;
-    e.v[0] = 1;
-    int32_t zeta = -1;
-#pragma unroll 1
-    for (int it = 0; it < 20; it++) {
-        int32_t t[4];
-        zeta = s30_divsteps_30(zeta, (u32)f.v[0], (u32)g.v[0], t);
-        s30_update_de(d, e, t);
-        s30_update_fg(f, g, t);
-    }
-    s30_normalize(d, f.v[8]);
-    // 9 x 30 bits -> 8 x 32-bit words -> limbs
-    u32 o[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int bit = 32 * j, i = bit / 30, sh = bit % 30;
-        u64 v = (u64)(u32)d.v[i] >> sh;
-        if (i + 1 < 9) v |= (u64)(u32)d.v[i + 1] << (30 - sh);
-        if (i + 2 < 9) v |= (u64)(u32)d.v[i + 2] << (60 - sh);
-        o[j] = (u32)v;
-    }
+    u32 w[8], o[8]; fe_to_words(w, an);
+    s30_inverse_words(o, w, S30_MOD_P);
     fe_from_words(r, o);
 }
 // r = a^((p+1)/4); returns 1 iff r^2 == a, i.e. a is a square (cf. secp256k1_fe_sqrt, field_impl.h:37-146).

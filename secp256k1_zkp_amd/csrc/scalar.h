@@ -7,6 +7,7 @@
 // cycles go.  Encodings: 32-byte big-endian, identical to secp256k1_scalar_get_b32 / set_b32.
 #pragma once
 #include "s2k_common.h"
+#include "modinv.h"
 
 struct scalar { u32 d[8]; };   // d[0] least significant
 
@@ -230,15 +231,10 @@ S2K_HD void sc_to_half(half_scalar& h, const scalar& s) {
     for (int i = 0; i < 5; i++) h.w[i] = t.d[i];
 }
 
-// a^(n-2) mod n by square-and-multiply (only a few per proof; cf. secp256k1_scalar_inverse_var)
-S2K_HD_NOINLINE void sc_inverse(scalar& r, const scalar& a) {
-    scalar acc; sc_set_int(acc, 1);
-    // exponent n-2, scanned MSB first
-    for (int i = 255; i >= 0; i--) {
-        sc_sqr(acc, acc);
-        u32 limb = sc_n_limb(i >> 5);
-        if ((i >> 5) == 0) limb -= 2u;          // N0 - 2 does not borrow
-        if ((limb >> (i & 31)) & 1u) sc_mul(acc, acc, a);
-    }
-    r = acc;
+// a^-1 mod n (0 for 0) by division steps (modinv.h); cf. secp256k1_scalar_inverse_var
+S2K_HD void sc_inverse(scalar& r, const scalar& a) {
+    u32 o[8];
+    s30_inverse_words(o, a.d, S30_MOD_N);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.d[i] = o[i];
 }
