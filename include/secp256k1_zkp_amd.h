@@ -35,6 +35,15 @@ S2K_API s2k_engine* s2k_engine_create(int device);
 S2K_API void s2k_engine_destroy(s2k_engine* e);
 /* Last engine-level error of the calling thread ("" if none). */
 S2K_API const char* s2k_last_error(void);
+/* Why the most recent call on this thread returned 0.  Batch entry points return 0 only for S2K_STATUS_* != OK (verdicts
+ * go to results[]); the single-item `_amd` forms return the verdict itself, so for them 0 + S2K_STATUS_OK = "invalid" and
+ * 0 + S2K_STATUS_ENGINE_FAILURE = "no verdict: take the CPU path" (a failed engine never yields 1).
+ * The `_amd` forms reset the status on entry; batch callers may call s2k_clear_status() first. */
+#define S2K_STATUS_OK 0
+#define S2K_STATUS_ENGINE_FAILURE 1   /* no device, HIP error, out of memory */
+#define S2K_STATUS_ILLEGAL_ARGUMENT 2 /* what the reference's ARG_CHECK would have rejected */
+S2K_API int s2k_last_status(void);
+S2K_API void s2k_clear_status(void);
 /* Make sure the per-batch HBM workspace can hold `n_items` rangeproofs (optional; calls grow it on demand). */
 S2K_API int s2k_engine_reserve(s2k_engine* e, size_t n_items);
 /* Block until everything queued on the engine's stream has finished. */
@@ -127,6 +136,18 @@ S2K_API int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, u
 S2K_API int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value, uint64_t* max_value, const void* commit,
                                             const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
                                             size_t extra_commit_len, const void* gen);
+
+/* Further single-item forms with the reference's argument lists (ctx ignored; same process-global engine; see
+ * s2k_last_status() for telling "invalid" from "engine failed"):
+ *   secp256k1_schnorrsig_verify(ctx, sig64, msg, msglen, pubkey)                       include/secp256k1_schnorrsig.h:178
+ *   secp256k1_pedersen_verify_tally(ctx, commits, pcnt, ncommits, ncnt)                include/secp256k1_generator.h:190
+ *   secp256k1_surjectionproof_verify(ctx, proof, input_tags, n_input_tags, output_tag) include/secp256k1_surjectionproof.h:256
+ * Pointers to opaque objects are passed as const void* (64-byte xonly_pubkey / pedersen_commitment / generator objects,
+ * the secp256k1_surjectionproof struct). */
+S2K_API int secp256k1_schnorrsig_verify_amd(const void* ctx, const unsigned char* sig64, const unsigned char* msg, size_t msglen, const void* pubkey);
+S2K_API int secp256k1_pedersen_verify_tally_amd(const void* ctx, const void* const* commits, size_t pcnt, const void* const* ncommits, size_t ncnt);
+S2K_API int secp256k1_surjectionproof_verify_amd(const void* ctx, const void* proof, const void* ephemeral_input_tags, size_t n_ephemeral_input_tags,
+                                                 const void* ephemeral_output_tag);
 
 /* ---- Pedersen commitment tallies ------------------------------------------------------------------------------------
  * results[t] = secp256k1_pedersen_verify_tally(ctx, pos_t, pcnt_t, neg_t, ncnt_t)

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsecp256k1_zkp_amd.so")
+LIB_PATH = os.environ.get("S2K_LIB") or os.path.join(_HERE, "libsecp256k1_zkp_amd.so")     # S2K_LIB: diagnostic builds (tools/prof_regions.py)
 
 _c = ctypes
 _vp, _sz, _i32p = _c.c_void_p, _c.c_size_t, _c.c_void_p
@@ -18,6 +18,8 @@ SIGNATURES = {
     "s2k_engine_create": (_vp, [_c.c_int]),
     "s2k_engine_destroy": (None, [_vp]),
     "s2k_last_error": (_c.c_char_p, []),
+    "s2k_last_status": (_c.c_int, []),
+    "s2k_clear_status": (None, []),
     "s2k_engine_reserve": (_c.c_int, [_vp, _sz]),
     "s2k_engine_sync": (_c.c_int, [_vp]),
     "s2k_engine_gtable": (_vp, [_vp, _c.POINTER(_sz)]),
@@ -37,6 +39,9 @@ SIGNATURES = {
     "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_rewind_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "secp256k1_schnorrsig_verify_amd": (_c.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "secp256k1_pedersen_verify_tally_amd": (_c.c_int, [_vp, _vp, _sz, _vp, _sz]),
+    "secp256k1_surjectionproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "secp256k1_surjectionproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
     "secp256k1_surjectionproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "secp256k1_bppp_norm_product_verify_batch": (_c.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),

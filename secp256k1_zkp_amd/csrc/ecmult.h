@@ -13,7 +13,7 @@
 //                    per-lane 1152-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
 //                    addition ahead so the ~1-2 us of latency hides under the previous ~4 us of arithmetic.
 //   generator:       no doublings at all: ng is cut into 13 windows of 20 bits (S2K_GTAB_BITS), each indexing a precomputed
-//                    (window, value) -> affine multiple table (gtable.h, 981 MB in HBM), 13 mixed additions.
+//                    (window, value) -> affine multiple table (gtable.h, 872 MB in HBM), 13 mixed additions.
 //   digits:          both digit streams live in LDS (lane_mem), not in registers.
 //   control:         one loop whose body contains exactly ONE doubling site and ONE mixed-add site, driven by a
 //                    per-lane micro-program counter.  The only data-dependent *arithmetic* case (P + P inside an add)
@@ -26,19 +26,23 @@
 #include "scalar.h"
 
 // ---- generator table ---------------------------------------------------------------------------------
-// gtab[((w << B) + v) * 18 .. +18) = affine (x limbs[9], y limbs[9]) of  v * 2^(B w) * G ,  v = 1..2^B-1, w = 0..W-1, with
-// B = S2K_GTAB_BITS and W = ceil(256 / B).  B = 20: 13 windows, 981 MB of the 288 GB (the host emulation builds B = 12).
+// gtab[((w << B) + v) * 16 .. +16) = affine (x words[8], y words[8], canonical, least significant word first) of
+// v * 2^(B w) * G ,  v = 1..2^B-1, w = 0..W-1, with B = S2K_GTAB_BITS and W = ceil(256 / B).  One entry = one aligned 64-byte
+// sector, the same record format as the per-lane table below, so that the main loop has a single operand pipeline.
+// B = 20: 13 windows, 872 MB of the 288 GB (the host emulation builds B = 12).
 #ifndef S2K_GTAB_BITS
 #define S2K_GTAB_BITS 20
 #endif
 #define S2K_GTAB_WINDOWS ((256 + S2K_GTAB_BITS - 1) / S2K_GTAB_BITS)
-#define S2K_GTAB_ENTRY_WORDS 18
+#define S2K_GTAB_ENTRY_WORDS 16
 #define S2K_GTAB_WORDS (((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) * S2K_GTAB_ENTRY_WORDS)
 
 S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
     const u32* p = gtab + ((size_t)(window << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
+    u32 w[16];
 #pragma unroll
-    for (int i = 0; i < 9; i++) { r.x.n[i] = p[i]; r.y.n[i] = p[9 + i]; }
+    for (int i = 0; i < 16; i++) w[i] = p[i];
+    fe_from_words(r.x, w); fe_from_words(r.y, w + 8);
 }
 
 // ---- per-lane table of odd multiples ----------------------------------------------------------------------
@@ -96,20 +100,6 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
         fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
     }
 }
-// operand for digit value v (4 bits: d = 2v - 15) of half `half`; sign_flip = the half's own sign.  Magnitudes (1, <=2).
-S2K_HD void ptab_fetch(ge& o, const u32* ptab, u32 v, int half, int sign_flip) {
-    const int neg = (v < 8u) ^ sign_flip;
-    const u32 idx = (v < 8u) ? (7u - v) : (v - 8u);
-    const u32* e = ptab + idx * S2K_PTAB_ENTRY_WORDS + (half ? 16 : 0);
-    u32 w[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = e[k];
-    fe y;
-    fe_from_words(o.x, w); fe_from_words(y, w + 8);
-    fe yn; fe_neg(yn, y, 1);
-    fe_select(o.y, yn, y, neg);
-}
-
 // ---- wave-level predicates ------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 #define S2K_WAVE_ANY(p) (__any(p))
@@ -162,6 +152,7 @@ S2K_HD u32 digit_reg_pop(digit_reg& r) {
 // R is returned on the real curve, magnitudes (<=5,<=3,1).
 S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng, int has_ng, const u32* gtab, const lane_mem& lm) {
     u32* const ptab = lm.ptab; const s2k_lds_ptr dig = lm.dig;
+    S2K_PROF_DECL;
     const int p_active = (!A.inf) & (!sc_is_zero(na));
     const int g_active = has_ng & (!sc_is_zero(ng));
     int hneg0, hneg1, skew0, skew1;
@@ -188,6 +179,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
 #pragma unroll
             for (int i = 0; i < 9; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
         }
+        S2K_PROF_MARK(1);
         if (S2K_WAVE_ANY(p_active)) {
             ptab_build(ziso, ptab, A);
 #pragma unroll
@@ -197,41 +189,59 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
 #pragma unroll
     for (int i = 0; i < 8; i++) dig[(9 + i) * S2K_DIG_STRIDE] = ng.d[i];
 
+    S2K_PROF_MARK(2);
     // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
     int a = p_active ? 0 : S2K_ADD_G0;
     int zfixed = !p_active;
     int dbl_left = 0, pending = 0;
     const int a_end = g_active ? S2K_ADDS_TOTAL : S2K_ADD_G0;
-    ge cur, nxt; int cur_valid = 0, nxt_valid = 0;
-    fe_set_zero(cur.x); fe_set_zero(cur.y); fe_set_zero(nxt.x); fe_set_zero(nxt.y);
-    // operand of addition `idx` (called once per idx, in increasing order: the digit registers are consumed as we go)
-#define S2K_FETCH(dst, dst_valid, idx)                                                                              \
-    do {                                                                                                            \
-        const int _i = (idx);                                                                                       \
-        dst_valid = 0;                                                                                              \
-        if (_i < S2K_ADD_G0) {                                                                                      \
-            const int _h = _i & 1;                                                                                  \
-            const int _hn = _h ? hneg1 : hneg0;                                                                     \
-            u32 _v = 8u; int _flip = _hn; dst_valid = 1;                       /* top digit (a = 0, 1) is always +1 */ \
-            if (_i >= 2 && _i < S2K_ADDS_P) _v = (dig[(_i >> 3) * S2K_DIG_STRIDE] >> ((_i & 7) * 4)) & 15u;          \
-            if (_i >= S2K_ADDS_P) { _flip = !_hn; dst_valid = _h ? skew1 : skew0; }      /* skew correction: -(+-P) */ \
-            ptab_fetch(dst, ptab, _v, _h, _flip);                                                                   \
-        }                                                                                                           \
-        else if (_i < S2K_ADDS_TOTAL) {                                                                             \
-            const int _g = _i - S2K_ADD_G0;                                                                         \
-            const int _b = _g * S2K_GTAB_BITS, _w = _b >> 5;                                                        \
-            const u64 _pair = (u64)dig[(9 + _w) * S2K_DIG_STRIDE] | ((u64)(_w + 1 < 8 ? dig[(10 + _w) * S2K_DIG_STRIDE] : 0u) << 32); \
-            const u32 _v = (u32)(_pair >> (_b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);                                 \
-            if (_v) { gtab_load(dst, gtab, (u32)_g, _v); dst_valid = 1; }                                           \
-        }                                                                                                           \
-    } while (0)
-    if (a < a_end) S2K_FETCH(cur, cur_valid, a);
+    // Operand pipeline.  Every operand -- an odd multiple from this lane's table or a generator-table entry -- is one aligned
+    // 64-byte record of canonical words (x, y).  `op_locate` turns an addition index into (record address, use it?, negate y?);
+    // the record of addition a+1 is *requested* (16 words into `raw`, no use of the data) before the arithmetic of addition a
+    // and *decoded* into limbs after it, so the gather's latency lies under ~1800 instructions instead of in front of them.
+    // A lane that does not advance in a trip simply requests the same record again: no per-lane select ever waits on the data.
+    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
+        addr = ptab; valid = 0; neg = 0;
+        if (idx < S2K_ADD_G0) {
+            const int h = idx & 1;
+            const int hn = h ? hneg1 : hneg0;
+            u32 v = 8u; int flip = hn; valid = 1;                                                   // top digit (a = 0, 1) is always +1
+            if (idx >= 2 && idx < S2K_ADDS_P) v = (dig[(idx >> 3) * S2K_DIG_STRIDE] >> ((idx & 7) * 4)) & 15u;
+            if (idx >= S2K_ADDS_P) { flip = !hn; valid = h ? skew1 : skew0; }                       // skew correction: -(+-P)
+            neg = (v < 8u) ^ flip;
+            const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
+            addr = ptab + e * S2K_PTAB_ENTRY_WORDS + (h ? 16 : 0);
+        } else if (idx < a_end) {
+            const int g = idx - S2K_ADD_G0;
+            const int b = g * S2K_GTAB_BITS, w = b >> 5;
+            const u64 pair = (u64)dig[(9 + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(10 + w) * S2K_DIG_STRIDE] : 0u) << 32);
+            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+            if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+        }
+    };
+    auto op_decode = [&](ge& o, const u32 raw[16], int neg) {
+        fe y, yn;
+        fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
+        fe_neg(yn, y, 1);
+        fe_select(o.y, yn, y, neg);
+    };
+    const u32* nxt_addr; int nxt_valid, nxt_neg;
+    u32 raw[16];
+    ge cur; int cur_valid;
+    op_locate(nxt_addr, nxt_valid, nxt_neg, a);
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+    op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
     gej_set_infinity(R);
     if (p_active) {                                 // addition 0 would add the top digit of half 0 to infinity: just take it
         gej_set_ge(R, cur);
         a = 1;
-        S2K_FETCH(cur, cur_valid, a);
+        op_locate(nxt_addr, nxt_valid, nxt_neg, a);
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
     }
+    op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
     int done = !(a < a_end);
     while (S2K_WAVE_ANY(!done)) {
         int do_dbl = 0, do_add = 0;
@@ -245,13 +255,16 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             if (do_dbl) R = t;
         }
         if (S2K_WAVE_ANY(do_add)) {
-            if (do_add && a + 1 < a_end) S2K_FETCH(nxt, nxt_valid, a + 1);      // issue the next gather before the arithmetic
+#pragma unroll
+            for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
             gej t; const int f = gej_add_ge(t, R, cur);
+            ge nx; op_decode(nx, raw, nxt_neg);
             if (do_add) {
                 if (cur_valid) { R = t; pending = (f == GEJ_ADD_NEEDS_DOUBLE); }
                 a++;
-                cur = nxt; cur_valid = nxt_valid;
+                cur = nx; cur_valid = nxt_valid;
                 dbl_left = (a >= 2 && a < S2K_ADDS_P && !(a & 1)) ? 4 : 0;
+                op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
             }
         }
         // leaving the isomorphic curve: after the skew corrections, before the generator additions
@@ -265,5 +278,5 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         }
         if ((a >= a_end) & (!pending) & zfixed) done = 1;
     }
-#undef S2K_FETCH
+    S2K_PROF_MARK(3);
 }

@@ -29,14 +29,23 @@
 // error plumbing
 // ------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+static thread_local int g_last_status = 0;            // S2K_STATUS_* of the most recent failing call on this thread
 static int s2k_fail(const char* what, const char* detail) {
     g_last_error = std::string(what) + ": " + (detail ? detail : "");
+    g_last_status = S2K_STATUS_ENGINE_FAILURE;
+    return 0;
+}
+static int s2k_fail_arg(const char* what, const char* detail) {
+    g_last_error = std::string(what) + ": " + (detail ? detail : "");
+    g_last_status = S2K_STATUS_ILLEGAL_ARGUMENT;
     return 0;
 }
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return s2k_fail(#call, hipGetErrorString(_e)); } while (0)
 #define HIPCHK_NULL(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); return nullptr; } } while (0)
 
 extern "C" const char* s2k_last_error(void) { return g_last_error.c_str(); }
+extern "C" int s2k_last_status(void) { return g_last_status; }
+extern "C" void s2k_clear_status(void) { g_last_status = S2K_STATUS_OK; g_last_error.clear(); }
 
 // ------------------------------------------------------------------------------------------------------------
 // engine object
@@ -190,7 +199,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
 extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
-    if (e->stream) hipStreamSynchronize(e->stream);
+    hipDeviceSynchronize();            // `_dev` calls may have been issued on caller streams: nothing of this engine may still be in flight
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
     if (e->gtab) hipFree(e->gtab);
@@ -214,6 +223,14 @@ extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
     return e ? e->gtab : nullptr;
 }
 extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) { return e ? e->msm_fallback : 0; }
+#ifdef S2K_PROF
+// diagnostic builds only: read (and clear) the per-region cycle table of s2k_common.h
+extern "C" __attribute__((visibility("default"))) int s2k_prof_read(unsigned long long out[16]) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(s2k_prof_slots), 16 * sizeof(unsigned long long)) != hipSuccess) return 0;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2k_prof_slots), z, sizeof(z)) == hipSuccess;
+}
+#endif
 extern "C" float s2k_engine_last_ms(s2k_engine* e, int which) {
     float ms = -1.0f;
     if (!e) return ms;
@@ -418,6 +435,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
                      const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr) {
     if (!engine_ptab(e, ((std::min(n, RP_CHUNK) * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
+    HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
     // the scratch records `w` hold one chunk; chunks run back to back on the stream and reuse them
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
@@ -467,6 +485,7 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
                                                  const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
     if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch", "null engine");
     if (n == 0) return 1;
+    memset(results, 0, sizeof(int32_t) * n);
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
@@ -500,7 +519,7 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     if (!e) return s2k_fail("secp256k1_rangeproof_rewind_batch", "null engine");
     if (n == 0) return 1;
     if (!results || !blind_out || !value_out || !nonces || !min_value || !max_value || !commits33 || !proofs || !proof_off || !gens64 || (message_out && !outlen))
-        return s2k_fail("secp256k1_rangeproof_rewind_batch", "illegal argument (ARG_CHECK)");
+        return s2k_fail_arg("secp256k1_rangeproof_rewind_batch", "illegal argument (ARG_CHECK)");
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
@@ -537,25 +556,83 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }
-// single-item form with the reference's argument list (include/secp256k1_rangeproof.h:70-80)
+// single-item forms with the reference's argument lists.  A 0 from these means "invalid" only while s2k_last_status() is
+// S2K_STATUS_OK; an engine-level failure also returns 0 (never 1) and leaves S2K_STATUS_ENGINE_FAILURE for the caller's
+// CPU fallback (integration/secp256k1_amd_hook.c does exactly that).
 static s2k_engine* g_default_engine = nullptr;
 static std::mutex g_default_mu;
+static s2k_engine* default_engine() {
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    if (!g_default_engine) {
+        const char* d = getenv("S2K_DEVICE");
+        g_default_engine = s2k_engine_create(d ? atoi(d) : 0);
+    }
+    return g_default_engine;
+}
+// include/secp256k1_rangeproof.h:70-80
 extern "C" int secp256k1_rangeproof_verify_amd(const void* ctx, uint64_t* min_value, uint64_t* max_value, const void* commit,
                                                const unsigned char* proof, size_t plen, const unsigned char* extra_commit,
                                                size_t extra_commit_len, const void* gen) {
     (void)ctx;
-    if (!min_value || !max_value || !commit || !proof || !gen || (!extra_commit && extra_commit_len)) return s2k_fail("secp256k1_rangeproof_verify_amd", "illegal argument (ARG_CHECK)");
-    {
-        std::lock_guard<std::mutex> lock(g_default_mu);
-        if (!g_default_engine) {
-            const char* d = getenv("S2K_DEVICE");
-            g_default_engine = s2k_engine_create(d ? atoi(d) : 0);
-            if (!g_default_engine) return 0;
-        }
-    }
+    s2k_clear_status();
+    if (!min_value || !max_value || !commit || !proof || !gen || (!extra_commit && extra_commit_len)) return s2k_fail_arg("secp256k1_rangeproof_verify_amd", "illegal argument (ARG_CHECK)");
+    s2k_engine* e = default_engine();
+    if (!e) return 0;
     int32_t res = 0; uint64_t off[2] = {0, plen}, eoff[2] = {0, extra_commit_len};
-    if (!secp256k1_rangeproof_verify_batch(g_default_engine, &res, min_value, max_value, (const unsigned char*)commit, proof, off,
+    if (!secp256k1_rangeproof_verify_batch(e, &res, min_value, max_value, (const unsigned char*)commit, proof, off,
                                            extra_commit_len ? extra_commit : nullptr, extra_commit_len ? eoff : nullptr, (const unsigned char*)gen, 1)) return 0;
+    return res;
+}
+// include/secp256k1_schnorrsig.h:178 -- pubkey points at the 64-byte secp256k1_xonly_pubkey object
+extern "C" int secp256k1_schnorrsig_verify_amd(const void* ctx, const unsigned char* sig64, const unsigned char* msg, size_t msglen, const void* pubkey) {
+    (void)ctx;
+    s2k_clear_status();
+    if (!sig64 || (!msg && msglen) || !pubkey) return s2k_fail_arg("secp256k1_schnorrsig_verify_amd", "illegal argument (ARG_CHECK)");
+    s2k_engine* e = default_engine();
+    if (!e) return 0;
+    int32_t res = 0; const unsigned char dummy = 0;
+    if (!secp256k1_schnorrsig_verify_batch(e, &res, sig64, msglen ? msg : &dummy, msglen, (const unsigned char*)pubkey, 1, 1)) return 0;
+    return res;
+}
+// include/secp256k1_generator.h:190 -- arrays of pointers to 64-byte secp256k1_pedersen_commitment objects
+extern "C" int secp256k1_pedersen_verify_tally_amd(const void* ctx, const void* const* commits, size_t pcnt, const void* const* ncommits, size_t ncnt) {
+    (void)ctx;
+    s2k_clear_status();
+    if ((!commits && pcnt) || (!ncommits && ncnt)) return s2k_fail_arg("secp256k1_pedersen_verify_tally_amd", "illegal argument (ARG_CHECK)");
+    s2k_engine* e = default_engine();
+    if (!e) return 0;
+    std::vector<unsigned char> c33(33 * (pcnt + ncnt) + 1);
+    for (size_t i = 0; i < pcnt; i++) memcpy(&c33[33 * i], commits[i], 33);
+    for (size_t i = 0; i < ncnt; i++) memcpy(&c33[33 * (pcnt + i)], ncommits[i], 33);
+    const uint64_t off[2] = {0, pcnt + ncnt}, npos[1] = {pcnt};
+    int32_t res = 0;
+    if (!secp256k1_pedersen_verify_tally_batch(e, &res, c33.data(), off, npos, 1)) return 0;
+    return res;
+}
+// include/secp256k1_surjectionproof.h:256 -- proof points at a secp256k1_surjectionproof object (:50-62 of that header:
+// size_t n_inputs; unsigned char used_inputs[256/8]; unsigned char data[32*(1+256)]), tags at arrays of 64-byte generators.
+// The object is re-serialised (secp256k1_surjectionproof_serialize, main_impl.h:84-106) and takes the batch path, so an
+// object that secp256k1_surjectionproof_parse could not have produced verifies as 0.
+extern "C" int secp256k1_surjectionproof_verify_amd(const void* ctx, const void* proof, const void* ephemeral_input_tags, size_t n_ephemeral_input_tags,
+                                                    const void* ephemeral_output_tag) {
+    (void)ctx;
+    s2k_clear_status();
+    if (!proof || !ephemeral_input_tags || !ephemeral_output_tag) return s2k_fail_arg("secp256k1_surjectionproof_verify_amd", "illegal argument (ARG_CHECK)");
+    s2k_engine* e = default_engine();
+    if (!e) return 0;
+    struct sj_obj { size_t n_inputs; unsigned char used[32]; unsigned char data[32 * 257]; };
+    const sj_obj* o = (const sj_obj*)proof;
+    if (o->n_inputs > 256) return 0;
+    const size_t bm = (o->n_inputs + 7) / 8;
+    size_t used = 0;
+    for (size_t i = 0; i < bm; i++) used += (size_t)__builtin_popcount(o->used[i]);
+    std::vector<unsigned char> ser(2 + bm + 32 * (1 + used));
+    ser[0] = (unsigned char)(o->n_inputs & 0xFF); ser[1] = (unsigned char)(o->n_inputs >> 8);
+    memcpy(&ser[2], o->used, bm);
+    memcpy(&ser[2 + bm], o->data, 32 * (1 + used));
+    const uint64_t poff[2] = {0, ser.size()}, toff[2] = {0, n_ephemeral_input_tags};
+    int32_t res = 0;
+    if (!secp256k1_surjectionproof_verify_batch(e, &res, ser.data(), poff, (const unsigned char*)ephemeral_input_tags, toff, (const unsigned char*)ephemeral_output_tag, 1)) return 0;
     return res;
 }
 
@@ -581,6 +658,7 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
+    HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
     for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {
         const size_t m = std::min(n - i0, e->max_lanes);
@@ -594,6 +672,7 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
 extern "C" int secp256k1_schnorrsig_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* sigs, const unsigned char* msgs,
                                                  size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n) {
     if (!e) return s2k_fail("secp256k1_schnorrsig_verify_batch", "null engine");
+    if (results && n) memset(results, 0, sizeof(int32_t) * n);
     if (n == 0) return 1;
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
@@ -873,14 +952,19 @@ static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const
 // core: leaves the Jacobian result (28 words) at *result28 (device).  Workspace must already be large enough.
 // Stream-ordered, but not asynchronous: the host waits for the binning pass to learn the largest bucket (which fixes the number
 // of partial-sum rounds) and whether a bucket region overflowed.
+__global__ void k_set_word(u32* p, u32 v) { *p = v; }
 static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
                       const unsigned char* pt, const unsigned char* pt_inf, size_t n) {
     const size_t nt = n + (g_sc ? 1 : 0);
+    // term references are packed as (u32)(term << 2 | half << 1 | sign) and the exact-sort fallback keeps u32 prefix sums
+    // over 2 * windows digits per term: refuse what those cannot index instead of wrapping silently
+    if (nt >= (size_t(1) << 30) || nt * 2 * msm_make_plan(nt).windows >= (size_t(1) << 32))
+        return s2k_fail("s2k_ecmult_multi", "too many terms for 32-bit bucket references (2 * windows * n >= 2^32): split the sum, partial sums add");
     u32* final28 = c.take<u32>(28);
     *result28 = final28;
     if (nt < MSM_SMALL_N) {
         u32* lanes = c.take<u32>((nt + 1) * 28); u32* bufA = c.take<u32>(64 * 28); u32* bufB = c.take<u32>(64 * 28);
-        if (nt == 0) { HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st)); const u32 one = 1; HIPCHK(hipMemcpyAsync(final28 + 27, &one, 4, hipMemcpyHostToDevice, st)); return 1; }
+        if (nt == 0) { HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st)); hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, final28 + 27, 1u); HIPCHK(hipGetLastError()); return 1; }
         HIPCHK(hipEventRecord(e->ev[2], st));
         if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
         hipLaunchKernelGGL(k_msm_small, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, lanes, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt);
@@ -993,7 +1077,7 @@ extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy,
 extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
                                 const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
     if (!e) return s2k_fail("s2k_ecmult_multi", "null engine");
-    if (!r_xy || !r_inf || (n && (!sc || !pt_xy))) return s2k_fail("s2k_ecmult_multi", "illegal argument (ARG_CHECK)");
+    if (!r_xy || !r_inf || (n && (!sc || !pt_xy))) return s2k_fail_arg("s2k_ecmult_multi", "illegal argument (ARG_CHECK)");
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t nt = n + (g_sc ? 1 : 0);
@@ -1090,6 +1174,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
                                                         const unsigned char* commits33, size_t n) {
     if (!e) return s2k_fail("secp256k1_bppp_norm_product_verify_batch", "null engine");
     if (n == 0) return 1;
+    memset(results, 0, sizeof(int32_t) * n);
     bp_shape sh;
     if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { for (size_t i = 0; i < n; i++) results[i] = 0; return 1; }   // :446-461
     std::lock_guard<std::recursive_mutex> lock(e->mu);
@@ -1124,8 +1209,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     HIPCHK(hipMemcpyAsync(d_g33, gens33, 33 * n_gens, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_cv, c_vec, 32 * c_vec_len * n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_cm, commits33, 33 * n, hipMemcpyHostToDevice, st));
-    const int one = 1;
-    HIPCHK(hipMemcpyAsync(gens_ok, &one, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
     // fixed-base table of this generator set: built on first use, kept for the following calls (a deployment has one set).
@@ -1141,6 +1225,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
             hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
             hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));             // the key is only remembered for a table whose build is known to have completed
             e->bp_key.assign(gens33, gens33 + 33 * n_gens);
         }
     }
@@ -1187,6 +1272,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* s
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
+    HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
     for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {     // offsets are absolute, so a sub-range only shifts the per-item arrays
         const size_t m = std::min(n - i0, e->max_lanes);
@@ -1200,6 +1286,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* s
 extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off,
                                                       const unsigned char* input_tags64, const uint64_t* tag_off, const unsigned char* output_tags64, size_t n) {
     if (!e) return s2k_fail("secp256k1_surjectionproof_verify_batch", "null engine");
+    if (results && n) memset(results, 0, sizeof(int32_t) * n);
     if (n == 0) return 1;
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
@@ -1273,7 +1360,7 @@ __global__ void k_ha_final(int32_t* result, const u32* flags, const u32* res28) 
 extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32,
                                                   size_t n, const unsigned char* aggsig, size_t aggsig_len) {
     if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "null engine");
-    if (!result || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "illegal argument (ARG_CHECK)");
+    if (!result || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail_arg("secp256k1_schnorrsig_aggverify_amd", "illegal argument (ARG_CHECK)");
     *result = 0;
     if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 1;          // main_impl.h:122-125
     std::lock_guard<std::recursive_mutex> lock(e->mu);
@@ -1340,12 +1427,13 @@ extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* res
                                                      const uint64_t* n_pos, size_t n_tallies) {
     if (!e) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "null engine");
     if (n_tallies == 0) return 1;
-    if (!results || !tally_off || !n_pos) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
+    if (!results || !tally_off || !n_pos) return s2k_fail_arg("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
+    memset(results, 0, sizeof(int32_t) * n_tallies);
     const size_t total = (size_t)tally_off[n_tallies];
     if (total >= ((size_t)1 << 32)) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "more than 2^32 commitments in one call");
     for (size_t t = 0; t < n_tallies; t++)
         if (tally_off[t + 1] < tally_off[t] || n_pos[t] > tally_off[t + 1] - tally_off[t]) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "malformed tally offsets");
-    if (total && !commits33) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
+    if (total && !commits33) return s2k_fail_arg("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
     // the offset arrays of every partial-sum round are known from the sizes alone: built here, uploaded once
     const u32 T = 8;
     std::vector<std::vector<u32>> offs;

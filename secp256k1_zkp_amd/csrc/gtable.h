@@ -2,9 +2,9 @@
 //
 // Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
 // src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine with
-// 288 GB of HBM that would rather gather 72 bytes than execute doublings: entry (w, v) = v * 2^(B w) * G for every B-bit
-// value of every window of a scalar (B = S2K_GTAB_BITS = 20: 13 windows), in the engine's own 9x29 limb format (18 words,
-// affine), so ng*G is 13 mixed additions and zero doublings.  13 x 2^20 entries x 72 B = 981 MB; the gathers are issued one
+// 288 GB of HBM that would rather gather 64 bytes than execute doublings: entry (w, v) = v * 2^(B w) * G for every B-bit
+// value of every window of a scalar (B = S2K_GTAB_BITS = 20: 13 windows), as one aligned 64-byte sector of canonical words
+// (affine x, y), so ng*G is 13 mixed additions and zero doublings.  13 x 2^20 entries x 64 B = 872 MB; the gathers are issued one
 // addition ahead, so their HBM latency is covered.  The table is *computed on the device* when an engine is created (two
 // kernels, ~30 ms), never shipped as data.
 #pragma once
@@ -18,7 +18,9 @@ S2K_HD void ge_set_generator(ge& g) {
 }
 S2K_HD void gtab_store(u32* gtab, u32 w, u32 v, const ge& a) {
     u32* p = gtab + ((size_t)(w << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
-    for (int i = 0; i < 9; i++) { p[i] = a.x.n[i]; p[9 + i] = a.y.n[i]; }
+    u32 wx[8], wy[8];
+    fe_to_words(wx, a.x); fe_to_words(wy, a.y);                     // `a` is normalised (ge_set_gej)
+    for (int i = 0; i < 8; i++) { p[i] = wx[i]; p[8 + i] = wy[i]; }
 }
 // step 1 (one thread per window w): base[w] = 2^(B w) * G, affine, stored as entry (w, 1).
 S2K_HD void gtab_build_base(u32* gtab, u32 w) {

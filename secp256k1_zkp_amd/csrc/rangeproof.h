@@ -320,6 +320,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
     // Nothing but flags and pointers stays live across ecmult_lane: the ring key is re-read from its scratch record and the
     // next key (key + base, pub_expand :43-45) is written back there before the multiplication starts.
     u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
+    S2K_PROF_DECL;
 #pragma unroll 1
     for (u32 j = 0; j < 4; j++) {
         const int step_live = ok & (j < rsize);
@@ -337,9 +338,12 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
             if (live) gej_store28_h(pub28, nxt);
         }
         gej R;
+        S2K_PROF_MARK(0);
         ecmult_lane(R, pub, ens, s, 1, gtab, lm);
+        S2K_PROF_RESET;
         good &= !R.inf;
         ge a; ge_set_gej(a, R);
+        S2K_PROF_MARK(4);
         u32 xw[8]; fe_to_words(xw, a.x);
         u32 xb[8];
 #pragma unroll
@@ -356,6 +360,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
             for (int i = 0; i < 8; i++) outx[i] = xb[i];
             outp = prefix;
         }
+        S2K_PROF_MARK(5);
     }
     if (live) {
         ring_out33[0] = (unsigned char)outp;

@@ -46,6 +46,23 @@
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// S2K_PROF (diagnostic builds only, -DS2K_PROF): per-region shader-clock attribution.  S2K_PROF_MARK(i) adds the cycles since
+// the previous mark of this wave to slot i of a device-global table (one atomic per wave); tools/prof_regions.py reads it.
+#if defined(S2K_PROF) && (defined(__HIPCC__) || defined(__HIP__))
+__device__ unsigned long long s2k_prof_slots[16];
+#endif
+#if defined(S2K_PROF) && defined(__HIP_DEVICE_COMPILE__)
+struct s2k_prof_clock { unsigned long long t; };
+#define S2K_PROF_DECL s2k_prof_clock _pc; _pc.t = __builtin_readcyclecounter()
+#define S2K_PROF_RESET _pc.t = __builtin_readcyclecounter()
+#define S2K_PROF_MARK(i) do { const unsigned long long _n = __builtin_readcyclecounter(); \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s2k_prof_slots[i], _n - _pc.t); _pc.t = __builtin_readcyclecounter(); } while (0)
+#else
+#define S2K_PROF_DECL
+#define S2K_PROF_RESET
+#define S2K_PROF_MARK(i) do { } while (0)
+#endif
+
 S2K_HD u32 s2k_load_be32(const unsigned char* p) {
     return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
 }
