@@ -1,0 +1,280 @@
+/* secp256k1_amd_hook.c -- reference-side adapters between secp256k1-zkp's own types and the engine's C ABI.
+ *
+ * Meant to be #included at the end of the library's translation unit (the way src/secp256k1.c includes each module's
+ * main_impl.h), because -- like the modules -- it uses the library's internal types: secp256k1_scalar, secp256k1_ge,
+ * secp256k1_gej, secp256k1_callback, the static secp256k1_ecmult_multi_var (reference src/ecmult.h:49,62) and
+ * checked_malloc (src/util.h:162-168).  See secp256k1_amd_hook.h for the rules.  Test tier only (oracle/Makefile `hooked`).
+ */
+#include "secp256k1_amd_hook.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static secp256k1_amd_backend secp256k1_amd_be;              /* all-NULL: CPU library */
+static size_t secp256k1_amd_served = 0, secp256k1_amd_fell_back = 0;
+static size_t secp256k1_amd_msm_min_terms = 0;              /* MSMs shorter than this stay on the CPU (one GPU round trip ~ 1 ms) */
+
+void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend) {
+    if (backend == NULL) memset(&secp256k1_amd_be, 0, sizeof(secp256k1_amd_be));
+    else secp256k1_amd_be = *backend;
+}
+void secp256k1_amd_stats(size_t *served, size_t *fell_back) {
+    if (served != NULL) *served = secp256k1_amd_served;
+    if (fell_back != NULL) *fell_back = secp256k1_amd_fell_back;
+}
+void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n; }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Batch form of secp256k1_rangeproof_verify (reference include/secp256k1_rangeproof.h:70-80).
+ * results[i], min_value[i], max_value[i] are what the single call returns / writes for item i.  Returns 1 when the batch
+ * was processed (on the engine or on the CPU), 0 only for illegal arguments.
+ * --------------------------------------------------------------------------------------------------------------- */
+int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *results, uint64_t *min_value, uint64_t *max_value,
+        const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
+        const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
+    size_t i;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(min_value != NULL);
+    ARG_CHECK(max_value != NULL);
+    ARG_CHECK(commits != NULL);
+    ARG_CHECK(proofs != NULL);
+    ARG_CHECK(plens != NULL);
+    ARG_CHECK(gens != NULL);
+    ARG_CHECK(extra_commits == NULL || extra_commit_lens != NULL);
+    for (i = 0; i < n; i++) {
+        ARG_CHECK(commits[i] != NULL);
+        ARG_CHECK(proofs[i] != NULL);
+        ARG_CHECK(gens[i] != NULL);
+        ARG_CHECK(extra_commits == NULL || extra_commits[i] != NULL || extra_commit_lens[i] == 0);
+    }
+    if (n == 0) return 1;
+    if (secp256k1_amd_be.rangeproof_verify_batch != NULL) {
+        size_t pbytes = 0, ebytes = 0, po = 0, eo = 0;
+        unsigned char *c33, *pbuf, *ebuf, *g64;
+        uint64_t *poff, *eoff;
+        int32_t *res32;
+        int ok;
+        for (i = 0; i < n; i++) { pbytes += plens[i]; if (extra_commits != NULL) ebytes += extra_commit_lens[i]; }
+        c33 = (unsigned char*)checked_malloc(&ctx->error_callback, 33 * n);
+        g64 = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * n);
+        pbuf = (unsigned char*)checked_malloc(&ctx->error_callback, pbytes + 1);
+        ebuf = (unsigned char*)checked_malloc(&ctx->error_callback, ebytes + 1);
+        poff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        eoff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n);
+        ok = c33 != NULL && g64 != NULL && pbuf != NULL && ebuf != NULL && poff != NULL && eoff != NULL && res32 != NULL;
+        if (ok) {
+            for (i = 0; i < n; i++) {
+                /* the first 33 bytes of the 64-byte commitment object are its serialisation (generator/main_impl.h:266-279),
+                 * the generator object is 64 bytes x||y (generator/main_impl.h:40-56) */
+                memcpy(c33 + 33 * i, commits[i]->data, 33);
+                memcpy(g64 + 64 * i, gens[i]->data, 64);
+                poff[i] = po; memcpy(pbuf + po, proofs[i], plens[i]); po += plens[i];
+                eoff[i] = eo;
+                if (extra_commits != NULL && extra_commit_lens[i] != 0) { memcpy(ebuf + eo, extra_commits[i], extra_commit_lens[i]); eo += extra_commit_lens[i]; }
+                res32[i] = 0;
+            }
+            poff[n] = po; eoff[n] = eo;
+            ok = secp256k1_amd_be.rangeproof_verify_batch(secp256k1_amd_be.engine, res32, min_value, max_value, c33, pbuf, poff,
+                                                          extra_commits != NULL ? ebuf : NULL, extra_commits != NULL ? eoff : NULL, g64, n);
+            if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
+        }
+        free(c33); free(g64); free(pbuf); free(ebuf); free(poff); free(eoff); free(res32);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;              /* engine-level failure: the whole batch takes the library's own path */
+    }
+    for (i = 0; i < n; i++) {
+        results[i] = secp256k1_rangeproof_verify(ctx, &min_value[i], &max_value[i], commits[i], proofs[i], plens[i],
+                                                 extra_commits != NULL ? extra_commits[i] : NULL, extra_commits != NULL ? extra_commit_lens[i] : 0, gens[i]);
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The MSM seam: same signature and contract as the static secp256k1_ecmult_multi_var (reference src/ecmult.h:62,
+ * ecmult_impl.h:823-867): R = inp_g_sc*G + sum sc_i*pt_i; inp_g_sc may be NULL; a callback that returns 0 makes the call
+ * return 0; the result may be infinity.  The pull-callback (src/ecmult.h:49) is drained into arrays on the host.
+ * --------------------------------------------------------------------------------------------------------------- */
+static int secp256k1_ecmult_multi_var_amd(const secp256k1_callback *error_callback, secp256k1_scratch *scratch, secp256k1_gej *r,
+        const secp256k1_scalar *inp_g_sc, secp256k1_ecmult_multi_callback cb, void *cbdata, size_t n) {
+    if (secp256k1_amd_be.ecmult_multi != NULL && n >= secp256k1_amd_msm_min_terms && n > 0) {
+        unsigned char *sc = (unsigned char*)checked_malloc(error_callback, 32 * n);
+        unsigned char *pt = (unsigned char*)checked_malloc(error_callback, 64 * n);
+        unsigned char *inf = (unsigned char*)checked_malloc(error_callback, n);
+        unsigned char g32[32], out[64];
+        int32_t rinf = 0;
+        int ok = sc != NULL && pt != NULL && inf != NULL;
+        size_t i;
+        for (i = 0; ok && i < n; i++) {
+            secp256k1_scalar s; secp256k1_ge p;
+            if (!cb(&s, &p, i, cbdata)) { free(sc); free(pt); free(inf); return 0; }        /* the reference's rule, ecmult_impl.h:747-750 */
+            secp256k1_scalar_get_b32(sc + 32 * i, &s);
+            inf[i] = (unsigned char)secp256k1_ge_is_infinity(&p);
+            if (inf[i]) memset(pt + 64 * i, 0, 64);
+            else {
+                secp256k1_fe_normalize_var(&p.x); secp256k1_fe_normalize_var(&p.y);
+                secp256k1_fe_get_b32(pt + 64 * i, &p.x); secp256k1_fe_get_b32(pt + 64 * i + 32, &p.y);
+            }
+        }
+        if (ok) {
+            if (inp_g_sc != NULL) secp256k1_scalar_get_b32(g32, inp_g_sc);
+            ok = secp256k1_amd_be.ecmult_multi(secp256k1_amd_be.engine, out, &rinf, inp_g_sc != NULL ? g32 : NULL, sc, pt, inf, n);
+        }
+        free(sc); free(pt); free(inf);
+        if (ok) {
+            secp256k1_amd_served++;
+            if (rinf) secp256k1_gej_set_infinity(r);
+            else {
+                secp256k1_ge a; secp256k1_fe x, y;
+                secp256k1_fe_set_b32_mod(&x, out); secp256k1_fe_set_b32_mod(&y, out + 32);
+                secp256k1_ge_set_xy(&a, &x, &y);
+                secp256k1_gej_set_ge(r, &a);
+            }
+            return 1;
+        }
+        secp256k1_amd_fell_back++;
+    }
+    return secp256k1_ecmult_multi_var(error_callback, scratch, r, inp_g_sc, cb, cbdata, n);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Batch form of secp256k1_schnorrsig_verify (reference include/secp256k1_schnorrsig.h:178); all messages msglen long.
+ * --------------------------------------------------------------------------------------------------------------- */
+#ifdef ENABLE_MODULE_SCHNORRSIG
+int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *results, const unsigned char *const *sigs64,
+        const unsigned char *const *msgs, size_t msglen, const secp256k1_xonly_pubkey *const *pubkeys, size_t n) {
+    size_t i;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(sigs64 != NULL);
+    ARG_CHECK(msgs != NULL || msglen == 0);
+    ARG_CHECK(pubkeys != NULL);
+    for (i = 0; i < n; i++) { ARG_CHECK(sigs64[i] != NULL); ARG_CHECK(msglen == 0 || msgs[i] != NULL); ARG_CHECK(pubkeys[i] != NULL); }
+    if (n == 0) return 1;
+    if (secp256k1_amd_be.schnorrsig_verify_batch != NULL) {
+        unsigned char *s = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * n);
+        unsigned char *m = (unsigned char*)checked_malloc(&ctx->error_callback, msglen * n + 1);
+        unsigned char *pk = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * n);
+        int32_t *res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n);
+        int ok = s != NULL && m != NULL && pk != NULL && res32 != NULL;
+        if (ok) {
+            for (i = 0; i < n; i++) {
+                memcpy(s + 64 * i, sigs64[i], 64);
+                if (msglen != 0) memcpy(m + msglen * i, msgs[i], msglen);
+                memcpy(pk + 64 * i, pubkeys[i]->data, 64);              /* pk_format 1: the opaque object as it lies in memory */
+                res32[i] = 0;
+            }
+            ok = secp256k1_amd_be.schnorrsig_verify_batch(secp256k1_amd_be.engine, res32, s, m, msglen, pk, 1, n);
+            if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
+        }
+        free(s); free(m); free(pk); free(res32);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;
+    }
+    for (i = 0; i < n; i++) results[i] = secp256k1_schnorrsig_verify(ctx, sigs64[i], msglen != 0 ? msgs[i] : NULL, msglen, pubkeys[i]);
+    return 1;
+}
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Batch form of secp256k1_surjectionproof_verify (reference include/secp256k1_surjectionproof.h:256).
+ * Item i: proofs[i], input_tags[i][0 .. n_input_tags[i]), output_tags[i].
+ * --------------------------------------------------------------------------------------------------------------- */
+#ifdef ENABLE_MODULE_SURJECTIONPROOF
+int secp256k1_amd_surjectionproof_verify_batch(const secp256k1_context *ctx, int *results, const secp256k1_surjectionproof *const *proofs,
+        const secp256k1_generator *const *input_tags, const size_t *n_input_tags, const secp256k1_generator *const *output_tags, size_t n) {
+    size_t i;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(proofs != NULL);
+    ARG_CHECK(input_tags != NULL);
+    ARG_CHECK(n_input_tags != NULL);
+    ARG_CHECK(output_tags != NULL);
+    for (i = 0; i < n; i++) { ARG_CHECK(proofs[i] != NULL); ARG_CHECK(input_tags[i] != NULL); ARG_CHECK(output_tags[i] != NULL); }
+    if (n == 0) return 1;
+    if (secp256k1_amd_be.surjectionproof_verify_batch != NULL) {
+        size_t ntags = 0, po = 0, to = 0;
+        unsigned char *pbuf, *tags, *outs;
+        uint64_t *poff, *toff;
+        int32_t *res32;
+        int ok;
+        for (i = 0; i < n; i++) ntags += n_input_tags[i];
+        pbuf = (unsigned char*)checked_malloc(&ctx->error_callback, SECP256K1_SURJECTIONPROOF_SERIALIZATION_BYTES_MAX * n);
+        tags = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * ntags + 1);
+        outs = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * n);
+        poff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        toff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n);
+        ok = pbuf != NULL && tags != NULL && outs != NULL && poff != NULL && toff != NULL && res32 != NULL;
+        for (i = 0; ok && i < n; i++) {
+            size_t len = SECP256K1_SURJECTIONPROOF_SERIALIZATION_BYTES_MAX, k;
+            poff[i] = po; toff[i] = to;
+            ok = secp256k1_surjectionproof_serialize(ctx, pbuf + po, &len, proofs[i]);
+            po += len;
+            for (k = 0; k < n_input_tags[i]; k++) memcpy(tags + 64 * (to + k), input_tags[i][k].data, 64);
+            to += n_input_tags[i];
+            memcpy(outs + 64 * i, output_tags[i]->data, 64);
+            res32[i] = 0;
+        }
+        if (ok) {
+            poff[n] = po; toff[n] = to;
+            ok = secp256k1_amd_be.surjectionproof_verify_batch(secp256k1_amd_be.engine, res32, pbuf, poff, tags, toff, outs, n);
+            if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
+        }
+        free(pbuf); free(tags); free(outs); free(poff); free(toff); free(res32);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;
+    }
+    for (i = 0; i < n; i++) results[i] = secp256k1_surjectionproof_verify(ctx, proofs[i], input_tags[i], n_input_tags[i], output_tags[i]);
+    return 1;
+}
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Batch form of secp256k1_pedersen_verify_tally (reference include/secp256k1_generator.h:190): tally t checks
+ * sum(pos[t][0..pcnt[t])) - sum(neg[t][0..ncnt[t])) == 0.
+ * --------------------------------------------------------------------------------------------------------------- */
+#ifdef ENABLE_MODULE_GENERATOR
+int secp256k1_amd_pedersen_verify_tally_batch(const secp256k1_context *ctx, int *results,
+        const secp256k1_pedersen_commitment *const *const *pos, const size_t *pcnt,
+        const secp256k1_pedersen_commitment *const *const *neg, const size_t *ncnt, size_t n_tallies) {
+    size_t t, k;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(pos != NULL);
+    ARG_CHECK(pcnt != NULL);
+    ARG_CHECK(neg != NULL);
+    ARG_CHECK(ncnt != NULL);
+    for (t = 0; t < n_tallies; t++) { ARG_CHECK(pcnt[t] == 0 || pos[t] != NULL); ARG_CHECK(ncnt[t] == 0 || neg[t] != NULL); }
+    if (n_tallies == 0) return 1;
+    if (secp256k1_amd_be.pedersen_verify_tally_batch != NULL) {
+        size_t total = 0, o = 0;
+        unsigned char *c33;
+        uint64_t *off, *npos;
+        int32_t *res32;
+        int ok;
+        for (t = 0; t < n_tallies; t++) total += pcnt[t] + ncnt[t];
+        c33 = (unsigned char*)checked_malloc(&ctx->error_callback, 33 * total + 1);
+        off = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n_tallies + 1));
+        npos = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * n_tallies);
+        res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n_tallies);
+        ok = c33 != NULL && off != NULL && npos != NULL && res32 != NULL;
+        if (ok) {
+            for (t = 0; t < n_tallies; t++) {
+                off[t] = o; npos[t] = pcnt[t]; res32[t] = 0;
+                for (k = 0; k < pcnt[t]; k++) { memcpy(c33 + 33 * o, pos[t][k]->data, 33); o++; }
+                for (k = 0; k < ncnt[t]; k++) { memcpy(c33 + 33 * o, neg[t][k]->data, 33); o++; }
+            }
+            off[n_tallies] = o;
+            ok = secp256k1_amd_be.pedersen_verify_tally_batch(secp256k1_amd_be.engine, res32, c33, off, npos, n_tallies);
+            if (ok) for (t = 0; t < n_tallies; t++) results[t] = res32[t] != 0;
+        }
+        free(c33); free(off); free(npos); free(res32);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;
+    }
+    for (t = 0; t < n_tallies; t++) results[t] = secp256k1_pedersen_verify_tally(ctx, pos[t], pcnt[t], neg[t], ncnt[t]);
+    return 1;
+}
+#endif

@@ -1,0 +1,69 @@
+/* secp256k1_amd_hook.h -- the reference-side half of the MI355X drop-in boundary.
+ *
+ * What a secp256k1-zkp maintainer adds to the library (it is C89-compatible C and sees the library's internal types):
+ * a context-independent function-pointer table modelled on the library's one existing pluggable seam, the SHA-256
+ * compression hook (reference include/secp256k1.h:420-446), NULL => the existing CPU code runs.  Nothing hangs off
+ * secp256k1_context (its layout is compared by secp256k1_context_eq, reference src/secp256k1.c:80-81).
+ *
+ * The table's members have exactly the C ABI of include/secp256k1_zkp_amd.h, so an application registers the engine with
+ *
+ *     s2k_engine *e = s2k_engine_create(0);
+ *     secp256k1_amd_backend b = {0};
+ *     b.engine = e;
+ *     b.rangeproof_verify_batch = (secp256k1_amd_rangeproof_verify_batch_fn)secp256k1_rangeproof_verify_batch;
+ *     b.ecmult_multi            = (secp256k1_amd_ecmult_multi_fn)s2k_ecmult_multi;
+ *     ...
+ *     secp256k1_amd_set_backend(&b);
+ *
+ * Rules every adapter in secp256k1_amd_hook.c follows:
+ *   - a backend call that returns 0 (engine-level failure) makes the adapter run the library's own CPU path for the
+ *     whole batch: results are the reference's, a failed device never turns into a verdict;
+ *   - argument checks and their illegal-callback behaviour are the library's (ARG_CHECK) and happen before any packing;
+ *   - the caller owns every buffer; packing buffers are malloc'ed per call through checked_malloc (src/util.h:162-168)
+ *     and freed before returning.
+ *
+ * This file is built and tested in the test tier only (oracle/Makefile target `hooked`, against /root/reference);
+ * it is never linked into the product library.
+ */
+#ifndef SECP256K1_AMD_HOOK_H
+#define SECP256K1_AMD_HOOK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI of the engine entry points (include/secp256k1_zkp_amd.h); `engine` is the s2k_engine*. */
+typedef int (*secp256k1_amd_rangeproof_verify_batch_fn)(void *engine, int32_t *results, uint64_t *min_value, uint64_t *max_value,
+        const unsigned char *commits33, const unsigned char *proofs, const uint64_t *proof_off,
+        const unsigned char *extra, const uint64_t *extra_off, const unsigned char *gens64, size_t n);
+typedef int (*secp256k1_amd_ecmult_multi_fn)(void *engine, unsigned char *r_xy, int32_t *r_inf, const unsigned char *g_sc,
+        const unsigned char *sc, const unsigned char *pt_xy, const unsigned char *pt_inf, size_t n);
+typedef int (*secp256k1_amd_schnorrsig_verify_batch_fn)(void *engine, int32_t *results, const unsigned char *sigs, const unsigned char *msgs,
+        size_t msglen, const unsigned char *pubkeys, int pk_format, size_t n);
+typedef int (*secp256k1_amd_surjectionproof_verify_batch_fn)(void *engine, int32_t *results, const unsigned char *proofs, const uint64_t *proof_off,
+        const unsigned char *input_tags64, const uint64_t *tag_off, const unsigned char *output_tags64, size_t n);
+typedef int (*secp256k1_amd_pedersen_verify_tally_batch_fn)(void *engine, int32_t *results, const unsigned char *commits33,
+        const uint64_t *tally_off, const uint64_t *n_pos, size_t n_tallies);
+
+typedef struct secp256k1_amd_backend {
+    void *engine;
+    secp256k1_amd_rangeproof_verify_batch_fn rangeproof_verify_batch;            /* may be NULL: that call stays on the CPU */
+    secp256k1_amd_ecmult_multi_fn ecmult_multi;
+    secp256k1_amd_schnorrsig_verify_batch_fn schnorrsig_verify_batch;
+    secp256k1_amd_surjectionproof_verify_batch_fn surjectionproof_verify_batch;
+    secp256k1_amd_pedersen_verify_tally_batch_fn pedersen_verify_tally_batch;
+} secp256k1_amd_backend;
+
+/* Install (copy) a backend table; NULL restores the pure CPU library.  Not thread-safe against concurrent verification
+ * calls -- call it once at start-up, like secp256k1_context_set_sha256_compression. */
+void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend);
+/* Counters for tests / monitoring: batches served by the backend, batches that fell back to the CPU after a backend failure. */
+void secp256k1_amd_stats(size_t *served, size_t *fell_back);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -100,11 +100,18 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
         fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
     }
 }
+S2K_HD void ptab_load_ziso(fe& zi, const u32* ptab) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) zi.n[i] = ptab[S2K_PTAB_ZISO + i];
+}
+
 // ---- wave-level predicates ------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 #define S2K_WAVE_ANY(p) (__any(p))
+#define S2K_WAVE_ALL(p) (__all(p))
 #else
 #define S2K_WAVE_ANY(p) (p)
+#define S2K_WAVE_ALL(p) (p)
 #endif
 
 // Per-lane memory handed to ecmult_lane: the table slice in HBM and the digit stream in LDS.  The digit stream is what the
@@ -242,7 +249,36 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
     }
     op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
-    int done = !(a < a_end);
+    // Lock-step fast path.  When every lane of the wavefront multiplies a live point (and the lanes agree on whether there is a
+    // generator part) they all sit at the same place of the same micro-program, so the schedule is a plain loop: no per-lane
+    // program counter, no select after every point operation, lean formulas (group.h).  A lane that meets an operand with its
+    // own x coordinate (P + P, P - P: adversarial inputs only) makes the wavefront leave the fast path *before* that addition
+    // is committed; the general loop below picks up from exactly that state.
+#ifndef S2K_NO_FAST_PATH
+    if (S2K_WAVE_ALL(p_active) && (S2K_WAVE_ALL(g_active) || !S2K_WAVE_ANY(g_active))) {
+        int au = 1;                                              // uniform copy of `a`
+        while (au < a_end) {
+            if (au >= 2 && au < S2K_ADDS_P && !(au & 1)) {
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) gej_double_lean(R, R);
+                S2K_PROF_MARK(6);
+            }
+            if (au == S2K_ADD_G0) { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); zfixed = 1; }      // back to the real curve
+#pragma unroll
+            for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
+            gej t; const int same_x = gej_add_ge_lean(t, R, cur);
+            if (S2K_WAVE_ANY(same_x & cur_valid)) break;                        // -> general loop, nothing committed
+            if (au < S2K_ADDS_P) R = t;                                         // regular digits are never zero
+            else if (cur_valid) R = t;                                          // skew corrections, generator windows: per lane
+            au++;
+            op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+            op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+        }
+        if (au == S2K_ADD_G0 && !zfixed) { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); zfixed = 1; }      // no generator part
+        a = au;
+    }
+#endif
+    int done = !(a < a_end) & zfixed;
     while (S2K_WAVE_ANY(!done)) {
         int do_dbl = 0, do_add = 0;
         if (!done) {

@@ -366,6 +366,58 @@ S2K_HD void fe_mul2(fe& r1, const fe& a1, const fe& b1, fe& r2, const fe& a2, co
 S2K_HD void fe_mul_sqr(fe& r1, const fe& a1, const fe& b1, fe& r2, const fe& a2) { fe_dual<false, true>(r1, a1, b1, r2, a2, a2); }
 S2K_HD void fe_sqr2(fe& r1, const fe& a1, fe& r2, const fe& a2) { fe_dual<true, true>(r1, a1, a1, r2, a2, a2); }
 
+// ---- sum of two products with ONE reduction ---------------------------------------------------------------------
+// r = a1*b1 + a2*b2  (a1^2 when SQ1, a2^2 when SQ2): both products accumulate into the same pair of column chains, so the
+// whole reduction (18 fold multiply-accumulates, 17 column carries, the tail) is paid once instead of twice -- the "lazy
+// reduction" that the point formulas' Y3 = A*B + C*D lines ask for.  Needs mag(a1)*mag(b1) + mag(a2)*mag(b2) <= 7.
+template <bool SQ1, bool SQ2>
+S2K_HD void fe_muladd(fe& r, const fe& a1_in, const fe& b1_in, const fe& a2_in, const fe& b2_in) {
+    u32 a1[FE_LIMBS], b1[FE_LIMBS], a2[FE_LIMBS], b2[FE_LIMBS], x1[FE_LIMBS], x2[FE_LIMBS];      // x = 2a for squarings
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) {
+        a1[i] = a1_in.n[i]; b1[i] = SQ1 ? a1_in.n[i] : b1_in.n[i]; x1[i] = a1[i] << 1;
+        a2[i] = a2_in.n[i]; b2[i] = SQ2 ? a2_in.n[i] : b2_in.n[i]; x2[i] = a2[i] << 1;
+        if (SQ1) S2K_CHECK(a1[i] < (1u << 31));
+        if (SQ2) S2K_CHECK(a2[i] < (1u << 31));
+    }
+    S2K_OPAQUE(a1[8]); S2K_OPAQUE(b1[8]); S2K_OPAQUE(a2[8]); S2K_OPAQUE(b2[8]); S2K_OPAQUE(x1[8]); S2K_OPAQUE(x2[8]);
+    u32 k256 = 256u; S2K_OPAQUE(k256);
+    u64 c = 0, d = 0; u32 u = 0, uprev = 0;
+#pragma unroll
+    for (int k = 0; k < FE_LIMBS; k++) {
+#pragma unroll
+        for (int t = 0; t < FE_LIMBS; t++) {
+            // issue order d, c, d, c: the two chains alternate, so a multiply-accumulate rarely follows the one it depends on
+            const int ih = k + 1 + t, jh = 8 - t;                            // high column 9 + k (ih + jh = 9 + k)
+            const int il = t, jl = k - t;                                    // low column k
+            if (k < 8 && ih < FE_LIMBS && (!SQ1 || ih <= jh)) {
+                const u64 pr = !SQ1 ? (u64)a1[ih] * b1[jh] : (ih == jh) ? (u64)a1[ih] * a1[ih] : (u64)x1[ih] * a1[jh];
+                S2K_CHECK(d + pr >= d); d += pr; S2K_CHAIN(d);
+            }
+            if (jl >= 0 && (!SQ1 || il <= jl)) {
+                const u64 pr = !SQ1 ? (u64)a1[il] * b1[jl] : (il == jl) ? (u64)a1[il] * a1[il] : (u64)x1[il] * a1[jl];
+                S2K_CHECK(c + pr >= c); c += pr; S2K_CHAIN(c);
+            }
+            if (k < 8 && ih < FE_LIMBS && (!SQ2 || ih <= jh)) {
+                const u64 pr = !SQ2 ? (u64)a2[ih] * b2[jh] : (ih == jh) ? (u64)a2[ih] * a2[ih] : (u64)x2[ih] * a2[jh];
+                S2K_CHECK(d + pr >= d); d += pr; S2K_CHAIN(d);
+            }
+            if (jl >= 0 && (!SQ2 || il <= jl)) {
+                const u64 pr = !SQ2 ? (u64)a2[il] * b2[jl] : (il == jl) ? (u64)a2[il] * a2[il] : (u64)x2[il] * a2[jl];
+                S2K_CHECK(c + pr >= c); c += pr; S2K_CHAIN(c);
+            }
+        }
+        if (k < 8) { u = (u32)d & FE_M; d >>= FE_BITS; }
+        else { S2K_CHECK((d >> 32) == 0); u = (u32)d; }
+        S2K_CHECK(c + (u64)u * 31264u >= c);
+        c += (u64)u * 31264u; S2K_CHAIN(c);
+        if (k > 0) { c += (u64)uprev * k256; S2K_CHAIN(c); }
+        uprev = u;
+        r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
+    }
+    fe_mul_tail(r, c, u);
+}
+
 // ---- exponentiation chains ------------------------------------------------------------------------
 // r = x^(2^n) * y  -- the only place the chains below instantiate fe_sqr/fe_mul, kept out of line so that
 // an inversion costs ~15 calls instead of ~36 KB of inlined code.

@@ -87,6 +87,51 @@ S2K_HD int gej_add_ge(gej& r, const gej& a, const ge& b, fe* zr = nullptr) {
     return dbl ? GEJ_ADD_NEEDS_DOUBLE : 0;
 }
 
+// ---- lean forms for the lock-step main loop (ecmult.h) ------------------------------------------------------------
+// Same formulas, no case analysis, the Y3 line as one fused product pair (fe_muladd) and the weak normalisations placed so
+// that none is repeated at the next operation's entry.  Contract (both directions): X magnitude 1, Y magnitude <= 2, Z
+// magnitude 1, point finite.  What they do NOT handle is reported or excluded by the caller: gej_double_lean assumes a finite
+// point (a doubled point of odd order is never infinity); gej_add_ge_lean returns 1 when the operands share their x
+// coordinate (P + P or P - P) and the caller redoes that addition through gej_add_ge.
+S2K_HD void gej_double_lean(gej& r, const gej& a) {
+    fe l, s, t, nx, w;
+    fe_mul_sqr(r.z, a.y, a.z, s, a.y);         // Z3 = Y*Z (2*1), S = Y^2 (mag 2 ok)          -> (1, 1)
+    fe_neg(nx, a.x, 1);                        // -X                                           (2)
+    fe_mul_sqr(t, nx, s, l, a.x);              // T = -X*S (2*1), X^2                          -> (1, 1)
+    fe_mul_int(l, 3); fe_half(l);              // L = 3/2 X^2                                  (<= 2)
+    fe_norm_weak(l);                           //                                              (1)
+    fe_sqr(r.x, l);                            // L^2                                          (1)
+    fe_add(r.x, t); fe_add(r.x, t);            // X3 = L^2 + 2T                                (3)
+    fe_norm_weak(r.x);                         //                                              (1)
+    fe_add2(w, r.x, t);                        // X3 + T                                       (2)
+    fe_muladd<false, true>(r.y, l, w, s, s);   // L*(X3+T) + S^2 : 1*2 + 1*1 <= 7              (1)
+    fe_neg(r.y, r.y, 1);                       // Y3                                           (2)
+    r.inf = 0;
+}
+// r = a + b (b affine, magnitudes (1, <= 2)); returns 1 iff a and b have the same x (then r is meaningless).
+S2K_HD int gej_add_ge_lean(gej& r, const gej& a, const ge& b) {
+    fe z12, u2, s2, h, i, h2, h3, t, i2, ny, w;
+    fe_sqr(z12, a.z);
+    fe_mul2(u2, b.x, z12, s2, b.y, z12);       // U2 = x2*Z1^2, y2*Z1^2 (2*1)
+    fe_neg(h, a.x, 1); fe_add(h, u2);          // h = U2 - X1                                  (3)
+    fe_norm_seq(h);                            // exact limbs for the zero test, magnitude 1
+    fe_mul2(s2, s2, a.z, r.z, a.z, h);         // S2 = y2*Z1^3, Z3 = Z1*h
+    fe_neg(ny, a.y, 2);                        // -Y1                                          (3)
+    fe_add2(i, s2, ny);                        // i = S2 - Y1                                  (4)
+    fe_norm_weak(i);                           //                                              (1)
+    const int hz = fe_seq_is_zero(h);
+    fe_sqr2(i2, i, h2, h);
+    fe_mul2(h3, h, h2, t, a.x, h2);            // h^3, t = X1*h^2
+    fe_add2(w, t, t); fe_add(w, h3);           // h^3 + 2t                                     (3)
+    fe_neg(w, w, 3);                           //                                              (4)
+    fe_add2(r.x, i2, w);                       // X3 = i^2 - h^3 - 2t                          (5)
+    fe_norm_weak(r.x);                         //                                              (1)
+    fe_neg(w, r.x, 1); fe_add(w, t);           // t - X3                                       (3)
+    fe_muladd<false, false>(r.y, i, w, ny, h3);    // Y3 = i*(t - X3) - Y1*h^3 : 1*3 + 3*1 <= 7    (1)
+    r.inf = 0;
+    return hz;
+}
+
 // r = a + b, both Jacobian.  12M + 4S (cf. secp256k1_gej_add_var, group_impl.h:534-596).  Complete: handles
 // infinity, a == b (by doubling -- this function is only used in cold prologue/epilogue code) and a == -b.
 // Inputs magnitudes up to (5,3,1).

@@ -28,8 +28,9 @@ pr(buf)
 res, mn, mx = eng.rangeproof_verify_batch(commits, proofs, gens)
 pr(buf)
 v = np.array(list(buf), dtype=np.float64)
-names = ["step prologue (key load, next key)", "ecmult: split + digits", "ecmult: table build", "ecmult: main loop", "to-affine (inversion)", "hash + bookkeeping"]
-tot = v[:6].sum()
-out = {names[i]: {"wave_cycles": v[i], "share": v[i] / tot} for i in range(6)}
+names = ["step prologue (key load, next key)", "ecmult: split + digits", "ecmult: table build", "ecmult: main loop (rest: first operand, general loop)", "to-affine (inversion)",
+         "hash + bookkeeping", "main loop: 4 lean doublings", "main loop: lean addition + operand decode/locate"]
+tot = v[:8].sum()
+out = {names[i]: {"wave_cycles": v[i], "share": v[i] / tot, "cycles_per_wave_step": v[i] / (n * 32 * 4 / 64)} for i in range(8)}
 out["steps"] = n * 32 * 4 / 64
 print(json.dumps(out, indent=1))
