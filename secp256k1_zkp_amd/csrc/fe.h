@@ -461,7 +461,7 @@ S2K_HD void fe_inv_fermat(fe& r, const fe& a) {
 S2K_HD void fe_inv(fe& r, const fe& a) {
     fe an = a; fe_normalize(an);
     u32 w[8], o[8]; fe_to_words(w, an);
-    s30_inverse_words(o, w, S30_MOD_P);
+    ds_inverse_words(o, w, DS_MOD_P);
     fe_from_words(r, o);
 }
 // r = a^((p+1)/4); returns 1 iff r^2 == a, i.e. a is a square (cf. secp256k1_fe_sqrt, field_impl.h:37-146).

@@ -234,7 +234,7 @@ S2K_HD void sc_to_half(half_scalar& h, const scalar& s) {
 // a^-1 mod n (0 for 0) by division steps (modinv.h); cf. secp256k1_scalar_inverse_var
 S2K_HD void sc_inverse(scalar& r, const scalar& a) {
     u32 o[8];
-    s30_inverse_words(o, a.d, S30_MOD_N);
+    ds_inverse_words(o, a.d, DS_MOD_N);
 #pragma unroll
     for (int i = 0; i < 8; i++) r.d[i] = o[i];
 }

@@ -12,7 +12,7 @@ wc -l $O/avail_sq.txt
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_FLAT" ; do
+           "GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_IOPS SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_INSTS_FLAT" ; do
   i=$((i+1))
   timeout 400 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm > /dev/null 2>$O/pmc$i.err
   tail -3 $O/pmc$i.err

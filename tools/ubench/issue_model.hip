@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "group.h"
 
 #define CHECK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){fprintf(stderr,"HIP error %s at %d\n",hipGetErrorString(e_),__LINE__); exit(1);} }while(0)
@@ -124,6 +125,19 @@ FB(k_gej_add_ge) gej p; ge q; fe_seed(p.x, threadIdx.x + seed); fe_seed(p.y, thr
   fe_norm_weak(p.x); fe_norm_weak(p.y); fe_add(p.x, p.y); fe_add(p.x, p.z);
 FE_END(p.x)
 
+FB(k_fe_muladd) fe x, y, z; fe_seed(x, threadIdx.x + seed); fe_seed(y, threadIdx.x * 7 + 3); fe_seed(z, threadIdx.x * 11 + 5);
+  for (int it = 0; it < iters; ++it) fe_muladd<false, true>(x, x, y, z, z);           // one fused pair (product + square, one reduction)
+FE_END(x)
+FB(k_gej_double_lean) gej p; fe_seed(p.x, threadIdx.x + seed); fe_seed(p.y, threadIdx.x * 7 + 3); fe_seed(p.z, threadIdx.x * 11 + 5); p.inf = 0;
+  for (int it = 0; it < iters; ++it) gej_double_lean(p, p);
+  fe_add(p.x, p.y); fe_add(p.x, p.z);
+FE_END(p.x)
+FB(k_gej_add_ge_lean) gej p; ge q; fe_seed(p.x, threadIdx.x + seed); fe_seed(p.y, threadIdx.x * 7 + 3); fe_seed(p.z, threadIdx.x * 11 + 5); p.inf = 0;
+  fe_seed(q.x, threadIdx.x * 13 + 1); fe_seed(q.y, threadIdx.x * 17 + 2); int acc = 0;
+  for (int it = 0; it < iters; ++it) acc += gej_add_ge_lean(p, p, q);
+  fe_add(p.x, p.y); fe_add(p.x, p.z); p.x.n[0] += acc;
+FE_END(p.x)
+
 typedef void (*kern_t)(uint32_t*, uint32_t, int);
 struct entry { const char* name; kern_t k; double ops_per_iter; double approx_cyc_per_iter; };
 
@@ -138,13 +152,16 @@ int main(int argc, char** argv) {
         {"v_mad_u64_u32 1 chain + s_nop 0", k_mac1_nop, 8, 60}, {"v_mad_u64_u32 1 chain + v_and fill", k_mac1_fill, 8, 60},
         {"v_add_u32 x8", k_add8, 8, 20}, {"v_lshrrev_b64 x8", k_shr64_8, 8, 36}, {"column mix 6 mac+and+shr64", k_mix_col, 8, 36},
         {"fe_mul (fe.h)", k_fe_mul, 1, 800}, {"fe_sqr (fe.h)", k_fe_sqr, 1, 600}, {"fe_mul2 lockstep (per product)", k_fe_mul2, 2, 1500},
-        {"fe_sqr2 lockstep (per product)", k_fe_sqr2, 2, 1100}, {"gej_double", k_gej_double, 1, 5000}, {"gej_add_ge", k_gej_add_ge, 1, 8000}};
+        {"fe_sqr2 lockstep (per product)", k_fe_sqr2, 2, 1100}, {"gej_double", k_gej_double, 1, 5000}, {"gej_add_ge", k_gej_add_ge, 1, 8000},
+        {"fe_muladd (product + square, one reduction)", k_fe_muladd, 1, 1100}, {"gej_double_lean", k_gej_double_lean, 1, 4500}, {"gej_add_ge_lean", k_gej_add_ge_lean, 1, 7500}};
+    const char* only = (argc > 2) ? argv[2] : nullptr;
     const double target_ms = (argc > 1) ? atof(argv[1]) : 12.0;
     for (auto& e : es) {
+        if (only && !strstr(e.name, only)) continue;
         hipFuncAttributes fa; CHECK(hipFuncGetAttributes(&fa, (const void*)e.k));
         CHECK(hipFuncSetAttribute((const void*)e.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         printf("== %-36s VGPRs=%d\n", e.name, fa.numRegs);
-        for (int k : {1, 2, 3, 4, 5, 6, 8}) {
+        for (int k : {1, 2, 4, 8}) {
             const int alloc = ((fa.numRegs + 7) / 8) * 8;
             const int kmax = alloc ? 512 / alloc : 8;
             if (k > kmax) continue;
