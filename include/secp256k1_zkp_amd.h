@@ -53,7 +53,8 @@ S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
 /* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
  * `which`: 0 = whole call, 1 = dominant kernel only.  Valid after s2k_engine_sync(). */
 S2K_API float s2k_engine_last_ms(s2k_engine* e, int which);
-/* 1 if the most recent bucket MSM on this engine overflowed a bucket region and re-sorted exactly (diagnostics / tests). */
+/* 1 if the most recent MSM launch on this engine overflowed a bucket region and took the exact bucket-free path (diagnostics /
+ * tests; synchronises the device). */
 S2K_API int s2k_engine_last_msm_fallback(s2k_engine* e);
 
 /* ---- batch double multiplication ---------------------------------------------------------------------------
@@ -83,6 +84,13 @@ S2K_API int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* r_x
 S2K_API int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
                                          const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
 S2K_API int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count);
+/* The other way to spread ONE sum over the GPUs of a node (BASELINE config 5: "Pippenger bucket windows sharded across 8 GPUs"):
+ * every rank holds all n terms and owns share `part` of `parts` of the signed-digit windows of the bucket method
+ * (ecmult_impl.h:516-591 generalised); it returns  sum_{w in share} 2^(c w) S_w  as a Jacobian partial.  The partials of all
+ * shares add up to the full result exactly as the term-sharded partials do (all-gather of raw limbs + s2k_gej_sum_dev).
+ * All ranks must pass the same n (the window width depends on it) and the same g_sc. */
+S2K_API int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc, const unsigned char* sc,
+                                                const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n, uint32_t part, uint32_t parts);
 
 /* ---- BIP-340 batch verification -------------------------------------------------------------------------------
  * results[i] = secp256k1_schnorrsig_verify(ctx, sig64_i, msg_i, msglen, pubkey_i)
@@ -185,6 +193,22 @@ S2K_API int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* res
                                                      const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
                                                      size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
                                                      const unsigned char* commits33, size_t n);
+
+/* ---- Bulletproofs++ commitments on the fixed-base tables -----------------------------------------------
+ * commits33[i] = serialize_ext( secp256k1_bppp_commit(ctx, scratch, &commit, gens, n_vec_i, g_len, l_vec_i, h_len, c_vec_i, h_len, &mu_i) )
+ *              = v G + sum n_i G_i + sum l_j H_j ,  v = sum n_i^2 mu^(i+1) + <l, c>
+ *                                       (static, src/modules/bppp/bppp_norm_product_impl.h:105-151; serialisation src/secp256k1.c:885-891:
+ *                                        33 zero bytes = infinity)
+ * gens33: n_gens = g_len + h_len compressed generators (G_i first, then H_j), shared by the batch and cached as a fixed-base table
+ * like the verifier's; n_vec n*g_len*32, l_vec / c_vec n*h_len*32, mu n*32 (scalars, big-endian, reduced mod the group order).
+ * results (may be NULL): 1 per item when the generator set parsed, else 0 (the reference cannot be handed an unparsed set).
+ * The `_dev` form takes every array in HBM plus the generator set a second time on the host (gens33_host: the table's cache key). */
+S2K_API int secp256k1_bppp_commit_batch(s2k_engine* e, unsigned char* commits33, int32_t* results, const unsigned char* gens33, size_t n_gens, size_t g_len,
+                                        const unsigned char* n_vec, const unsigned char* l_vec, const unsigned char* c_vec, size_t h_len,
+                                        const unsigned char* mu, size_t n);
+S2K_API int secp256k1_bppp_commit_batch_dev(s2k_engine* e, void* stream, unsigned char* commits33, int32_t* results, const unsigned char* gens33_dev,
+                                            const unsigned char* gens33_host, size_t n_gens, size_t g_len, const unsigned char* n_vec,
+                                            const unsigned char* l_vec, const unsigned char* c_vec, size_t h_len, const unsigned char* mu, size_t n);
 
 #ifdef __cplusplus
 }

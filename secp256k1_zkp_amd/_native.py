@@ -31,6 +31,7 @@ SIGNATURES = {
     "s2k_ecmult_multi_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "s2k_ecmult_multi_partial_dev": (_c.c_int, [_vp, _vp] + [_vp] * 5 + [_sz]),
     "s2k_gej_sum_dev": (_c.c_int, [_vp, _vp] + [_vp] * 3 + [_sz]),
+    "s2k_ecmult_multi_window_partial_dev": (_c.c_int, [_vp, _vp] + [_vp] * 5 + [_sz, _c.c_uint32, _c.c_uint32]),
     "secp256k1_schnorrsig_verify_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
     "secp256k1_schnorrsig_verify_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
     "secp256k1_schnorrsig_aggverify_amd": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _vp, _sz, _vp, _sz]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "secp256k1_surjectionproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "secp256k1_surjectionproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
     "secp256k1_surjectionproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
+    "secp256k1_bppp_commit_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _sz]),
+    "secp256k1_bppp_commit_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _sz]),
     "secp256k1_bppp_norm_product_verify_batch": (_c.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),
 }
 

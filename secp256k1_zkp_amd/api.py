@@ -99,6 +99,11 @@ class Engine:
         self._check(self._lib.s2k_ecmult_multi_partial_dev(self._h, stream, _dp(r_gej28), _dp(g_sc), _dp(sc), _dp(pt_xy), _dp(pt_inf), n),
                     "s2k_ecmult_multi_partial_dev")
 
+    def ecmult_multi_window_partial_dev(self, r_gej28, sc, pt_xy, part, parts, g_sc=None, pt_inf=None, stream=None):
+        n = sc.numel() // 32
+        self._check(self._lib.s2k_ecmult_multi_window_partial_dev(self._h, stream, _dp(r_gej28), _dp(g_sc), _dp(sc), _dp(pt_xy), _dp(pt_inf), n, part, parts),
+                    "s2k_ecmult_multi_window_partial_dev")
+
     def gej_sum_dev(self, r_xy, r_inf, gej28, count, stream=None):
         self._check(self._lib.s2k_gej_sum_dev(self._h, stream, _dp(r_xy), _dp(r_inf), _dp(gej28), count), "s2k_gej_sum_dev")
 
@@ -114,6 +119,20 @@ class Engine:
         n = sigs.numel() // 64
         self._check(self._lib.secp256k1_schnorrsig_verify_batch_dev(self._h, stream, _dp(results), _dp(sigs), _dp(msgs), msglen, _dp(pubkeys),
                                                                     pk_format, n), "secp256k1_schnorrsig_verify_batch_dev")
+
+    # ---- secp256k1_bppp_commit (modules/bppp/bppp_norm_product_impl.h:105-151), batched on the fixed-base tables -----
+    def bppp_commit_batch(self, gens33, g_len, n_vec, l_vec, c_vec, mu):
+        """gens33 (n_gens,33); n_vec (n,g_len,32); l_vec, c_vec (n,h_len,32); mu (n,32) -> (commits (n,33), set_ok (n,))"""
+        gens33 = _u8(gens33); n_gens = gens33.size // 33
+        mu = _u8(mu); n = mu.size // 32
+        h_len = n_gens - g_len
+        n_vec = _u8(n_vec); l_vec = _u8(l_vec); c_vec = _u8(c_vec)
+        if n_vec.size != n * g_len * 32 or l_vec.size != n * h_len * 32 or c_vec.size != n * h_len * 32:
+            raise ValueError("bppp_commit_batch: vector shapes do not match (n, g_len, h_len)")
+        out = np.zeros((n, 33), np.uint8); res = np.zeros(n, np.int32)
+        self._check(self._lib.secp256k1_bppp_commit_batch(self._h, _p(out), _p(res), _p(gens33), n_gens, g_len, _p(n_vec), _p(l_vec), _p(c_vec), h_len, _p(mu), n),
+                    "secp256k1_bppp_commit_batch")
+        return out, res
 
     # ---- secp256k1_schnorrsig_aggverify (modules/schnorrsig_halfagg/main_impl.h:108-198) as one MSM -------------
     def schnorrsig_aggverify(self, pubkeys, msgs32, aggsig, pk_format=0, n=None):

@@ -222,3 +222,37 @@ S2K_HD void bp_term_fixed(gej& out, const u32* tab, u32 gen, const u32* k8) {
     }
     out = acc;
 }
+
+// ---- secp256k1_bppp_commit (bppp_norm_product_impl.h:105-151), batched ---------------------------------------
+//   commit = v G + sum_i n_i G_i + sum_j l_j H_j ,   v = sum_i n_i^2 mu^(i+1) + <l, c>     (:33-69, :131-134)
+// Every base is fixed: the generators use the set's fixed-base table above (16 additions each, no doubling), G the engine's
+// generator table (13 additions).  One lane per (commitment, base); the per-commitment sums reuse the segmented tree reduction.
+S2K_HD void bpc_v_scalar(u32 v8[8], const unsigned char* n_vec32, u32 g_len, const unsigned char* l_vec32, const unsigned char* c_vec32, u32 h_len,
+                         const unsigned char* mu32) {
+    scalar mu, mu_pow, v; sc_set_b32(mu, mu32, nullptr); mu_pow = mu; sc_set_zero(v);
+    for (u32 i = 0; i < g_len; i++) {
+        scalar a, t; sc_set_b32(a, n_vec32 + 32 * i, nullptr);
+        sc_mul(t, a, a); sc_mul(t, t, mu_pow); sc_mul(mu_pow, mu_pow, mu);
+        sc_add(v, v, t);
+    }
+    for (u32 j = 0; j < h_len; j++) {
+        scalar a, b, t; sc_set_b32(a, l_vec32 + 32 * j, nullptr); sc_set_b32(b, c_vec32 + 32 * j, nullptr);
+        sc_mul(t, a, b); sc_add(v, v, t);
+    }
+    for (int k = 0; k < 8; k++) v8[k] = v.d[k];
+}
+// k * G through the generator table (gtable.h): S2K_GTAB_WINDOWS additions, no doubling
+S2K_HD void bpc_gmul(gej& out, const u32* gtab, const u32* k8) {
+    gej acc; gej_set_infinity(acc);
+    for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
+        const u32 b = w * S2K_GTAB_BITS, word = b >> 5;
+        const u64 pair = (u64)k8[word] | ((u64)(word + 1 < 8 ? k8[word + 1] : 0u) << 32);
+        const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+        if (v) {
+            ge p; gtab_load(p, gtab, w, v);
+            gej t; const int f = gej_add_ge(t, acc, p); acc = t;
+            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
+        }
+    }
+    out = acc;
+}

@@ -63,8 +63,8 @@ struct s2k_engine {
     hipEvent_t ev_fork, ev_join;
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
-    u32* host_flags;           // pinned, 64 bytes: device -> host flags of the MSM binning pass
-    int msm_fallback;          // the most recent bucket MSM took the exact-sort fallback
+    u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
+    u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
     u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
     std::recursive_mutex mu;
@@ -175,7 +175,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->msm_fallback = 0; e->bp_tab = nullptr;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr;
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
@@ -187,6 +187,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) S2K_CREATE_CHK(hipEventCreate(&e->ev[i]));
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
+    S2K_CREATE_CHK(hipMalloc((void**)&e->dev_flags, 64));
+    S2K_CREATE_CHK(hipMemset(e->dev_flags, 0, 64));
     S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
     S2K_CREATE_CHK(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
@@ -205,6 +207,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->gtab) hipFree(e->gtab);
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
+    if (e->dev_flags) hipFree(e->dev_flags);
     for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -222,7 +225,13 @@ extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
     if (bytes) *bytes = sizeof(u32) * S2K_GTAB_WORDS;
     return e ? e->gtab : nullptr;
 }
-extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) { return e ? e->msm_fallback : 0; }
+extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) {
+    if (!e) return 0;
+    u32 f = 0;
+    hipSetDevice(e->device);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, e->dev_flags, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return f != 0;
+}
 #ifdef S2K_PROF
 // diagnostic builds only: read (and clear) the per-region cycle table of s2k_common.h
 extern "C" __attribute__((visibility("default"))) int s2k_prof_read(unsigned long long out[16]) {
@@ -708,8 +717,9 @@ k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned cha
 // The top window only has 128 - c*(windows-1) live bits (both GLV halves are below 2^128, scalar_impl.h:183-285), so its
 // few buckets are proportionally fuller: they get their own capacity.  Bucket k = w*nb + b starts at msm_region(k).
 struct msm_layout { u32 cap, cap_top, top_used; };     // top_used: buckets 0..top_used-1 of the top window have a region
+// (w = window index inside the launch's share [pl.w0, pl.w0 + pl.wn); the top window, if the share has it, is its last one)
 __device__ __forceinline__ size_t msm_region(const msm_layout& L, const msm_plan& pl, u32 w, u32 b) {
-    return (w + 1 < pl.windows) ? ((size_t)w * pl.nb + b) * L.cap : (size_t)(pl.windows - 1) * pl.nb * L.cap + (size_t)b * L.cap_top;
+    return (pl.w0 + w + 1 < pl.windows) ? ((size_t)w * pl.nb + b) * L.cap : (size_t)(pl.wn - 1) * pl.nb * L.cap + (size_t)b * L.cap_top;
 }
 #define MSM_BIN_THREADS 1024
 __global__ void __launch_bounds__(MSM_BIN_THREADS)
@@ -719,7 +729,7 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     const size_t t0 = (size_t)blockIdx.x * chunk;
     const size_t t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
     for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) s_cnt[b] = 0;
-    msm_wconst wc; msm_window_const(wc, w, pl.c);
+    msm_wconst wc; msm_window_const(wc, pl.w0 + w, pl.c);
     __syncthreads();
     // sweep: digit of every half-scalar of the chunk, rank inside the workgroup from the LDS histogram; the (bucket, rank, sign)
     // of the at most 8 terms x 2 halves a thread owns stay in registers (chunk <= 8 * MSM_BIN_THREADS)
@@ -747,7 +757,7 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     }
     __syncthreads();
     int over = 0;
-    const int top = (w + 1 == pl.windows);
+    const int top = (pl.w0 + w + 1 == pl.windows);
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
@@ -762,21 +772,6 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
         }
     }
     if (over) flags[0] = 1u;
-}
-// exact counting-sort scatter (fallback when a bucket region overflowed): cur = exclusive scan of gcnt
-__global__ void __launch_bounds__(256)
-k_msm_scatter(u32* refs, u32* cur, const u32* halves, size_t nt, msm_plan pl) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nt) return;
-    u32 h[MSM_HALF_WORDS];
-    for (int q = 0; q < MSM_HALF_WORDS; q++) h[q] = halves[i * MSM_HALF_WORDS + q];
-    for (u32 w = 0; w < pl.windows; w++) {
-        msm_wconst wc; msm_window_const(wc, w, pl.c);
-        for (int half = 0; half < 2; half++) {
-            const u32 key = msm_key_at(h, half, w, wc, pl);
-            if (key) { const u32 pos = atomicAdd(&cur[key >> 1], 1u); refs[pos] = (u32)(i << 2) | ((u32)half << 1) | (key & 1u); }
-        }
-    }
 }
 // exclusive scan of in[0..nk) into off[0..nk] (and a copy in cur if non-null): tiles of 1024, then the tile totals
 __global__ void __launch_bounds__(256)
@@ -808,12 +803,18 @@ k_scan_fix(u32* off, u32* cur, const u32* tile_sum, u32 nk) {
     for (int k = 0; k < 4; k++) if (base + k < nk) { const u32 o = off[base + k] + pre; off[base + k] = o; if (cur) cur[base + k] = o; }
     if (blockIdx.x == gridDim.x - 1 && t == 0) off[nk] = pre + tile_sum[blockIdx.x];
 }
-__global__ void k_msm_counts(u32* cnt_out, const u32* cnt_in, u32 nk, u32 T, u32* max_out) {
+// cap: a bucket's count can exceed its region (the binning pass then raised the overflow flag and the launch's result comes from
+// the exact path); clamping keeps every later kernel inside the memory the references were written to
+__global__ void k_msm_counts(u32* cnt_out, u32* cnt_clamped, const u32* cnt_in, u32 nk, u32 T, msm_layout L, msm_plan pl) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nk) {
-        const u32 c = cnt_in[k];
+        u32 c = cnt_in[k];
+        if (cnt_clamped) {
+            const int top = (pl.w0 + k / pl.nb + 1 == pl.windows);
+            const u32 cap = top ? ((k % pl.nb) < L.top_used ? L.cap_top : 0u) : L.cap;
+            c = c < cap ? c : cap; cnt_clamped[k] = c;
+        }
         cnt_out[k] = (c + T - 1) / T;
-        if (max_out && c > T) atomicMax(max_out, c);      // only buckets that need more than one round matter
     }
 }
 __global__ void __launch_bounds__(256, 2)
@@ -821,8 +822,8 @@ k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* cnt_in, 
     const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= off_out[nk]) return;
     const u32 k = msm_find_key(off_out, nk, m), j = m - off_out[k];
-    // bucket k's references: its region of the fixed-capacity layout (off_in == NULL), refs[off_in[k] ..) after the exact sort
-    const size_t first = off_in ? (size_t)off_in[k] : msm_region(L, pl, k / pl.nb, k % pl.nb);
+    // bucket k's references: its region of the fixed-capacity layout
+    const size_t first = msm_region(L, pl, k / pl.nb, k % pl.nb); (void)off_in;
     const size_t start = first + (size_t)j * T, end = min(start + T, first + cnt_in[k]);
     gej o; msm_sum_refs(o, refs, start, end, term);
     gej_store28(out28 + (size_t)m * 28, o);
@@ -849,8 +850,9 @@ k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, ms
 }
 // segmented tree sum: block (seg, chunk) adds up items [chunk*per_block, ...) of segment `seg` (seg_len items each)
 __global__ void __launch_bounds__(256)
-k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunks) {
+k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunks, const u32* gate) {
     __shared__ u32 sh[256 * 28];
+    if (gate && *gate == 0) return;                  // exact-path launches do nothing unless the overflow flag is up
     const u32 seg = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, t = threadIdx.x;
     const u32 lo = chunk * per_block, hi = min(lo + per_block, seg_len);
     gej acc; gej_set_infinity(acc);
@@ -870,28 +872,44 @@ k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunk
     }
     if (t == 0) for (int i = 0; i < 28; i++) out28[(size_t)blockIdx.x * 28 + i] = sh[i];
 }
-__global__ void k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
+// Horner over the share's windows (~c*windows sequential doublings: the latency floor of one MSM).  One lane; its own launch
+// bounds so that the whole point state stays in registers.
+__global__ void __launch_bounds__(64)
+k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
     if (threadIdx.x || blockIdx.x) return;
     gej r; msm_combine(r, wsum28, pl);
     gej_store28(out28, r);
 }
-// small inputs: one full double-and-add per lane; lane n carries g_sc*G
+// exact path: final <- exact result when the binning pass overflowed a bucket region
+__global__ void k_msm_pick(u32* final28, const u32* exact28, const u32* flags) {
+    if (flags[0] == 0) return;
+    for (int i = threadIdx.x; i < 28; i += blockDim.x) final28[i] = exact28[i];
+}
+// Bucket-free form: lane l sums (share of k_i)*P_i over the terms i = l, l + lanes, ... with one full double-and-add each
+// (ecmult.h); the term with index n carries g_sc*G.  Two uses: small inputs (n < MSM_SMALL_N, the analogue of the reference
+// switching to Strauss), and -- gated by the overflow flag -- the exact path of a bucket launch whose regions overflowed.
 __global__ void __launch_bounds__(256, 2)
-k_msm_small(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
-            const u32* gtab, u32* ptab, size_t n, size_t nt) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int live = i < nt, isg = live && (i == n);
-    gej A; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
-    if (live && !isg) {
-        ge a; ge_load_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a);
-        A.inf = pt_inf ? (pt_inf[i] != 0) : 0;
-        sc_set_b32(k, sc + 32 * i, nullptr);
-    }
-    if (isg) sc_set_b32(g, g_sc, nullptr);
+k_msm_direct(u32* out28, const u32* gate, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
+             const u32* gtab, u32* ptab, size_t n, size_t nt, msm_plan pl) {
+    if (gate && *gate == 0) return;
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x, lanes = (size_t)gridDim.x * blockDim.x;
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
-    const lane_mem lm{ptab + i * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
-    gej R; ecmult_lane(R, A, k, g, 1, gtab, lm);
-    if (live) gej_store28(out28 + i * 28, R);
+    const lane_mem lm{ptab + lane * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    gej acc; gej_set_infinity(acc);
+    for (size_t i0 = 0; i0 < nt; i0 += lanes) {
+        const size_t i = i0 + lane;
+        const int live = i < nt, isg = live && (i == n);
+        gej A; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
+        if (live && !isg) {
+            ge a; ge_load_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a);
+            A.inf = pt_inf ? (pt_inf[i] != 0) : 0;
+            scalar kk; sc_set_b32(kk, sc + 32 * i, nullptr); msm_share_scalar(k, kk, pl);
+        }
+        if (isg) { scalar gg; sc_set_b32(gg, g_sc, nullptr); msm_share_scalar(g, gg, pl); }
+        gej R; ecmult_lane(R, A, k, g, 1, gtab, lm);
+        gej s; gej_add_var(s, acc, R); acc = s;
+    }
+    gej_store28(out28 + lane * 28, acc);
 }
 __global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in28) {
     if (threadIdx.x || blockIdx.x) return;
@@ -902,11 +920,11 @@ __global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in2
 }
 
 // reduce `count` gej28 (one segment) down to one, ping-ponging between two scratch buffers; returns pointer to the result
-static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u32* bufB, u32 nseg, u32 seg_len) {
+static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u32* bufB, u32 nseg, u32 seg_len, const u32* gate = nullptr) {
     const u32* cur = in; u32* dst = bufA;
     while (seg_len > 1) {
         const u32 per_block = 1024, nchunks = (seg_len + per_block - 1) / per_block;
-        hipLaunchKernelGGL(k_gej_reduce, dim3(nseg * nchunks), dim3(256), 0, st, dst, cur, seg_len, per_block, nchunks);
+        hipLaunchKernelGGL(k_gej_reduce, dim3(nseg * nchunks), dim3(256), 0, st, dst, cur, seg_len, per_block, nchunks, gate);
         cur = dst; dst = (dst == bufA) ? bufB : bufA; seg_len = nchunks;
     }
     return cur;
@@ -930,19 +948,22 @@ static msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
     return L;
 }
 static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
-    return (size_t)(pl.windows - 1) * pl.nb * L.cap + (size_t)L.top_used * L.cap_top;
+    if (pl.wn == 0) return 8;
+    const int has_top = (pl.w0 + pl.wn == pl.windows);
+    return has_top ? (size_t)(pl.wn - 1) * pl.nb * L.cap + (size_t)L.top_used * L.cap_top : (size_t)pl.wn * pl.nb * L.cap;
 }
 // run lengths of the partial-sum rounds: round 1 sums up to T references per lane (about 1.3e5 lanes' worth at the largest
 // sizes), later rounds up to MSM_T2 partial sums -- short, because there are only a few per bucket left and lanes are scarce
 static u32 msm_run_len(size_t E) { u32 T = (u32)(E / 131072); if (T < 8) T = 8; if (T > 128) T = 128; return T; }
 #define MSM_T2 8u
+#define MSM_DIRECT_LANES 16384u          /* lanes of the bucket-free exact path (each walks its terms with a stride) */
 static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
     const size_t T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
-    return ws_need({28 * 4, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4, 64, msm_refs_words(pl, L) * 4, E * 4, nk * 28 * 4,
-                    (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4, (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2,
-                    (nt + 2) * 28 * 4, 64 * 28 * 4 * 2}) + 32 * 256;
+    return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
+                    msm_refs_words(pl, L) * 4, nk * 28 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
+                    (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2}) + 32 * 256;
 }
 static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
     const u32 tiles = (nk + 1023) / 1024;
@@ -950,80 +971,91 @@ static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const
     hipLaunchKernelGGL(k_scan_fix, dim3(tiles), dim3(256), 0, st, off, cur, tile_sum, nk);
 }
 // core: leaves the Jacobian result (28 words) at *result28 (device).  Workspace must already be large enough.
-// Stream-ordered, but not asynchronous: the host waits for the binning pass to learn the largest bucket (which fixes the number
-// of partial-sum rounds) and whether a bucket region overflowed.
+// Fully stream-ordered: nothing is read back.  The number of partial-sum rounds follows from the bucket-region capacity (a
+// bucket never holds more than its region), and an input that overflows a region (adversarially equal scalars) raises a
+// device flag that un-gates the exact bucket-free path queued behind the bucket pipeline; k_msm_pick then publishes its
+// result instead.  (part, parts): the share of the digit windows this launch owns (msm_plan_share) -- (0, 1) = all of them.
 __global__ void k_set_word(u32* p, u32 v) { *p = v; }
+__global__ void k_msm_flag_copy(u32* persist, const u32* flags) { persist[0] = flags[0]; }
 static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
-                      const unsigned char* pt, const unsigned char* pt_inf, size_t n) {
+                      const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1) {
     const size_t nt = n + (g_sc ? 1 : 0);
-    // term references are packed as (u32)(term << 2 | half << 1 | sign) and the exact-sort fallback keeps u32 prefix sums
-    // over 2 * windows digits per term: refuse what those cannot index instead of wrapping silently
-    if (nt >= (size_t(1) << 30) || nt * 2 * msm_make_plan(nt).windows >= (size_t(1) << 32))
+    if (parts == 0 || part >= parts) return s2k_fail_arg("s2k_ecmult_multi", "window share out of range");
+    msm_plan pl = msm_make_plan(nt ? nt : 1);
+    // term references are packed as (u32)(term << 2 | half << 1 | sign): refuse what those cannot index instead of wrapping silently
+    if (nt >= (size_t(1) << 30) || nt * 2 * pl.windows >= (size_t(1) << 32))
         return s2k_fail("s2k_ecmult_multi", "too many terms for 32-bit bucket references (2 * windows * n >= 2^32): split the sum, partial sums add");
+    msm_plan_share(pl, part, parts);
     u32* final28 = c.take<u32>(28);
     *result28 = final28;
-    if (nt < MSM_SMALL_N) {
-        u32* lanes = c.take<u32>((nt + 1) * 28); u32* bufA = c.take<u32>(64 * 28); u32* bufB = c.take<u32>(64 * 28);
-        if (nt == 0) { HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st)); hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, final28 + 27, 1u); HIPCHK(hipGetLastError()); return 1; }
-        HIPCHK(hipEventRecord(e->ev[2], st));
-        if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
-        hipLaunchKernelGGL(k_msm_small, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, lanes, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt);
-        HIPCHK(hipEventRecord(e->ev[3], st));
-        const u32* r = launch_gej_reduce(st, lanes, bufA, bufB, 1, (u32)nt);
-        HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
+    u32* flags = c.take<u32>(16);                              // flags[0]: a bucket region overflowed
+    u32* lanes = c.take<u32>((size_t)MSM_DIRECT_LANES * 28); u32* dbufA = c.take<u32>(64 * 28); u32* dbufB = c.take<u32>(64 * 28);
+    HIPCHK(hipMemsetAsync(flags, 0, 64, st));
+    if (nt == 0 || pl.wn == 0) {                               // empty sum / empty share: infinity
+        HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st));
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, final28 + 27, 1u);
+        hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
         HIPCHK(hipGetLastError());
         return 1;
     }
-    const msm_plan pl = msm_make_plan(nt);
-    const u32 nk = pl.windows * pl.nb;
-    const size_t E = nt * 2 * pl.windows;                      // upper bound on bucket references
-    const u32 T = msm_run_len(E), T2 = MSM_T2; const msm_layout L = msm_make_layout(nt, pl);
+    if (nt < MSM_SMALL_N) {
+        const unsigned dl = (unsigned)(((nt + 255) / 256) * 256);
+        if (!engine_ptab(e, dl)) return 0;
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(k_msm_direct, dim3(dl / 256), dim3(256), 0, st, lanes, (const u32*)nullptr, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
+        HIPCHK(hipEventRecord(e->ev[3], st));
+        const u32* r = launch_gej_reduce(st, lanes, dbufA, dbufB, 1, dl);
+        HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
+        HIPCHK(hipGetLastError());
+        return 1;
+    }
+    if (!engine_ptab(e, MSM_DIRECT_LANES)) return 0;
+    const u32 nk = pl.wn * pl.nb;
+    const size_t E = nt * 2 * pl.wn;                           // upper bound on this share's bucket references
+    const u32 T = msm_run_len(nt * 2 * pl.windows), T2 = MSM_T2; const msm_layout L = msm_make_layout(nt, pl);
     const size_t bound1 = (size_t)nk + E / T + 2;
     u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
-    u32* gcnt = c.take<u32>(nk + 1); u32* off0 = c.take<u32>(nk + 1); u32* cur = c.take<u32>(nk + 1);
+    u32* gcnt = c.take<u32>(nk + 1); u32* gclamp = c.take<u32>(nk + 1); u32* spare = c.take<u32>(nk + 1);
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
-    u32* tile_sum = c.take<u32>(1024); u32* flags = c.take<u32>(16);           // flags[0] overflow, flags[1] largest bucket (if > T)
-    u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* refs_dense = c.take<u32>(E); u32* buckets = c.take<u32>((size_t)nk * 28);
+    u32* tile_sum = c.take<u32>(1024); (void)spare;
+    u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* buckets = c.take<u32>((size_t)nk * 28);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
     HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
-    HIPCHK(hipMemsetAsync(flags, 0, 64, st));
     const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
-    u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.windows < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
-    hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.windows), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
-    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gcnt, nk, T, flags + 1);
-    HIPCHK(hipMemcpyAsync(e->host_flags, flags, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const int overflow = e->host_flags[0] != 0;
-    e->msm_fallback = overflow;
-    const u32 maxcnt = e->host_flags[1];
-    int rounds = 1; { size_t reach = T; while (reach < maxcnt) { reach *= T2; rounds++; } }
-    const u32* refs = refs_cap; const u32* first = nullptr;
-    if (overflow) {                                           // exact counting sort of the same references
-        launch_scan(st, off0, cur, tile_sum, gcnt, nk);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(bt), dim3(256), 0, st, refs_dense, cur, halves, nt, pl);
-        refs = refs_dense; first = off0;
-    }
+    u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
+    hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl);
+    // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
+    const int has_top = (pl.w0 + pl.wn == pl.windows);
+    const u32 maxcap = std::max(pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, has_top ? L.cap_top : 0u);
+    int rounds = 1; { size_t reach = T; while (reach < maxcap) { reach *= T2; rounds++; } }
     // round 1: references -> partial sums (at most T references each)
     launch_scan(st, offA, nullptr, tile_sum, cntA, nk);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs, first, gcnt, L, pl, offA, term, nk, T);
+    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
     HIPCHK(hipEventRecord(e->ev[3], st));
     // rounds 2..R: partial sums of partial sums until every bucket holds at most one
     u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
     size_t bound = bound1;
     for (int r = 2; r <= rounds; r++) {
         bound = (size_t)nk + bound / T2 + 2;
-        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, cin, nk, T2, (u32*)nullptr);
+        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, (u32*)nullptr, cin, nk, T2, L, pl);
         launch_scan(st, oout, nullptr, tile_sum, cout, nk);
         hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T2);
         u32* t;
         t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
     }
     hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl);
-    const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.windows, pl.nb);
+    const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
+    // exact path, un-gated only by the overflow flag
+    hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, st, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
+    const u32* ex = launch_gej_reduce(st, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
+    hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags);
+    hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
     HIPCHK(hipGetLastError());
     return 1;
 }
@@ -1039,6 +1071,22 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     ws_carver c{e->ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], st));
     if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
+    HIPCHK(hipMemcpyAsync(r_gej28, res, 28 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc, const unsigned char* sc,
+                                                   const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n, uint32_t part, uint32_t parts) {
+    if (!e) return s2k_fail("s2k_ecmult_multi_window_partial_dev", "null engine");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t nt = n + (g_sc ? 1 : 0);
+    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    ws_carver c{e->ws, 0}; u32* res = nullptr;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n, part, parts)) return 0;
     HIPCHK(hipMemcpyAsync(r_gej28, res, 28 * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
@@ -1168,6 +1216,27 @@ __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof
     ok &= (int)sums28[p * 28 + 27];            // res2 - res1 must be the point at infinity (gej_eq_var, :551)
     results[p] = ok;
 }
+// fixed-base table of a generator set: built on first use, kept for the following calls (a deployment has one set).
+// Sets too large for the table (> 256 generators = 19 GB) take the general path (*fixed = 0).  gens18: the set's affine points on
+// the device (k_bp_gens already queued on st); gens33: the serialised set on the HOST (the cache key).
+static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, const unsigned char* gens33, size_t n_gens, int* fixed) {
+    *fixed = n_gens <= 256;
+    if (*fixed && (e->bp_key.size() != 33 * n_gens || memcmp(e->bp_key.data(), gens33, 33 * n_gens) != 0)) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (e->bp_tab) { hipFree(e->bp_tab); e->bp_tab = nullptr; }
+        e->bp_key.clear();
+        if (hipMalloc((void**)&e->bp_tab, bp_tab_words(n_gens) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); e->bp_tab = nullptr; *fixed = 0; }
+        else {
+            const size_t total = (n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS;
+            hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
+            hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));             // the key is only remembered for a table whose build is known to have completed
+            e->bp_key.assign(gens33, gens33 + 33 * n_gens);
+        }
+    }
+    return 1;
+}
 extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
                                                         const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
                                                         size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
@@ -1212,23 +1281,8 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
-    // fixed-base table of this generator set: built on first use, kept for the following calls (a deployment has one set).
-    // Sets too large for the table (> 256 generators = 19 GB) take the general path.
-    int fixed = n_gens <= 256;
-    if (fixed && (e->bp_key.size() != 33 * n_gens || memcmp(e->bp_key.data(), gens33, 33 * n_gens) != 0)) {
-        HIPCHK(hipStreamSynchronize(st));
-        if (e->bp_tab) { hipFree(e->bp_tab); e->bp_tab = nullptr; }
-        e->bp_key.clear();
-        if (hipMalloc((void**)&e->bp_tab, bp_tab_words(n_gens) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); e->bp_tab = nullptr; fixed = 0; }
-        else {
-            const size_t total = (n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS;
-            hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
-            hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));             // the key is only remembered for a table whose build is known to have completed
-            e->bp_key.assign(gens33, gens33 + 33 * n_gens);
-        }
-    }
+    int fixed = 0;
+    if (!bp_ensure_table(e, st, gens18, gens33, n_gens, &fixed)) return 0;
     hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
     {
@@ -1243,6 +1297,128 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+
+
+// ---- secp256k1_bppp_commit, batched (bppp.h) ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_bpc_scalars(u32* v8, const unsigned char* n_vec, const unsigned char* l_vec, const unsigned char* c_vec, const unsigned char* mu, u32 g_len, u32 h_len, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bpc_v_scalar(v8 + 8 * i, n_vec + (size_t)32 * g_len * i, g_len, l_vec + (size_t)32 * h_len * i, c_vec + (size_t)32 * h_len * i, h_len, mu + 32 * i);
+}
+// lane (item, t): t < n_gens -> scalar_t * generator_t (fixed-base table, or the general double-and-add when there is none), t == n_gens -> v * G
+__global__ void __launch_bounds__(256, 2)
+k_bpc_terms(u32* out28, const u32* v8, const unsigned char* n_vec, const unsigned char* l_vec, u32 g_len, u32 h_len, const u32* tab, const u32* gens18, const int* gens_ok,
+            const u32* gtab, u32* ptab, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 T = g_len + h_len + 1;
+    const size_t i = t / T; const u32 ti = (u32)(t % T);
+    const int live = (i < n) && *gens_ok;
+    const size_t ii = i < n ? i : 0;
+    u32 k8[8];
+    if (ti < g_len + h_len) {
+        scalar k; sc_set_b32(k, ti < g_len ? n_vec + ((size_t)g_len * ii + ti) * 32 : l_vec + ((size_t)h_len * ii + (ti - g_len)) * 32, nullptr);
+        for (int q = 0; q < 8; q++) k8[q] = live ? k.d[q] : 0u;
+    } else for (int q = 0; q < 8; q++) k8[q] = live ? v8[8 * ii + q] : 0u;
+    gej o;
+    if (ti == g_len + h_len) bpc_gmul(o, gtab, k8);
+    else if (tab) bp_term_fixed(o, tab, ti, k8);
+    else {
+        __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+        const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+        gej A; ge p; for (int q = 0; q < 9; q++) { p.x.n[q] = gens18[18 * ti + q]; p.y.n[q] = gens18[18 * ti + 9 + q]; }
+        gej_set_ge(A, p);
+        scalar k, g; for (int q = 0; q < 8; q++) k.d[q] = k8[q]; sc_set_zero(g);
+        ecmult_lane(o, A, k, g, 0, gtab, lm);
+    }
+    if (i < n) gej_store28(out28 + t * 28, o);
+}
+// secp256k1_ge_serialize_ext (src/secp256k1.c:885-891): 33 zero bytes for infinity, else 0x02/0x03 || x; results[i] = the set parsed
+__global__ void __launch_bounds__(64)
+k_bpc_final(unsigned char* commits33, int32_t* results, const u32* sums28, const int* gens_ok, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gej r; gej_load28(r, sums28 + i * 28);
+    ge a; ge_set_gej(a, r);
+    unsigned char* o = commits33 + 33 * i;
+    if (r.inf || !*gens_ok) { for (int k = 0; k < 33; k++) o[k] = 0; }
+    else { o[0] = (unsigned char)(2 | fe_is_odd(a.y)); fe_get_b32(o + 1, a.x); }
+    if (results) results[i] = *gens_ok;
+}
+static int bpc_launch(s2k_engine* e, hipStream_t st, ws_carver& c, unsigned char* d_out33, int32_t* d_res, const unsigned char* d_g33, const unsigned char* gens33_host,
+                      size_t n_gens, size_t g_len, size_t h_len, const unsigned char* d_nv, const unsigned char* d_lv, const unsigned char* d_cv, const unsigned char* d_mu, size_t n) {
+    const size_t T = n_gens + 1;
+    u32* gens18 = c.take<u32>(n_gens * 18); int* gens_ok = c.take<int>(16); u32* v8 = c.take<u32>(8 * n);
+    u32* out28 = c.take<u32>(n * T * 28); u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
+    int fixed = 0;
+    if (!bp_ensure_table(e, st, gens18, gens33_host, n_gens, &fixed)) return 0;
+    if (!fixed && !engine_ptab(e, ((n * T + 255) / 256) * 256)) return 0;
+    hipLaunchKernelGGL(k_bpc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, v8, d_nv, d_lv, d_cv, d_mu, (u32)g_len, (u32)h_len, n);
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_bpc_terms, dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st, out28, v8, d_nv, d_lv, (u32)g_len, (u32)h_len, fixed ? e->bp_tab : (const u32*)nullptr,
+                       gens18, gens_ok, e->gtab, e->ptab, n);
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);
+    hipLaunchKernelGGL(k_bpc_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_out33, d_res, sums, gens_ok, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+static size_t bpc_ws_bytes(size_t n, size_t n_gens) {
+    const size_t T = n_gens + 1;
+    return ws_need({n_gens * 18 * 4, 64, 32 * n, n * T * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4});
+}
+extern "C" int secp256k1_bppp_commit_batch_dev(s2k_engine* e, void* stream, unsigned char* commits33, int32_t* results, const unsigned char* gens33_dev,
+                                               const unsigned char* gens33_host, size_t n_gens, size_t g_len, const unsigned char* n_vec, const unsigned char* l_vec,
+                                               const unsigned char* c_vec, size_t h_len, const unsigned char* mu, size_t n) {
+    if (!e) return s2k_fail("secp256k1_bppp_commit_batch_dev", "null engine");
+    if (!commits33 || !gens33_dev || !gens33_host || !n_vec || !l_vec || !c_vec || !mu || n_gens != g_len + h_len || n_gens == 0)
+        return s2k_fail_arg("secp256k1_bppp_commit_batch_dev", "illegal argument (ARG_CHECK)");
+    if (n == 0) return 1;
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t per = std::max<size_t>(1, e->max_lanes / (n_gens + 1));
+    if (!engine_workspace(e, bpc_ws_bytes(std::min(n, per), n_gens))) return 0;
+    for (size_t i0 = 0; i0 < n; i0 += per) {
+        const size_t m = std::min(n - i0, per);
+        ws_carver c{e->ws, 0};
+        if (!bpc_launch(e, st, c, commits33 + 33 * i0, results ? results + i0 : nullptr, gens33_dev, gens33_host, n_gens, g_len, h_len, n_vec + 32 * g_len * i0,
+                        l_vec + 32 * h_len * i0, c_vec + 32 * h_len * i0, mu + 32 * i0, m)) return 0;
+    }
+    return 1;
+}
+extern "C" int secp256k1_bppp_commit_batch(s2k_engine* e, unsigned char* commits33, int32_t* results, const unsigned char* gens33, size_t n_gens, size_t g_len,
+                                           const unsigned char* n_vec, const unsigned char* l_vec, const unsigned char* c_vec, size_t h_len, const unsigned char* mu, size_t n) {
+    if (!e) return s2k_fail("secp256k1_bppp_commit_batch", "null engine");
+    if (!commits33 || !gens33 || !n_vec || !l_vec || !c_vec || !mu || n_gens != g_len + h_len || n_gens == 0)
+        return s2k_fail_arg("secp256k1_bppp_commit_batch", "illegal argument (ARG_CHECK)");
+    if (n == 0) return 1;
+    if (results) memset(results, 0, sizeof(int32_t) * n);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t per = std::max<size_t>(1, e->max_lanes / (n_gens + 1));
+    const size_t io = ws_need({33 * n, 4 * n, 33 * n_gens, 32 * g_len * n, 32 * h_len * n, 32 * h_len * n, 32 * n});
+    if (!engine_workspace(e, bpc_ws_bytes(std::min(n, per), n_gens) + io)) return 0;
+    hipStream_t st = e->stream;
+    ws_carver c0{e->ws, bpc_ws_bytes(std::min(n, per), n_gens)};
+    unsigned char* d_out = c0.take<unsigned char>(33 * n); int32_t* d_res = c0.take<int32_t>(n); unsigned char* d_g33 = c0.take<unsigned char>(33 * n_gens);
+    unsigned char* d_nv = c0.take<unsigned char>(32 * g_len * n); unsigned char* d_lv = c0.take<unsigned char>(32 * h_len * n);
+    unsigned char* d_cv = c0.take<unsigned char>(32 * h_len * n); unsigned char* d_mu = c0.take<unsigned char>(32 * n);
+    HIPCHK(hipMemcpyAsync(d_g33, gens33, 33 * n_gens, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_nv, n_vec, 32 * g_len * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_lv, l_vec, 32 * h_len * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cv, c_vec, 32 * h_len * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_mu, mu, 32 * n, hipMemcpyHostToDevice, st));
+    if (!secp256k1_bppp_commit_batch_dev(e, nullptr, d_out, d_res, d_g33, gens33, n_gens, g_len, d_nv, d_lv, d_cv, h_len, d_mu, n)) return 0;
+    HIPCHK(hipMemcpyAsync(commits33, d_out, 33 * n, hipMemcpyDeviceToHost, st));
+    if (results) HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }

@@ -32,13 +32,23 @@
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
 #define MSM_TERM_WORDS 28           // x[9], beta*x[9], y[9], flags
 
-struct msm_plan { u32 c; u32 windows; u32 nb; };   // nb = buckets per window = 2^(c-1) + 1 (bucket 0 unused)
+// nb = buckets per window = 2^(c-1) + 1 (bucket 0 unused).  [w0, w0 + wn) is the range of digit windows this launch owns:
+// all of them on one GPU; a contiguous share when one MSM's bucket windows are spread over the GPUs of a node (SURVEY 8e,
+// the reference's batching generalised, ecmult_impl.h:804-867).  A launch then returns sum_{w in range} 2^(c w) S_w, and
+// the shares simply add up.
+struct msm_plan { u32 c; u32 windows; u32 nb; u32 w0; u32 wn; };
 
 static inline msm_plan msm_make_plan(size_t n_terms) {
     u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n_terms) lg++;
     int c = (int)lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;      // minimises W*(2n + 23*2^(c-1)) over the sizes of interest
-    msm_plan p; p.c = (u32)c; p.windows = (129 + c - 1) / c; p.nb = (1u << (c - 1)) + 1u;
+    msm_plan p; p.c = (u32)c; p.windows = (129 + c - 1) / c; p.nb = (1u << (c - 1)) + 1u; p.w0 = 0; p.wn = p.windows;
     return p;
+}
+// share `part` of `parts` of the windows (contiguous, sizes differ by at most one; parts > windows leaves some shares empty)
+static inline void msm_plan_share(msm_plan& p, u32 part, u32 parts) {
+    const u32 base = p.windows / parts, rem = p.windows % parts;
+    p.w0 = part * base + (part < rem ? part : rem);
+    p.wn = base + (part < rem ? 1u : 0u);
 }
 
 // signed c-bit digits of a 129-bit magnitude: k = sum d_w 2^(c w), d_w in [-2^(c-1), 2^(c-1)]
@@ -221,15 +231,75 @@ S2K_HD void msm_scale(gej& out, const gej& in, u32 weight) {
     out = r;
 }
 
-// ---- final combine: r = sum_w 2^(c w) S_w ---------------------------------------------------------------------------
+// ---- final combine: r = sum_{w in [w0, w0+wn)} 2^(c w) S_w ; window_sums28 holds the wn local sums --------------------------
 S2K_HD void msm_combine(gej& r, const u32* window_sums28, const msm_plan& pl) {
     gej acc; gej_set_infinity(acc);
-    for (int w = (int)pl.windows - 1; w >= 0; w--) {
-        for (u32 k = 0; k < pl.c; k++) { gej s; gej_double(s, acc); acc = s; }
+    for (int w = (int)pl.wn - 1; w >= 0; w--) {
+        if (!acc.inf) for (u32 k = 0; k < pl.c; k++) { gej s; gej_double(s, acc); acc = s; }
         gej sw;
         for (int i = 0; i < 9; i++) { sw.x.n[i] = window_sums28[28 * w + i]; sw.y.n[i] = window_sums28[28 * w + 9 + i]; sw.z.n[i] = window_sums28[28 * w + 18 + i]; }
         sw.inf = (int)window_sums28[28 * w + 27];
         gej s; gej_add_var(s, acc, sw); acc = s;
     }
+    if (!acc.inf) for (u32 k = 0; k < pl.c * pl.w0; k++) { gej s; gej_double(s, acc); acc = s; }
     r = acc;
+}
+
+// ---- the part of a scalar that a window share sees -------------------------------------------------------------------------
+// k = k1 + lambda k2 with signed c-bit digits d_{h,w} of the two 129-bit magnitudes; a share [w0, w0+wn) of the windows
+// contributes  sum_h s_h lambda^h sum_{w in share} d_{h,w} 2^(c w).  msm_share_scalar returns that residue, so that
+// "k_share * P summed over the terms" is the share's result computed without any bucket -- the exact (slow) path a launch
+// falls back to when an adversarial input overflows a bucket region.  For the full range it returns k itself.
+S2K_HD void msm_low_part(u32 t[6], int& carry, const u32 k[5], u32 w, u32 c) {
+    // T(w) = sum_{j<w} d_j 2^(c j) = (k mod 2^(c w)) - carry_w 2^(c w); returns k mod 2^(c w) and carry_w
+    const u32 bits = w * c;
+    msm_wconst wc; msm_window_const(wc, w, c);
+    u32 low[6]; u64 cy = 0;
+    for (int i = 0; i < 6; i++) {
+        const u32 ki = i < 5 ? k[i] : 0u;
+        const int lo_bit = 32 * i;
+        u32 m = 0xFFFFFFFFu;
+        if ((int)bits <= lo_bit) m = 0u; else if (bits < (u32)lo_bit + 32u) m = (1u << (bits - lo_bit)) - 1u;
+        low[i] = ki & m; t[i] = low[i];
+    }
+    u32 s[6];
+    for (int i = 0; i < 6; i++) { cy += (u64)low[i] + (i < 5 ? wc.add[i] : 0u); s[i] = (u32)cy; cy >>= 32; }
+    carry = (bits < 192u) ? (int)((s[bits >> 5] >> (bits & 31)) & 1u) : 0;
+}
+S2K_HD void msm_add_bit(u32 x[6], u32 bit) {          // x += 2^bit (bit < 192)
+    u64 cy = 0;
+    for (int i = 0; i < 6; i++) {
+        cy += (u64)x[i] + (((bit >> 5) == (u32)i) ? ((u64)1 << (bit & 31)) : 0);
+        x[i] = (u32)cy; cy >>= 32;
+    }
+}
+S2K_HD void msm_share_scalar(scalar& r, const scalar& k, const msm_plan& pl) {
+    if (pl.w0 == 0 && pl.wn == pl.windows) { r = k; return; }
+    scalar ks[2]; half_scalar h[2];
+    sc_split_lambda(ks[0], ks[1], k);
+    sc_to_half(h[0], ks[0]); sc_to_half(h[1], ks[1]);
+    scalar part[2];
+    for (int hf = 0; hf < 2; hf++) {
+        // m = T(w1) - T(w0), as a 192-bit two's complement number
+        u32 hi[6], lo[6]; int chi, clo;
+        const u32 w1 = pl.w0 + pl.wn;
+        msm_low_part(hi, chi, h[hf].w, w1, pl.c);
+        if (w1 >= pl.windows) { for (int i = 0; i < 6; i++) hi[i] = i < 5 ? h[hf].w[i] : 0u; chi = 0; }      // the top window never carries out
+        msm_low_part(lo, clo, h[hf].w, pl.w0, pl.c);
+        // m = (hi + clo 2^(c w0)) - (lo + chi 2^(c w1))
+        if (clo) msm_add_bit(hi, pl.c * pl.w0);
+        if (chi) msm_add_bit(lo, pl.c * w1);
+        u32 m[6]; u32 borrow = 0;
+        for (int i = 0; i < 6; i++) {
+            const u64 d = (u64)hi[i] - (u64)lo[i] - (u64)borrow;
+            m[i] = (u32)d; borrow = (u32)(d >> 63);
+        }
+        const int neg = (m[5] >> 31) & 1;
+        if (neg) { u64 cy = 1; for (int i = 0; i < 6; i++) { cy += (u64)(~m[i]); m[i] = (u32)cy; cy >>= 32; } }
+        scalar mag; for (int i = 0; i < 8; i++) mag.d[i] = i < 6 ? m[i] : 0u;           // |m| < 2^131 < n
+        if (neg ^ h[hf].neg) sc_negate(part[hf], mag); else part[hf] = mag;
+    }
+    scalar lam; sc_set_lambda(lam);
+    scalar t; sc_mul(t, part[1], lam);
+    sc_add(r, part[0], t);
 }

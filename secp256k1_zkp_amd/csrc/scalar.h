@@ -202,6 +202,11 @@ S2K_HD void sc_mul_shift384(scalar& r, const scalar& a, const scalar& b) {
     }
 }
 
+// lambda: the cube root of unity mod n with lambda*(x, y) = (beta*x, y)
+S2K_HD void sc_set_lambda(scalar& r) {
+    const u32 l[8] = {0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu};
+    for (int i = 0; i < 8; i++) r.d[i] = l[i];
+}
 // GLV decomposition k = r1 + lambda*r2 (mod n), |r1|,|r2| < 2^128 as signed residues.
 // Same lattice constants and rounding as secp256k1_scalar_split_lambda (scalar_impl.h:142-180).
 S2K_HD void sc_split_lambda(scalar& r1, scalar& r2, const scalar& k) {
@@ -209,7 +214,7 @@ S2K_HD void sc_split_lambda(scalar& r1, scalar& r2, const scalar& k) {
     const scalar minus_b2 = {{0x3DB1562Cu, 0xD765CDA8u, 0x0774346Du, 0x8A280AC5u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};
     const scalar g1 = {{0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u}};
     const scalar g2 = {{0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u}};
-    const scalar lambda = {{0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu}};
+    scalar lambda; sc_set_lambda(lambda);
     scalar c1, c2;
     sc_mul_shift384(c1, k, g1);
     sc_mul_shift384(c2, k, g2);

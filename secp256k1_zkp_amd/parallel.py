@@ -1,12 +1,17 @@
 """Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
 
-Two shapes, as SURVEY.md section 8e lays out:
+Shapes, as SURVEY.md section 8e lays out:
   * batches of independent proofs / signatures: replicas -- `shard_range` splits the item index range, no exchange step,
     the caller concatenates per-rank result arrays (`gather_results`);
   * one large multi-scalar multiplication: term sharding -- every rank runs a complete bucket MSM on its slice of the terms
     and emits ONE Jacobian partial (28 uint32: x, y, z limbs + infinity flag).  EC addition is not an RCCL reduction
     operator, so the collective is an all-gather of the raw limb buffers followed by a local tree sum
     (`s2k_gej_sum_dev`).  Payload: world_size x 112 bytes -- latency, not bandwidth, is what it costs.
+  * the same sum with the bucket *windows* sharded (BASELINE config 5 as worded): every rank holds all terms and owns a
+    contiguous share of the signed-digit windows; its partial is  sum_{w in share} 2^(c w) S_w , so the exchange and the final
+    sum are exactly those of term sharding (`msm_window_sharded`).  Which is faster depends on n and on the rank count:
+    term sharding divides all per-term work by the world size, window sharding repeats the decode / GLV split on every rank
+    but needs no slicing of the inputs and gives each rank whole windows; `msm_auto` picks by a size rule.
 """
 import numpy as np
 
@@ -38,6 +43,41 @@ def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
         dist.all_gather(bufs, part, group=group)
         parts = torch.stack(bufs)
     return backend.gej_sum(parts)
+
+
+def _gather_and_sum(backend, part, group):
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        parts = part.reshape(1, 28)
+    else:
+        bufs = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(bufs, part, group=group)
+        parts = torch.stack(bufs)
+    return backend.gej_sum(parts)
+
+
+def msm_window_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
+    """r = g_sc*G + sum sc_i*pt_i with the Pippenger digit windows sharded over the ranks of `group`: rank r computes
+    sum_{w in share r} 2^(c w) S_w over ALL terms (`backend.msm_window_partial`), the Jacobian partials are all-gathered as raw
+    limb buffers and summed locally.  Every rank passes the same full input.  Returns (xy, inf) on all ranks."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    part = backend.msm_window_partial(sc, pt_xy, g_sc, pt_inf, rank, world)
+    return _gather_and_sum(backend, part, group)
+
+
+def msm_auto(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
+    """term sharding unless the per-rank slice would fall under the bucket method's useful size (each rank would then pay the
+    whole latency floor for a sliver of the terms) while whole windows are still available to hand out."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
+    if world > 1 and n // world < (1 << 14) and n >= (1 << 12):
+        return msm_window_sharded(backend, sc, pt_xy, g_sc, pt_inf, group)
+    return msm_sharded(backend, sc, pt_xy, g_sc, pt_inf, group)
 
 
 def gather_results(local, n_total, group=None):
@@ -88,6 +128,15 @@ class EngineBackend:
         sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
         h = self._enter()
         self.engine.ecmult_multi_partial_dev(out, sc, pt_xy, g_sc, pt_inf, stream=h)
+        self._leave()
+        return out
+
+    def msm_window_partial(self, sc, pt_xy, g_sc, pt_inf, part, parts):
+        import torch
+        out = torch.zeros(28, dtype=torch.int32, device=self.dev)
+        sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
+        h = self._enter()
+        self.engine.ecmult_multi_window_partial_dev(out, sc, pt_xy, part, parts, g_sc=g_sc, pt_inf=pt_inf, stream=h)
         self._leave()
         return out
 

@@ -50,6 +50,31 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         fe_add(t, rx); { fe q = t; fe_normalize(q); fe_get_b32(o + 192, q); }
         fe_mul(ry, t, l); { fe q = ry; fe_normalize(q); fe_get_b32(o + 224, q); }
     } break;
+    // lazy-limb inputs (9 raw uint32 limbs per operand, magnitudes up to the contract's limits): the products on the DEVICE at
+    // the edge of the 64-bit column accumulators
+    case 30: case 31: case 32: case 33: case 34: case 35: case 36: {
+        fe u, v2, w; const u32* la = (const u32*)a + 9 * i; const u32* lb = b ? (const u32*)b + 9 * i : la; const u32* lc = c ? (const u32*)c + 9 * i : la;
+        for (int k = 0; k < 9; k++) { u.n[k] = la[k]; v2.n[k] = lb[k]; w.n[k] = lc[k]; }
+        fe r1, r2; fe_set_zero(r2);
+        if (op == 30) fe_mul(r1, u, v2);
+        else if (op == 31) fe_sqr(r1, u);
+        else if (op == 32) fe_mul2(r1, u, v2, r2, w, v2);                       // a*b, c*b
+        else if (op == 33) fe_muladd<false, false>(r1, u, v2, w, u);            // a*b + c*a
+        else if (op == 34) fe_muladd<false, true>(r1, u, v2, w, w);             // a*b + c^2
+        else if (op == 35) fe_mul_sqr(r1, u, v2, r2, w);                        // a*b, c^2
+        else { fe_sqr2(r1, u, r2, w); }                                         // a^2, c^2
+        fe_normalize(r1); fe_normalize(r2);
+        fe_get_b32(out + 64 * i, r1); fe_get_b32(out + 64 * i + 32, r2);
+    } break;
+    case 37: {   // lean point operations (group.h) against the general ones: double, then add b, from an affine start
+        ge p, q; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_set_b32_mod(q.x, b + 64 * i); fe_set_b32_mod(q.y, b + 64 * i + 32);
+        gej j; gej_set_ge(j, p);
+        gej_double_lean(j, j); gej_double_lean(j, j);
+        gej t; const int same = gej_add_ge_lean(t, j, q);
+        flag[i] = same;
+        gej_double_lean(t, t);
+        ge r; ge_set_gej(r, t); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
+    } break;
     case 12: { scalar s; int o; sc_set_b32(s, a + 32 * i, &o); flag[i] = o; sc_negate(s, s); sc_get_b32(out + 32 * i, s); } break;
     case 13: { scalar s; sc_set_b32(s, a + 32 * i, nullptr); sc_inverse(s, s); sc_get_b32(out + 32 * i, s); } break;
     }

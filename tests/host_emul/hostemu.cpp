@@ -182,17 +182,21 @@ int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, siz
     return schnorr_verify_lane(mid, sig64, msg, msglen, pk, pk_format, 1, gtab_host(), g_lm);
 }
 
-// the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width)
-int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n, int force_c) {
+// the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width) for share `part` of `parts` of the windows;
+// leaves the share's Jacobian partial in out28
+static int emu_msm_core(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n, int force_c,
+                        u32 part, u32 parts) {
     const size_t nt = n + (g_sc ? 1 : 0);
     msm_plan pl = msm_make_plan(nt ? nt : 1);
-    if (force_c > 0) { pl.c = force_c; pl.windows = (129 + pl.c - 1) / pl.c; pl.nb = (1u << (pl.c - 1)) + 1u; }
-    const size_t nk = (size_t)pl.windows * pl.nb;
-    std::vector<u32> term(nt * MSM_TERM_WORDS + 1), keys(nt * 2 * pl.windows + 1), hist(nk + 1, 0), off(nk + 1, 0), cur(nk + 1, 0), refs(nt * 2 * pl.windows + 1);
+    if (force_c > 0) { pl.c = force_c; pl.windows = (129 + pl.c - 1) / pl.c; pl.nb = (1u << (pl.c - 1)) + 1u; pl.w0 = 0; pl.wn = pl.windows; }
+    msm_plan full = pl;
+    msm_plan_share(pl, part, parts);
+    const size_t nk = (size_t)full.windows * full.nb;
+    std::vector<u32> term(nt * MSM_TERM_WORDS + 1), keys(nt * 2 * full.windows + 1), hist(nk + 1, 0), off(nk + 1, 0), cur(nk + 1, 0), refs(nt * 2 * full.windows + 1);
     for (size_t i = 0; i < nt; i++) {
         const int isg = (g_sc && i == n);
-        msm_prep(term.data() + i * MSM_TERM_WORDS, keys.data() + i * 2 * pl.windows, hist.data(), isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
-                 isg ? 0 : (inf ? inf[i] : 0), isg, pl);
+        msm_prep(term.data() + i * MSM_TERM_WORDS, keys.data() + i * 2 * full.windows, hist.data(), isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
+                 isg ? 0 : (inf ? inf[i] : 0), isg, full);
     }
     // the carry-free digit form the binning kernel uses (msm_prep_term + msm_key_at) must give exactly the same keys
     for (size_t i = 0; i < nt; i++) {
@@ -200,28 +204,58 @@ int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* 
         u32 t2[MSM_TERM_WORDS], hv[MSM_HALF_WORDS];
         msm_prep_term(t2, hv, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i, isg ? 0 : (inf ? inf[i] : 0), isg);
         for (int q = 0; q < MSM_TERM_WORDS; q++) if (t2[q] != term[i * MSM_TERM_WORDS + q]) return -1;
-        for (u32 w = 0; w < pl.windows; w++) {
-            msm_wconst wc; msm_window_const(wc, w, pl.c);
-            for (int half = 0; half < 2; half++) if (msm_key_at(hv, half, w, wc, pl) != keys[i * 2 * pl.windows + half * pl.windows + w]) return -2;
+        for (u32 w = 0; w < full.windows; w++) {
+            msm_wconst wc; msm_window_const(wc, w, full.c);
+            for (int half = 0; half < 2; half++) if (msm_key_at(hv, half, w, wc, full) != keys[i * 2 * full.windows + half * full.windows + w]) return -2;
         }
     }
     for (size_t k = 0; k < nk; k++) off[k + 1] = off[k] + hist[k];
     cur = off;
-    for (size_t i = 0; i < nt; i++) for (int half = 0; half < 2; half++) for (u32 w = 0; w < pl.windows; w++) {
-        const u32 key = keys[i * 2 * pl.windows + half * pl.windows + w];
+    for (size_t i = 0; i < nt; i++) for (int half = 0; half < 2; half++) for (u32 w = 0; w < full.windows; w++) {
+        const u32 key = keys[i * 2 * full.windows + half * full.windows + w];
         if (key) refs[cur[key >> 1]++] = (u32)(i << 2) | (half << 1) | (key & 1);
     }
-    std::vector<u32> wsum(pl.windows * 28);
-    for (u32 w = 0; w < pl.windows; w++) {
+    std::vector<u32> wsum((pl.wn + 1) * 28);
+    for (u32 wl = 0; wl < pl.wn; wl++) {
+        const u32 w = pl.w0 + wl;
         gej s; gej_set_infinity(s);
         for (u32 b = 1; b < pl.nb; b++) {
             gej v, o; msm_sum_refs(v, refs.data(), off[w * pl.nb + b], off[w * pl.nb + b + 1], term.data()); msm_scale(o, v, b);
             gej t; gej_add_var(t, s, o); s = t;
         }
-        gej_store28_h(wsum.data() + 28 * w, s);
+        gej_store28_h(wsum.data() + 28 * wl, s);
     }
     gej r; msm_combine(r, wsum.data(), pl);
+    gej_store28_h(out28, r);
+    return 0;
+}
+int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n, int force_c) {
+    u32 o[28];
+    const int rc = emu_msm_core(o, g_sc, sc, pt, inf, n, force_c, 0, 1);
+    if (rc < 0) return rc;
+    gej r; gej_load28_h(r, o);
     return gej_to_b64(r64, r);
+}
+// a window share's partial by the bucket path (direct = 0) or by the bucket-free exact path of k_msm_direct (direct = 1)
+int emu_msm_window_partial(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n,
+                           unsigned part, unsigned parts, int direct, int force_c) {
+    if (!direct) return emu_msm_core(out28, g_sc, sc, pt, inf, n, force_c, part, parts);
+    const size_t nt = n + (g_sc ? 1 : 0);
+    msm_plan pl = msm_make_plan(nt ? nt : 1);
+    if (force_c > 0) { pl.c = force_c; pl.windows = (129 + pl.c - 1) / pl.c; pl.nb = (1u << (pl.c - 1)) + 1u; pl.w0 = 0; pl.wn = pl.windows; }
+    msm_plan_share(pl, part, parts);
+    gej acc; gej_set_infinity(acc);
+    for (size_t i = 0; i < nt && pl.wn; i++) {
+        gej A, R; scalar k, g; gej_set_infinity(A); sc_set_zero(k); sc_set_zero(g);
+        if (i < n) { ge a; ge_from_b64(a, pt + 64 * i); fe_norm_weak(a.x); fe_norm_weak(a.y); gej_set_ge(A, a); A.inf = inf ? inf[i] : 0;
+                     scalar kk; sc_set_b32(kk, sc + 32 * i, 0); msm_share_scalar(k, kk, pl); }
+        else { scalar gg; sc_set_b32(gg, g_sc, 0); msm_share_scalar(g, gg, pl); }
+        u32 dig[S2K_DIG_WORDS]; const lane_mem lm{g_ptab, dig};
+        ecmult_lane(R, A, k, g, 1, gtab_host(), lm);
+        gej s2; gej_add_var(s2, acc, R); acc = s2;
+    }
+    gej_store28_h(out28, acc);
+    return 0;
 }
 
 int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned char* transcript104, const unsigned char* rho32, const unsigned char* gens33,

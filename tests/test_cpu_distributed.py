@@ -25,6 +25,16 @@ class EmuBackend:
         self.lib.emu_msm_partial(out.ctypes.data_as(ctypes.c_void_p), g, sc.tobytes(), pt.tobytes(), None, ctypes.c_size_t(sc.shape[0]))
         return torch.from_numpy(out.view(np.int32).copy())
 
+    def msm_window_partial(self, sc, pt_xy, g_sc, pt_inf, part, parts, direct=0, force_c=0):
+        import torch
+        sc = np.ascontiguousarray(sc.numpy()); pt = np.ascontiguousarray(pt_xy.numpy())
+        out = np.zeros(28, np.uint32)
+        g = None if g_sc is None else np.ascontiguousarray(g_sc.numpy()).tobytes()
+        rc = self.lib.emu_msm_window_partial(out.ctypes.data_as(ctypes.c_void_p), g, sc.tobytes(), pt.tobytes(), None, ctypes.c_size_t(sc.shape[0]),
+                                             ctypes.c_uint(part), ctypes.c_uint(parts), ctypes.c_int(direct), ctypes.c_int(force_c))
+        assert rc == 0
+        return torch.from_numpy(out.view(np.int32).copy())
+
     def gej_sum(self, parts):
         p = np.ascontiguousarray(parts.numpy()).view(np.uint32)
         out = ctypes.create_string_buffer(64)
@@ -40,6 +50,8 @@ def _worker(rank, world, port, sc, pts, g, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         xy, inf = parallel.msm_sharded(EmuBackend(), torch.from_numpy(sc), torch.from_numpy(pts), torch.from_numpy(g))
+        xy2, inf2 = parallel.msm_window_sharded(EmuBackend(), torch.from_numpy(sc), torch.from_numpy(pts), torch.from_numpy(g))
+        assert inf2 == inf and xy2.tobytes() == xy.tobytes()
         lo, hi = parallel.shard_range(11, rank, world)
         local = torch.arange(lo, hi, dtype=torch.int32)
         allres = parallel.gather_results(local, 11)
@@ -69,6 +81,32 @@ def test_sharded_msm_gloo_world2(ref):
     for rank, xy, inf, allres in outs:
         assert inf == einf and xy == exp.tobytes()
         assert allres == list(range(11))
+
+
+def test_window_shares_add_up(ref):
+    """sum over the shares of  sum_{w in share} 2^(c w) S_w  == the reference's ecmult_multi_var, for share counts that divide the
+    windows evenly, unevenly, and exceed them; the bucket path and the bucket-free exact path (k_msm_direct with
+    msm_share_scalar, what an overflowing launch falls back to) give the same group element share by share."""
+    if not os.path.exists(EMU):
+        pytest.skip("host emulation library not built")
+    import torch
+    be = EmuBackend()
+    rng = np.random.default_rng(22)
+    for n, force_c in ((9, 0), (40, 5), (40, 13)):
+        pts = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(n)])
+        sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); sc[1] = 0; sc[2, :16] = 0
+        g = rng.integers(0, 256, 32, dtype=np.uint8)
+        exp, einf = ref.ecmult_multi(sc, pts, g.tobytes(), None)
+        tsc, tpt, tg = torch.from_numpy(sc), torch.from_numpy(pts), torch.from_numpy(g)
+        for parts in (1, 2, 3, 8, 40):
+            shares = [be.msm_window_partial(tsc, tpt, tg, None, p, parts, direct=0, force_c=force_c) for p in range(parts)]
+            xy, inf = be.gej_sum(torch.stack(shares))
+            assert inf == einf and xy.tobytes() == exp.tobytes(), (n, force_c, parts)
+            if parts in (2, 3):
+                for p in range(parts):
+                    d = be.msm_window_partial(tsc, tpt, tg, None, p, parts, direct=1, force_c=force_c)
+                    a = be.gej_sum(shares[p].reshape(1, 28)); b = be.gej_sum(d.reshape(1, 28))
+                    assert a[1] == b[1] and a[0].tobytes() == b[0].tobytes(), (n, force_c, parts, p)
 
 
 def test_shard_range():

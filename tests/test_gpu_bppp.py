@@ -85,3 +85,33 @@ def test_config4_full_size(engine, ref):
     res = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, base[3], base[4], cvs, commits)
     assert np.array_equal(res, exp)
     assert exp.sum() == n - len(range(0, n, 19))
+
+
+def test_bppp_commit_batch(engine, ref):
+    """secp256k1_bppp_commit (static, bppp_norm_product_impl.h:105-151) for a batch, on the generator set's fixed-base tables, byte for
+    byte against the reference's own function (through oracle/ref_shim.c): random vectors, zero vectors (v*G only / infinity), and a
+    table-free generator set size."""
+    import ctypes
+    rng = np.random.default_rng(88)
+    sc = lambda *shape: (rng.integers(0, 256, shape + (32,), dtype=np.uint8) & np.array([0x7F] + [0xFF] * 31, np.uint8))
+    for g_len, h_len, n in ((16, 4, 9), (64, 8, 5), (1, 1, 3)):
+        gens = ref.bppp_generators(g_len + h_len)
+        nv, lv, cv, mu = sc(n, g_len), sc(n, h_len), sc(n, h_len), sc(n)
+        nv[1] = 0; lv[1] = 0                                   # commitment 1 = 0*G...: infinity -> 33 zero bytes
+        if n > 2:
+            nv[2] = 0; lv[2, 1:] = 0                           # one H term + v*G
+        exp = np.zeros((n, 33), np.uint8)
+        for i in range(n):
+            cm = np.zeros(33, np.uint8)
+            assert ref.lib.ref_bppp_commit(cm.ctypes.data_as(ctypes.c_void_p), gens.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(g_len + h_len),
+                                           np.ascontiguousarray(nv[i]).ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(g_len),
+                                           np.ascontiguousarray(lv[i]).ctypes.data_as(ctypes.c_void_p), np.ascontiguousarray(cv[i]).ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_size_t(h_len), np.ascontiguousarray(mu[i]).ctypes.data_as(ctypes.c_void_p)) == 1
+            exp[i] = cm
+        got, ok = engine.bppp_commit_batch(gens, g_len, nv, lv, cv, mu)
+        assert ok.all() and np.array_equal(got, exp), (g_len, h_len)
+        assert not got[1].any()
+    # a generator that does not parse: no commitment is produced for the batch
+    bad = ref.bppp_generators(8).copy(); bad[3, 0] = 7
+    got, ok = engine.bppp_commit_batch(bad, 4, sc(2, 4), sc(2, 4), sc(2, 4), sc(2))
+    assert not ok.any() and not got.any()

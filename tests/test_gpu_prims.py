@@ -167,3 +167,80 @@ def test_chained(prims, ref):
         exp = [y, S, L, T, X3, S2, XT, XT * L % P]
         for k, v in enumerate(exp):
             assert int.from_bytes(got[i, 32 * k:32 * k + 32].tobytes(), "big") == v, (i, k)
+
+
+def _lazy_limbs(rng, n, mag, extreme):
+    """n field elements as 9 raw limbs at magnitude `mag` of the fe.h contract (n[i] <= mag*(2^29+2^20), n[8] <= mag*(2^24+2^10));
+    extreme: every limb AT its bound for the first rows, random below it afterwards"""
+    hi = np.array([mag * ((1 << 29) + (1 << 20))] * 8 + [mag * ((1 << 24) + (1 << 10))], np.uint64)
+    lim = (rng.random((n, 9)) * (hi + 1)).astype(np.uint64)
+    lim = np.minimum(lim, hi)
+    k = min(extreme, n)
+    lim[:k] = hi
+    if n > k + 1:
+        lim[k] = hi; lim[k, ::2] = 0
+        lim[k + 1] = 0
+    return lim.astype(np.uint32)
+
+
+def _val(limbs):
+    return [sum(int(x) << (29 * i) for i, x in enumerate(row)) for row in limbs]
+
+
+def test_lazy_magnitudes_on_device(prims):
+    """fe_mul / fe_sqr / the lockstep pairs / the fused product pair (fe_muladd) with LAZY inputs at the limits of the magnitude
+    contract (product of magnitudes 7: the 64-bit column accumulators are within a few percent of wrapping), on the device, against
+    Python integers.  The host emulation asserts the same bounds (S2K_VERIFY); this is the device-side half, where the one real
+    miscompile of round 1 lived."""
+    rng = np.random.default_rng(71)
+    n = 256
+    u8 = lambda l: l.view(np.uint8)
+    for ma, mb in ((7, 1), (1, 7), (3, 2), (2, 3), (1, 1), (5, 1)):
+        a, b = _lazy_limbs(rng, n, ma, 4), _lazy_limbs(rng, n, mb, 4)
+        got, _ = prims(30, n, 64, u8(a), u8(b))
+        va, vb = _val(a), _val(b)
+        for i in range(n):
+            assert int.from_bytes(got[i, :32].tobytes(), "big") == va[i] * vb[i] % P, ("mul", ma, mb, i)
+    for m in (1, 2):
+        a = _lazy_limbs(rng, n, m, 4); va = _val(a)
+        got, _ = prims(31, n, 64, u8(a))
+        for i in range(n):
+            assert int.from_bytes(got[i, :32].tobytes(), "big") == va[i] * va[i] % P, ("sqr", m, i)
+    # pairs: (a*b, c*b), (a*b, c^2), (a^2, c^2)
+    for op, ma, mb, mc in ((32, 3, 2, 3), (32, 7, 1, 1), (35, 3, 2, 2), (35, 1, 7, 2), (36, 2, 1, 2)):
+        a, b, c = _lazy_limbs(rng, n, ma, 4), _lazy_limbs(rng, n, mb, 4), _lazy_limbs(rng, n, mc, 4)
+        got, _ = prims(op, n, 64, u8(a), u8(b), u8(c))
+        va, vb, vc = _val(a), _val(b), _val(c)
+        for i in range(n):
+            e1 = va[i] * vb[i] % P if op != 36 else va[i] * va[i] % P
+            e2 = vc[i] * vb[i] % P if op == 32 else vc[i] * vc[i] % P
+            assert int.from_bytes(got[i, :32].tobytes(), "big") == e1 and int.from_bytes(got[i, 32:].tobytes(), "big") == e2, (op, ma, mb, mc, i)
+    # fused pairs, sum of magnitude products exactly 7
+    for op, ma, mb, mc in ((33, 3, 2, 0), (34, 3, 1, 2), (34, 1, 3, 2), (34, 6, 1, 1)):
+        # op 33: a*b + c*a needs ma*mb + mc*ma <= 7 -> (1, 3, 4) below; op 34: a*b + c^2 needs ma*mb + mc^2 <= 7
+        if op == 33:
+            ma, mb, mc = 1, 3, 4
+        a, b, c = _lazy_limbs(rng, n, ma, 4), _lazy_limbs(rng, n, mb, 4), _lazy_limbs(rng, n, mc, 4)
+        got, _ = prims(op, n, 64, u8(a), u8(b), u8(c))
+        va, vb, vc = _val(a), _val(b), _val(c)
+        for i in range(n):
+            e = (va[i] * vb[i] + (vc[i] * va[i] if op == 33 else vc[i] * vc[i])) % P
+            assert int.from_bytes(got[i, :32].tobytes(), "big") == e, (op, ma, mb, mc, i)
+
+
+def test_lean_point_ops(prims, ref):
+    """gej_double_lean / gej_add_ge_lean (the lock-step fast path of ecmult_lane) against the reference group law:
+    2*(4P + Q); and the same-x report for Q = +-4P."""
+    rng = np.random.default_rng(72)
+    pts = [ref.rand_point(rng) for _ in range(40)] + [G_XY]
+    n = len(pts)
+    A = np.frombuffer(b"".join(pts), np.uint8).reshape(n, 64)
+    B = np.roll(A, 3, axis=0).copy()
+    g4, _ = ref.ecmult_batch(A, np.tile(np.frombuffer(_b(4), np.uint8), (n, 1)))
+    B[0] = g4[0]; B[1] = g4[1]; B[1, 32:] = np.frombuffer(_b((P - int.from_bytes(g4[1, 32:].tobytes(), "big")) % P), np.uint8)
+    got, same = prims(37, n, 64, A, B)
+    assert list(same[:2]) == [1, 1] and not same[2:].any()
+    for i in range(2, n):
+        r1 = ref.call("ref_ge_add", [64], g4[i].tobytes(), 0, B[i].tobytes(), 0)[1][0]
+        r2 = ref.call("ref_ge_double", [64], r1, 0)[1][0]
+        assert got[i].tobytes() == r2, i
