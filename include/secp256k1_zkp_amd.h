@@ -194,6 +194,24 @@ S2K_API int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* res
                                                      size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
                                                      const unsigned char* commits33, size_t n);
 
+/* ---- `_dev` forms of the calls above (every array in HBM of the engine's GPU, stream-ordered, nothing read back) ------------------
+ * Same arguments and per-item results as the host forms.  Where a call needs a few bytes on the host to plan its launches, that is
+ * an explicit extra argument: gens33_host (the BP++ generator set, cache key of its fixed-base table), tally_off_host / n_pos_host
+ * (the ragged tally sizes; the call returns once they have been consumed).  The half-aggregate verdict lands in result_dev[0]. */
+S2K_API int secp256k1_bppp_norm_product_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* proofs, size_t proof_len,
+                                                         const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33_dev,
+                                                         const unsigned char* gens33_host, size_t n_gens, size_t g_len, const unsigned char* c_vec,
+                                                         size_t c_vec_len, const unsigned char* commits33, size_t n);
+S2K_API int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, int32_t* result_dev, const unsigned char* pubkeys, int pk_format,
+                                               const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len);
+S2K_API int secp256k1_pedersen_verify_tally_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* commits33,
+                                                      const uint64_t* tally_off_host, const uint64_t* n_pos_host, size_t n_tallies);
+S2K_API int secp256k1_rangeproof_rewind_batch_dev(s2k_engine* e, void* stream, int32_t* results, unsigned char* blind_out, uint64_t* value_out,
+                                                  unsigned char* message_out, uint64_t* outlen, size_t msg_stride, const unsigned char* nonces,
+                                                  uint64_t* min_value, uint64_t* max_value, const unsigned char* commits33, const unsigned char* proofs,
+                                                  const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off,
+                                                  const unsigned char* gens64, size_t n);
+
 /* ---- Bulletproofs++ commitments on the fixed-base tables -----------------------------------------------
  * commits33[i] = serialize_ext( secp256k1_bppp_commit(ctx, scratch, &commit, gens, n_vec_i, g_len, l_vec_i, h_len, c_vec_i, h_len, &mu_i) )
  *              = v G + sum n_i G_i + sum l_j H_j ,  v = sum n_i^2 mu^(i+1) + <l, c>

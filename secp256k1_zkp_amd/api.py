@@ -29,6 +29,20 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _need(what, arr, nbytes):
+    """host arrays reach hipMemcpy with sizes derived from n: a wrong-shaped argument must be an exception, not an out-of-bounds read"""
+    if arr is None:
+        raise ValueError(f"{what}: missing array")
+    if arr.size != nbytes:
+        raise ValueError(f"{what}: expected {nbytes} bytes, got {arr.size}")
+
+
+def _offsets_ok(what, off, nbytes):
+    off = np.asarray(off)
+    if off.size == 0 or int(off[0]) != 0 or (np.diff(off.astype(np.int64)) < 0).any() or int(off[-1]) > nbytes:
+        raise ValueError(f"{what}: offsets must start at 0, be non-decreasing and end inside the data ({nbytes} bytes)")
+
+
 def _dp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -72,6 +86,9 @@ class Engine:
     def ecmult_batch(self, a_xy, na, ng=None, a_inf=None):
         a_xy = _u8(a_xy); n = a_xy.size // 64
         na = _u8(na); ng = None if ng is None else _u8(ng); a_inf = None if a_inf is None else _u8(a_inf)
+        _need("ecmult_batch a_xy", a_xy, 64 * n); _need("ecmult_batch na", na, 32 * n)
+        if ng is not None: _need("ecmult_batch ng", ng, 32 * n)
+        if a_inf is not None: _need("ecmult_batch a_inf", a_inf, n)
         r = np.zeros((n, 64), np.uint8); inf = np.zeros(n, np.int32)
         self._check(self._lib.s2k_ecmult_batch(self._h, _p(r), _p(inf), _p(a_xy), _p(a_inf), _p(na), _p(ng), n), "s2k_ecmult_batch")
         return r, inf
@@ -85,6 +102,9 @@ class Engine:
     def ecmult_multi(self, sc, pt_xy, g_sc=None, pt_inf=None):
         sc = _u8(sc); pt_xy = _u8(pt_xy); n = sc.size // 32
         g_sc = None if g_sc is None else _u8(g_sc); pt_inf = None if pt_inf is None else _u8(pt_inf)
+        _need("ecmult_multi sc", sc, 32 * n); _need("ecmult_multi pt_xy", pt_xy, 64 * n)
+        if g_sc is not None: _need("ecmult_multi g_sc", g_sc, 32)
+        if pt_inf is not None: _need("ecmult_multi pt_inf", pt_inf, n)
         r = np.zeros(64, np.uint8); inf = np.zeros(1, np.int32)
         self._check(self._lib.s2k_ecmult_multi(self._h, _p(r), _p(inf), _p(g_sc), _p(sc), _p(pt_xy), _p(pt_inf), n), "s2k_ecmult_multi")
         return r, int(inf[0])
@@ -110,6 +130,8 @@ class Engine:
     # ---- secp256k1_schnorrsig_verify (modules/schnorrsig/main_impl.h:215-261), batched -------------------------
     def schnorrsig_verify_batch(self, sigs, msgs, pubkeys, msglen=32, pk_format=0):
         sigs = _u8(sigs); msgs = _u8(msgs); pubkeys = _u8(pubkeys); n = sigs.size // 64
+        _need("schnorrsig_verify_batch sigs", sigs, 64 * n); _need("schnorrsig_verify_batch msgs", msgs, msglen * n)
+        _need("schnorrsig_verify_batch pubkeys", pubkeys, (64 if pk_format else 32) * n)
         res = np.zeros(n, np.int32)
         self._check(self._lib.secp256k1_schnorrsig_verify_batch(self._h, _p(res), _p(sigs), _p(msgs), msglen, _p(pubkeys), pk_format, n),
                     "secp256k1_schnorrsig_verify_batch")
@@ -141,6 +163,8 @@ class Engine:
         pubkeys = _u8(pubkeys); msgs32 = _u8(msgs32); aggsig = _u8(aggsig)
         if n is None:
             n = msgs32.size // 32
+        if msgs32.size < 32 * n or pubkeys.size < (64 if pk_format else 32) * n:
+            raise ValueError("schnorrsig_aggverify: fewer keys / messages than n")
         res = np.zeros(1, np.int32)
         self._check(self._lib.secp256k1_schnorrsig_aggverify_amd(self._h, _p(res), _p(pubkeys) if n else None, pk_format, _p(msgs32) if n else None, n,
                                                                  _p(aggsig), aggsig.size), "secp256k1_schnorrsig_aggverify_amd")
@@ -181,10 +205,22 @@ class Engine:
         edata = eoff = None
         if extra is not None:
             edata, eoff = extra if isinstance(extra, tuple) else self.pack(list(extra))
+        self._check_rp_shapes("rangeproof_verify_batch", n, commits33, gens64, data, off, edata, eoff)
         res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
         self._check(self._lib.secp256k1_rangeproof_verify_batch(self._h, _p(res), _p(mn), _p(mx), _p(commits33), _p(data), _p(off),
                                                                  _p(edata), _p(eoff), _p(gens64), n), "secp256k1_rangeproof_verify_batch")
         return res, mn, mx
+
+    @staticmethod
+    def _check_rp_shapes(what, n, commits33, gens64, data, off, edata, eoff):
+        _need(what + " commits33", commits33, 33 * n); _need(what + " gens64", gens64, 64 * n)
+        if np.asarray(off).size != n + 1:
+            raise ValueError(what + ": proof offsets must have n + 1 entries")
+        _offsets_ok(what + " proofs", off, data.size)
+        if eoff is not None:
+            if np.asarray(eoff).size != n + 1:
+                raise ValueError(what + ": extra_commit offsets must have n + 1 entries")
+            _offsets_ok(what + " extra", eoff, edata.size)
 
     def rangeproof_rewind_batch(self, commits33, proofs, gens64, nonces, msg_capacity=4096, extra=None):
         """secp256k1_rangeproof_rewind per item.  Returns (results, blinds (n,32), values uint64[n], messages list[bytes], min, max)."""
@@ -194,6 +230,8 @@ class Engine:
         edata = eoff = None
         if extra is not None:
             edata, eoff = extra if isinstance(extra, tuple) else self.pack(list(extra))
+        self._check_rp_shapes("rangeproof_rewind_batch", n, commits33, gens64, data, off, edata, eoff)
+        _need("rangeproof_rewind_batch nonces", nonces, 32 * n)
         res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
         blind = np.zeros((n, 32), np.uint8); val = np.zeros(n, np.uint64)
         msg = np.zeros((n, max(msg_capacity, 1)), np.uint8) if msg_capacity else None
@@ -218,6 +256,9 @@ class Engine:
         toff = np.zeros(n + 1, np.uint64)
         toff[1:] = np.cumsum([np.asarray(t).size // 64 for t in input_tags], dtype=np.uint64)
         tags = np.concatenate([_u8(t).reshape(-1) for t in input_tags] + [np.zeros(64, np.uint8)])
+        if len(input_tags) != n:
+            raise ValueError("surjectionproof_verify_batch: one input-tag list per proof")
+        _need("surjectionproof_verify_batch output_tags64", _u8(output_tags64), 64 * n)
         res = np.zeros(n, np.int32)
         self._check(self._lib.secp256k1_surjectionproof_verify_batch(self._h, _p(res), _p(data), _p(off), _p(tags), _p(toff), _p(_u8(output_tags64)), n),
                     "secp256k1_surjectionproof_verify_batch")
@@ -229,6 +270,9 @@ class Engine:
         proof_len = proofs.size // max(n, 1)
         gens33 = _u8(gens33); n_gens = gens33.size // 33
         c_vec = _u8(c_vec); c_len = c_vec.size // 32 // max(n, 1)
+        _need("bppp_norm_product_verify_batch proofs", proofs, proof_len * n); _need("bppp_norm_product_verify_batch transcripts", _u8(transcripts), 104 * n)
+        _need("bppp_norm_product_verify_batch c_vec", c_vec, 32 * c_len * n); _need("bppp_norm_product_verify_batch commits33", _u8(commits33), 33 * n)
+        _need("bppp_norm_product_verify_batch gens33", gens33, 33 * n_gens)
         res = np.zeros(n, np.int32)
         self._check(self._lib.secp256k1_bppp_norm_product_verify_batch(self._h, _p(res), _p(proofs), proof_len, _p(_u8(transcripts)), _p(_u8(rho)),
                                                                         _p(gens33), n_gens, g_len, _p(c_vec), c_len, _p(_u8(commits33)), n),

@@ -12,8 +12,8 @@
 //                    isomorphic-curve / global-Z trick (ecmult_impl.h:73-115, group_impl.h:289-320) -- and parked in a
 //                    per-lane 1152-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
 //                    addition ahead so the ~1-2 us of latency hides under the previous ~4 us of arithmetic.
-//   generator:       no doublings at all: ng is cut into 13 windows of 20 bits (S2K_GTAB_BITS), each indexing a precomputed
-//                    (window, value) -> affine multiple table (gtable.h, 872 MB in HBM), 13 mixed additions.
+//   generator:       no doublings at all: ng is cut into 11 windows of 24 bits (S2K_GTAB_BITS), each indexing a precomputed
+//                    (window, value) -> affine multiple table (gtable.h, 11.8 GB of the 288 GB of HBM), 11 mixed additions.
 //   digits:          both digit streams live in LDS (lane_mem), not in registers.
 //   control:         one loop whose body contains exactly ONE doubling site and ONE mixed-add site, driven by a
 //                    per-lane micro-program counter.  The only data-dependent *arithmetic* case (P + P inside an add)
@@ -29,9 +29,10 @@
 // gtab[((w << B) + v) * 16 .. +16) = affine (x words[8], y words[8], canonical, least significant word first) of
 // v * 2^(B w) * G ,  v = 1..2^B-1, w = 0..W-1, with B = S2K_GTAB_BITS and W = ceil(256 / B).  One entry = one aligned 64-byte
 // sector, the same record format as the per-lane table below, so that the main loop has a single operand pipeline.
-// B = 20: 13 windows, 872 MB of the 288 GB (the host emulation builds B = 12).
+// B = 24: 11 windows, 11 x 2^24 x 64 B = 11.8 GB of the 288 GB (B = 20: 13 windows, 872 MB, two more additions per
+// multiplication; the host emulation builds B = 12).
 #ifndef S2K_GTAB_BITS
-#define S2K_GTAB_BITS 20
+#define S2K_GTAB_BITS 24
 #endif
 #define S2K_GTAB_WINDOWS ((256 + S2K_GTAB_BITS - 1) / S2K_GTAB_BITS)
 #define S2K_GTAB_ENTRY_WORDS 16
@@ -53,41 +54,70 @@ S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
 // 27 limbs (x, y, z-ratio) of the not-yet-rescaled entry.
 #define S2K_PTAB_ENTRIES 8
 #define S2K_PTAB_ENTRY_WORDS 32
-#define S2K_PTAB_ZISO (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)      // parked while the main loop runs, to keep VGPRs for arithmetic
+#define S2K_PTAB_TABLE_WORDS (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)
+#define S2K_PTAB_ZISO (2 * S2K_PTAB_TABLE_WORDS)          // parked while the main loop runs, to keep VGPRs for arithmetic
 #define S2K_PTAB_NG (S2K_PTAB_ZISO + 9)
-#define S2K_PTAB_WORDS 288
+#define S2K_PTAB_WORDS (2 * S2K_PTAB_TABLE_WORDS + 32)    // two tables (the second one only in the split form below) + parked factors
 
 S2K_HD void ptab_store_raw(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
     for (int i = 0; i < 9; i++) { e[i] = x.n[i]; e[9 + i] = y.n[i]; e[18 + i] = third.n[i]; }
 }
-// Builds the table for a finite Jacobian A (magnitudes <= (5,3,1)); returns the factor that takes the accumulator's Z
-// from the isomorphic curve back to the real one.  ~138 field multiplications.
-S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
-    gej d; gej_double(d, A);
-    fe c2, c3, beta; fe_set_beta(beta);
-    fe_sqr(c2, d.z); fe_mul(c3, c2, d.z);
-    gej cur;
-    { fe x = A.x, y = A.y; fe_norm_weak(x); fe_norm_weak(y); fe_mul(cur.x, x, c2); fe_mul(cur.y, y, c3); }
-    cur.z = A.z; cur.inf = 0;
-    ge dd; dd.x = d.x; dd.y = d.y; fe_norm_weak(dd.x); fe_norm_weak(dd.y);
-    { fe one; fe_set_int(one, 1); ptab_store_raw(ptab, cur.x, cur.y, one); }
+// Table construction in two passes.  ptab_build_raw: the odd multiples by co-Z additions of 2A, each entry parked as (x, y, z-ratio of
+// its step) limbs; returns the Z all of them will share once rescaled (the Z of the last entry).  ptab_rescale: brings every entry to the Z of the last one times `zs0`
+// (secp256k1_ge_table_set_globalz, group_impl.h:289-320) and packs it as canonical words with its beta*x twin.  zs0 = 1 for a
+// single table; with two tables each is rescaled by the OTHER one's Z so that all sixteen entries share one Z (ecmult_lane_split).
+S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) {
+    // 2A by the usual doubling, whose intermediates also give A itself at the Z of 2A for free: Z(2A) = Y Z, so A rescaled by Y is
+    // (X Y^2, Y^4) = (-T, S^2).  From then on every odd multiple is a CO-Z addition of 2A (both operands share Z: 5M + 2S instead of the
+    // 8M + 3S of a mixed addition, and 2A comes out rescaled to the sum's Z for the next step); the step's Z ratio is just X(2A) - X(P).
+    fe x = A.x, y = A.y; fe_norm_weak(x); fe_norm_weak(y);
+    fe zc, s, t, l, nx, s2, qx, qy, w, px, py;
+    fe_mul_sqr(zc, y, A.z, s, y);                          // Z(2A) = Y Z, S = Y^2
+    fe_neg(nx, x, 1);
+    fe_mul_sqr(t, nx, s, l, x);                            // T = -X S, X^2
+    fe_mul_int(l, 3); fe_half(l); fe_norm_weak(l);         // L = 3/2 X^2
+    fe_sqr2(qx, l, s2, s);                                 // L^2, S^2
+    fe_add(qx, t); fe_add(qx, t); fe_norm_weak(qx);        // X(2A)                                  (1)
+    fe_add2(w, qx, t);
+    fe_mul(qy, l, w); fe_add(qy, s2); fe_neg(qy, qy, 2); fe_norm_weak(qy);     // Y(2A) = -(L (X3 + T) + S^2)      (1)
+    fe_neg(px, t, 1); py = s2;                             // A at the Z of 2A                      (2, 1)
+    { fe one; fe_set_int(one, 1); ptab_store_raw(tab, px, py, one); }
     for (int i = 1; i < S2K_PTAB_ENTRIES; i++) {
-        gej nxt; fe h;
-        gej_add_ge(nxt, cur, dd, &h);
-        fe_norm_weak(nxt.y);
-        ptab_store_raw(ptab + i * S2K_PTAB_ENTRY_WORDS, nxt.x, nxt.y, h);     // third slot: z ratio of this step
-        cur = nxt;
+        fe dx, dy, c, d, w1, w2, e, a1, x3, y3, tmp;
+        fe_neg(dx, px, 4); fe_add(dx, qx); fe_norm_weak(dx);              // X(2A) - X(P): also Z(sum) / Z(operands)
+        fe_neg(dy, py, 3); fe_add(dy, qy); fe_norm_weak(dy);
+        fe_sqr2(c, dx, d, dy);
+        fe_mul2(w1, qx, c, w2, px, c);                                    // (1*1, 4*1)
+        fe_neg(e, w2, 1); fe_add(e, w1);                                  // W1 - W2                     (3)
+        fe_add2(tmp, w1, w2); fe_neg(tmp, tmp, 2);                        // -(W1 + W2)                  (3)
+        fe_add2(x3, d, tmp);                                              // X(P + 2A)                   (4)
+        fe_neg(tmp, x3, 4); fe_add(tmp, w1);                              // W1 - X3                     (6)
+        fe_mul2(a1, qy, e, y3, dy, tmp);                                  // (1*3, 1*6)
+        fe_neg(tmp, a1, 1); fe_add(y3, tmp);                              // Y(P + 2A)                   (3)
+        fe_mul(zc, zc, dx);
+        ptab_store_raw(tab + i * S2K_PTAB_ENTRY_WORDS, x3, y3, dx);       // third slot: z ratio of this step
+        px = x3; py = y3; qx = w1; qy = a1;                               // 2A rescaled to the new Z
     }
-    fe_mul(ziso, cur.z, d.z);
-    // bring every entry to the Z of the last one (secp256k1_ge_table_set_globalz, group_impl.h:289-320), then pack
-    fe zs; fe_set_int(zs, 1);
+    ziso = zc;
+}
+S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
+    fe beta; fe_set_beta(beta);
+    fe zs; if (zs0) zs = *zs0; else fe_set_int(zs, 1);
+    // the parked entry of step i-1 is requested before the arithmetic of step i (each is a dependent round trip to L2 otherwise)
+    u32 nraw[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) nraw[k] = tab[(S2K_PTAB_ENTRIES - 1) * S2K_PTAB_ENTRY_WORDS + k];
     for (int i = S2K_PTAB_ENTRIES - 1; i >= 0; i--) {
-        u32* e = ptab + i * S2K_PTAB_ENTRY_WORDS;
+        u32* e = tab + i * S2K_PTAB_ENTRY_WORDS;
         fe x, y, h, bx;
 #pragma unroll
-        for (int k = 0; k < 9; k++) { x.n[k] = e[k]; y.n[k] = e[9 + k]; h.n[k] = e[18 + k]; }
-        if (i != S2K_PTAB_ENTRIES - 1) {
+        for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
+        if (i > 0) {
+#pragma unroll
+            for (int k = 0; k < 27; k++) nraw[k] = e[k - S2K_PTAB_ENTRY_WORDS];
+        }
+        if (zs0 || i != S2K_PTAB_ENTRIES - 1) {
             fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
             fe_mul(x, x, zs2); fe_mul(y, y, zs3);
         }
@@ -99,6 +129,12 @@ S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
         for (int k = 0; k < 8; k++) { e[k] = wx[k]; e[8 + k] = wy[k]; e[16 + k] = wb[k]; e[24 + k] = wy[k]; }
         fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
     }
+}
+// Builds the table for a finite Jacobian A (magnitudes <= (5,3,1)); returns the factor that takes the accumulator's Z
+// from the table's common-Z frame back to the real curve.  ~105 field multiplications.
+S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
+    ptab_build_raw(ziso, ptab, A);
+    ptab_rescale(ptab, nullptr);
 }
 S2K_HD void ptab_load_ziso(fe& zi, const u32* ptab) {
 #pragma unroll
@@ -150,8 +186,7 @@ S2K_HD u32 digit_reg_pop(digit_reg& r) {
 }
 
 #define S2K_ADDS_P 66            // 33 digit positions x 2 halves
-#define S2K_ADDS_SKEW 2
-#define S2K_ADD_G0 (S2K_ADDS_P + S2K_ADDS_SKEW)
+#define S2K_ADD_G0 S2K_ADDS_P
 #define S2K_ADDS_TOTAL (S2K_ADD_G0 + S2K_GTAB_WINDOWS)
 
 // R = na*A + ng*G for this lane.  A is Jacobian (A.inf allowed), ng may be absent (has_ng = 0).
@@ -162,20 +197,12 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
     S2K_PROF_DECL;
     const int p_active = (!A.inf) & (!sc_is_zero(na));
     const int g_active = has_ng & (!sc_is_zero(ng));
-    int hneg0, hneg1, skew0, skew1;
+    int hneg0, hneg1;
     fe ziso;
     {
-        scalar k1s, k2s; half_scalar h0, h1;
-        sc_split_lambda(k1s, k2s, na);
-        sc_to_half(h0, k1s); sc_to_half(h1, k2s);
+        half_scalar h0, h1;
+        sc_split_lambda_odd(h0, h1, na);                         // both magnitudes odd (< 2^129): no recoding correction
         hneg0 = h0.neg; hneg1 = h1.neg;
-        skew0 = !(h0.w[0] & 1u); skew1 = !(h1.w[0] & 1u);       // make the magnitudes odd: k' = k + skew, corrected by -P at the end
-        u32 c = (u32)skew0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { const u32 t = h0.w[i] + c; c = (t < c); h0.w[i] = t; }
-        c = (u32)skew1;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { const u32 t = h1.w[i] + c; c = (t < c); h1.w[i] = t; }
         {
             digit_reg dr0, dr1; digit_reg_init(dr0, h0.w); digit_reg_init(dr1, h1.w);
             u32 dw[9];
@@ -214,7 +241,6 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             const int hn = h ? hneg1 : hneg0;
             u32 v = 8u; int flip = hn; valid = 1;                                                   // top digit (a = 0, 1) is always +1
             if (idx >= 2 && idx < S2K_ADDS_P) v = (dig[(idx >> 3) * S2K_DIG_STRIDE] >> ((idx & 7) * 4)) & 15u;
-            if (idx >= S2K_ADDS_P) { flip = !hn; valid = h ? skew1 : skew0; }                       // skew correction: -(+-P)
             neg = (v < 8u) ^ flip;
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
             addr = ptab + e * S2K_PTAB_ENTRY_WORDS + (h ? 16 : 0);
@@ -269,7 +295,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             gej t; const int same_x = gej_add_ge_lean(t, R, cur);
             if (S2K_WAVE_ANY(same_x & cur_valid)) break;                        // -> general loop, nothing committed
             if (au < S2K_ADDS_P) R = t;                                         // regular digits are never zero
-            else if (cur_valid) R = t;                                          // skew corrections, generator windows: per lane
+            else if (cur_valid) R = t;                                          // generator windows: a zero window adds nothing (per lane)
             au++;
             op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
             op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
@@ -303,7 +329,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
                 op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
             }
         }
-        // leaving the isomorphic curve: after the skew corrections, before the generator additions
+        // leaving the isomorphic curve: after the last digit, before the generator additions
         const int fix = (!done) & (!zfixed) & (a == S2K_ADD_G0) & (!pending);
         if (S2K_WAVE_ANY(fix)) {
             fe zi;
@@ -315,4 +341,146 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
         if ((a >= a_end) & (!pending) & zfixed) done = 1;
     }
     S2K_PROF_MARK(3);
+}
+
+
+// ---- the same multiplication with the variable part cut in two: R = na*A + ng*G given also T = 2^64 * A -------------------------
+// When 2^64*A is known (the rangeproof rings keep it next to every ring key: one 64-doubling chain per ring, then the same
+// "+ base" step as the key itself, rangeproof.h), each odd GLV half k = ka + 2^64 kb splits into two 65-bit odd pieces and
+//     na*A = (+-k1a) A + (+-k2a) lambda A + (+-k1b) T + (+-k2b) lambda T
+// needs 64 doublings instead of 128, for one more table and two more additions: four digit streams of 17 signed odd 4-bit
+// digits, 4 doublings + 4 additions per digit position.  Both tables are rescaled to ONE common Z (ptab_rescale), so the
+// accumulator sits on one isomorphic curve as before.  Only the lock-step form exists: the function returns 0 without having
+// produced anything when the wavefront is not uniform or a lane meets an operand with its own x coordinate, and the caller then
+// runs ecmult_lane.  Digit stream in LDS: words 0..7 = nibble (pos * 4 + stream), words 8..15 = ng.
+#define S2K_SPLIT_ADDS_P 68          // 4 streams x 17 digits
+struct piece65 { u32 w[3]; int neg; };
+S2K_HD void sc_split_pieces(piece65 out[4], const half_scalar& h0, const half_scalar& h1) {
+    // out[0] = low piece of k1, out[1] = low piece of k2, out[2] = high piece of k1, out[3] = high piece of k2 (stream order)
+    for (int hf = 0; hf < 2; hf++) {
+        const half_scalar& h = hf ? h1 : h0;
+        u32 lo[3] = {h.w[0], h.w[1], 0u};
+        u32 hi[3] = {h.w[2], h.w[3], h.w[4]};                        // k >> 64 (< 2^65)
+        int lo_neg = h.neg;
+        if (!(hi[0] & 1u)) {                                         // make the high piece odd: hi += 1, lo -= 2^64 (lo becomes negative)
+            u32 c = 1u;
+            for (int i = 0; i < 3; i++) { const u32 t = hi[i] + c; c = (t < c); hi[i] = t; }
+            // |lo - 2^64| = 2^64 - lo  (lo odd, so nonzero)
+            const u64 l = (u64)lo[0] | ((u64)lo[1] << 32);
+            const u64 m = 0ull - l;
+            lo[0] = (u32)m; lo[1] = (u32)(m >> 32); lo[2] = 0u;
+            lo_neg = !h.neg;
+        }
+        for (int i = 0; i < 3; i++) { out[hf].w[i] = lo[i]; out[2 + hf].w[i] = hi[i]; }
+        out[hf].neg = lo_neg; out[2 + hf].neg = h.neg;
+    }
+}
+S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& na, const scalar& ng, int has_ng, const u32* gtab, const lane_mem& lm) {
+    u32* const ptab = lm.ptab; const s2k_lds_ptr dig = lm.dig;
+    const int p_active = (!A.inf) & (!T.inf) & (!sc_is_zero(na));
+    const int g_active = has_ng & (!sc_is_zero(ng));
+    if (!(S2K_WAVE_ALL(p_active) && (S2K_WAVE_ALL(g_active) || !S2K_WAVE_ANY(g_active)))) return 0;
+    u32 sneg = 0;                                                    // bit st: stream st is negative
+    {
+        half_scalar h0, h1; sc_split_lambda_odd(h0, h1, na);
+        piece65 pc[4]; sc_split_pieces(pc, h0, h1);
+        u32 dw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) dw[i] = 0;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            sneg |= (u32)pc[st].neg << st;
+#pragma unroll
+            for (int pos = 0; pos < 16; pos++) {                     // pos 0 = digit 15 (most significant after the fixed top digit)
+                const int i = 15 - pos, bit = 4 * i + 1, word = bit >> 5, sh = bit & 31;
+                const u64 pair = (u64)pc[st].w[word] | ((u64)(word + 1 < 3 ? pc[st].w[word + 1] : 0u) << 32);
+                const u32 v = (u32)(pair >> sh) & 15u;
+                const int nib = pos * 4 + st;
+                dw[nib >> 3] |= v << ((nib & 7) * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) dig[(8 + i) * S2K_DIG_STRIDE] = ng.d[i];
+        fe za, zt, ziso;
+        ptab_build_raw(za, ptab, A);
+        ptab_build_raw(zt, ptab + S2K_PTAB_TABLE_WORDS, T);
+        ptab_rescale(ptab, &zt);
+        ptab_rescale(ptab + S2K_PTAB_TABLE_WORDS, &za);
+        fe_mul(ziso, za, zt);
+#pragma unroll
+        for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
+    }
+    const int a_g0 = S2K_SPLIT_ADDS_P;
+    const int a_end = g_active ? a_g0 + S2K_GTAB_WINDOWS : a_g0;
+    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
+        addr = ptab; valid = 0; neg = 0;
+        if (idx < a_g0) {
+            const int st = idx & 3;
+            u32 v = 8u;                                                                     // the fixed top digit +1
+            if (idx >= 4) { const int nib = idx - 4; v = (dig[(nib >> 3) * S2K_DIG_STRIDE] >> ((nib & 7) * 4)) & 15u; }
+            valid = 1;
+            neg = (v < 8u) ^ (int)((sneg >> st) & 1u);
+            const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
+            addr = ptab + (st >> 1) * S2K_PTAB_TABLE_WORDS + e * S2K_PTAB_ENTRY_WORDS + ((st & 1) ? 16 : 0);
+        } else if (idx < a_end) {
+            const int g = idx - a_g0;
+            const int b = g * S2K_GTAB_BITS, w = b >> 5;
+            const u64 pair = (u64)dig[(8 + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(9 + w) * S2K_DIG_STRIDE] : 0u) << 32);
+            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+            if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+        }
+    };
+    auto op_decode = [&](ge& o, const u32 raw[16], int neg) {
+        fe y, yn;
+        fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
+        fe_neg(yn, y, 1);
+        fe_select(o.y, yn, y, neg);
+    };
+    const u32* nxt_addr; int nxt_valid, nxt_neg;
+    u32 raw[16];
+    ge cur; int cur_valid;
+    op_locate(nxt_addr, nxt_valid, nxt_neg, 0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+    op_decode(cur, raw, nxt_neg);
+    gej_set_ge(R, cur);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+    op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+    op_locate(nxt_addr, nxt_valid, nxt_neg, 2);
+    // variable part: additions 1..67, in place (a lane that meets its own x coordinate makes the caller start over with ecmult_lane,
+    // so the accumulator of before the addition need not survive it)
+    int au = 1;
+    while (au < a_g0) {
+        if (au >= 4 && !(au & 3)) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) gej_double_lean(R, R);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
+        const int same_x = gej_add_ge_lean(R, R, cur);
+        if (S2K_WAVE_ANY(same_x)) return 0;
+        au++;
+        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+    }
+    { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); }             // back to the real curve
+    // generator part: a zero window adds nothing (per lane), so these additions are committed by select
+    while (au < a_end) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+        gej t; const int same_x = gej_add_ge_lean(t, R, cur);
+        if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
+        if (cur_valid) R = t;
+        au++;
+        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+    }
+#ifdef S2K_ON_SPLIT_DONE
+    S2K_ON_SPLIT_DONE();                                                                      // host test build: count completed split runs
+#endif
+    return 1;
 }

@@ -63,6 +63,7 @@ struct s2k_engine {
     hipEvent_t ev_fork, ev_join;
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
+    int rp_split;              // rangeproof rings use the two-piece double multiplication (ecmult_lane_split); $S2K_RP_SPLIT=0 turns it off
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
@@ -180,9 +181,16 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
+    e->rp_split = 1;
+    if (const char* sp = getenv("S2K_RP_SPLIT")) e->rp_split = atoi(sp) != 0;
     if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    {   // the side stream carries throughput-bound kernels that run NEXT TO short latency-bound ones on the main stream (k_rp_lift beside
+        // k_rp_prologue): lowest priority, so that the main stream's few waves are placed first instead of queueing behind 8192 others
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = 0; }
+        S2K_CREATE_CHK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
+    }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) S2K_CREATE_CHK(hipEventCreate(&e->ev[i]));
@@ -333,7 +341,7 @@ k_rp_prologue(rp_ws ws, const uint64_t* min_value, const unsigned char* commits3
             const unsigned char* ex = nullptr; uint64_t exlen = 0;
             if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
             rp_pp_hash(rec, commits33 + 33 * p, proofs + proof_off[p], ex, exlen, gens64 + 64 * p);
-        } else rp_pp_bases(rec, ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, gens64 + 64 * p);
+        } else rp_pp_bases(rec, ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, gens64 + 64 * p, ws.dbases + p * RP_MAX_RINGS * RP_GEJ_WORDS);
     }
     __syncthreads();
     if (p < n && role == 0 && (ws.rec[p].hdr & 1u)) ws.rec[p].ok = 1;
@@ -357,7 +365,7 @@ k_rp_sum(rp_ws ws, size_t n) {
 #define S2K_RINGS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev) {
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     int live = p < n;
@@ -367,7 +375,8 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
     const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-            ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr);
+            ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr,
+            split ? ws.dbases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (const u32*)nullptr, split ? ws.tcur + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (u32*)nullptr);
 }
 __global__ void __launch_bounds__(64)
 k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
@@ -428,12 +437,15 @@ k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_v
 }
 
 static size_t rp_ws_bytes(size_t n) {
-    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_RING_OUT_BYTES, n * RP_MAX_RINGS});
+    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4,
+                    n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_RING_OUT_BYTES, n * RP_MAX_RINGS});
 }
 static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
     w.rec = c.take<rp_rec>(n);
     w.bases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.pub0 = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
+    w.dbases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
+    w.tcur = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.lift_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
     w.ring_out = c.take<unsigned char>(n * RP_RING_OUT_BYTES);
     w.ring_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
@@ -461,7 +473,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
         HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
         hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);
         if (p0 == 0) HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr);
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
         if (p0 == 0) HIPCHK(hipEventRecord(e->ev[3], st));
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
         if (rewind) {
@@ -564,6 +576,28 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     if (message_out) { HIPCHK(hipMemcpyAsync(message_out, ra.msg_out, mbytes, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(outlen, ra.outlen, 8 * n, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
     return 1;
+}
+// rewind with every array already in HBM (stream-ordered; scratch comes from the engine workspace)
+extern "C" int secp256k1_rangeproof_rewind_batch_dev(s2k_engine* e, void* stream, int32_t* results, unsigned char* blind_out, uint64_t* value_out,
+                                                     unsigned char* message_out, uint64_t* outlen, size_t msg_stride, const unsigned char* nonces,
+                                                     uint64_t* min_value, uint64_t* max_value, const unsigned char* commits33, const unsigned char* proofs,
+                                                     const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_rewind_batch_dev", "null engine");
+    if (n == 0) return 1;
+    if (!results || !blind_out || !value_out || !nonces || !min_value || !max_value || !commits33 || !proofs || !proof_off || !gens64 || (message_out && !outlen))
+        return s2k_fail_arg("secp256k1_rangeproof_rewind_batch_dev", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t nw = std::min(n, RP_CHUNK);
+    if (!engine_workspace(e, rp_ws_bytes(nw) + ws_need({8 * n, nw * 4096, nw * 4096, nw * 1024}))) return 0;
+    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
+    rp_rewind_args ra;
+    ra.nonces = nonces; ra.blind_out = blind_out; ra.value_out = value_out; ra.msg_out = message_out; ra.msg_stride = msg_stride;
+    ra.outlen = message_out ? outlen : c.take<uint64_t>(n);
+    ra.ev = c.take<u32>(nw * 1024); ra.prep = c.take<u32>(nw * 1024); ra.secs = c.take<u32>(nw * 256);
+    if (!message_out) HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
+    return rp_launch(e, st, w, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n, &ra);
 }
 // single-item forms with the reference's argument lists.  A 0 from these means "invalid" only while s2k_last_status() is
 // S2K_STATUS_OK; an engine-level failure also returns 0 (never 1) and leaves S2K_STATUS_ENGINE_FAILURE for the caller's
@@ -1237,52 +1271,24 @@ static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, con
     }
     return 1;
 }
-extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
-                                                        const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
-                                                        size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
-                                                        const unsigned char* commits33, size_t n) {
-    if (!e) return s2k_fail("secp256k1_bppp_norm_product_verify_batch", "null engine");
-    if (n == 0) return 1;
-    memset(results, 0, sizeof(int32_t) * n);
-    bp_shape sh;
-    if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { for (size_t i = 0; i < n; i++) results[i] = 0; return 1; }   // :446-461
-    std::lock_guard<std::recursive_mutex> lock(e->mu);
-    {
-        const size_t per = std::max<size_t>(1, e->max_lanes / sh.n_terms);        // proofs per launch group
-        if (n > per) {
-            for (size_t p0 = 0; p0 < n; p0 += per) {
-                const size_t m = std::min(n - p0, per);
-                if (!secp256k1_bppp_norm_product_verify_batch(e, results + p0, proofs + p0 * proof_len, proof_len, transcripts + 104 * p0, rho + 32 * p0, gens33, n_gens,
-                                                              g_len, c_vec + 32 * c_vec_len * p0, c_vec_len, commits33 + 33 * p0, m)) return 0;
-            }
-            return 1;
-        }
-    }
-    HIPCHK(hipSetDevice(e->device));
+static size_t bpv_ws_bytes(size_t n, const bp_shape& sh) {
     const size_t T = sh.n_terms, nt = n * T;
-    const size_t need = ws_need({4 * n, n * proof_len + 64, 104 * n, 32 * n, 33 * n_gens, 32 * c_vec_len * n, 33 * n, n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n,
-                                 nt * 28 * 4, nt + 64, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4});
-    if (!engine_workspace(e, need)) return 0;
-    ws_carver c{e->ws, 0};
-    int32_t* d_res = c.take<int32_t>(n); unsigned char* d_pr = c.take<unsigned char>(n * proof_len + 64); unsigned char* d_tr = c.take<unsigned char>(104 * n);
-    unsigned char* d_rho = c.take<unsigned char>(32 * n); unsigned char* d_g33 = c.take<unsigned char>(33 * n_gens);
-    unsigned char* d_cv = c.take<unsigned char>(32 * c_vec_len * n); unsigned char* d_cm = c.take<unsigned char>(33 * n);
+    return ws_need({(size_t)sh.n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n, nt * 28 * 4, nt + 64, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4});
+}
+// device pointers in (gens33_host: the generator set once more on the host, the fixed-base table's cache key); one launch group
+static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res, const bp_shape& sh, const unsigned char* d_pr, size_t proof_len, const unsigned char* d_tr,
+                      const unsigned char* d_rho, const unsigned char* d_g33, const unsigned char* gens33_host, const unsigned char* d_cv, const unsigned char* d_cm, size_t n) {
+    const size_t T = sh.n_terms, nt = n * T, n_gens = sh.n_gens;
     u32* gens18 = c.take<u32>(n_gens * 18); int* gens_ok = c.take<int>(16); u32* term_sc = c.take<u32>(nt * 8); int* proof_ok = c.take<int>(n);
     u32* out28 = c.take<u32>(nt * 28); unsigned char* term_ok = c.take<unsigned char>(nt + 64);
     u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
-    hipStream_t st = e->stream;
     if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
-    HIPCHK(hipMemcpyAsync(d_pr, proofs, n * proof_len, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_tr, transcripts, 104 * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_rho, rho, 32 * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_g33, gens33, 33 * n_gens, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_cv, c_vec, 32 * c_vec_len * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_cm, commits33, 33 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_res, 0, sizeof(int32_t) * n, st));
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
     int fixed = 0;
-    if (!bp_ensure_table(e, st, gens18, gens33, n_gens, &fixed)) return 0;
+    if (!bp_ensure_table(e, st, gens18, gens33_host, n_gens, &fixed)) return 0;
     hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
     {
@@ -1296,11 +1302,61 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     hipLaunchKernelGGL(k_bp_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_res, sums, proof_ok, term_ok, gens_ok, (u32)T, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+extern "C" int secp256k1_bppp_norm_product_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* proofs, size_t proof_len,
+                                                            const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33_dev,
+                                                            const unsigned char* gens33_host, size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
+                                                            const unsigned char* commits33, size_t n) {
+    if (!e) return s2k_fail("secp256k1_bppp_norm_product_verify_batch_dev", "null engine");
+    if (n == 0) return 1;
+    if (!results || !proofs || !transcripts || !rho || !gens33_dev || !gens33_host || !c_vec || !commits33)
+        return s2k_fail_arg("secp256k1_bppp_norm_product_verify_batch_dev", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    bp_shape sh;
+    if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st)); return 1; }   // :446-461
+    const size_t per = std::max<size_t>(1, e->max_lanes / sh.n_terms);        // proofs per launch group
+    if (!engine_workspace(e, bpv_ws_bytes(std::min(n, per), sh))) return 0;
+    for (size_t p0 = 0; p0 < n; p0 += per) {
+        const size_t m = std::min(n - p0, per);
+        ws_carver c{e->ws, 0};
+        if (!bpv_launch(e, st, c, results + p0, sh, proofs + p0 * proof_len, proof_len, transcripts + 104 * p0, rho + 32 * p0, gens33_dev, gens33_host,
+                        c_vec + 32 * c_vec_len * p0, commits33 + 33 * p0, m)) return 0;
+    }
+    return 1;
+}
+extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* results, const unsigned char* proofs, size_t proof_len,
+                                                        const unsigned char* transcripts, const unsigned char* rho, const unsigned char* gens33,
+                                                        size_t n_gens, size_t g_len, const unsigned char* c_vec, size_t c_vec_len,
+                                                        const unsigned char* commits33, size_t n) {
+    if (!e) return s2k_fail("secp256k1_bppp_norm_product_verify_batch", "null engine");
+    if (n == 0) return 1;
+    memset(results, 0, sizeof(int32_t) * n);
+    bp_shape sh;
+    if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) return 1;   // :446-461: every item 0
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t per = std::max<size_t>(1, e->max_lanes / sh.n_terms);
+    const size_t inner = bpv_ws_bytes(std::min(n, per), sh);
+    if (!engine_workspace(e, inner + ws_need({4 * n, n * proof_len + 64, 104 * n, 32 * n, 33 * n_gens, 32 * c_vec_len * n, 33 * n}))) return 0;
+    ws_carver c{e->ws, inner};
+    int32_t* d_res = c.take<int32_t>(n); unsigned char* d_pr = c.take<unsigned char>(n * proof_len + 64); unsigned char* d_tr = c.take<unsigned char>(104 * n);
+    unsigned char* d_rho = c.take<unsigned char>(32 * n); unsigned char* d_g33 = c.take<unsigned char>(33 * n_gens);
+    unsigned char* d_cv = c.take<unsigned char>(32 * c_vec_len * n); unsigned char* d_cm = c.take<unsigned char>(33 * n);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(d_pr, proofs, n * proof_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_tr, transcripts, 104 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rho, rho, 32 * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_g33, gens33, 33 * n_gens, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cv, c_vec, 32 * c_vec_len * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cm, commits33, 33 * n, hipMemcpyHostToDevice, st));
+    if (!secp256k1_bppp_norm_product_verify_batch_dev(e, nullptr, d_res, d_pr, proof_len, d_tr, d_rho, d_g33, gens33, n_gens, g_len, d_cv, c_vec_len, d_cm, n)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
 }
-
 
 // ---- secp256k1_bppp_commit, batched (bppp.h) ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
@@ -1533,30 +1589,18 @@ __global__ void k_ha_final(int32_t* result, const u32* flags, const u32* res28) 
     if (threadIdx.x || blockIdx.x) return;
     *result = (flags[0] == 0u) && (res28[27] != 0u);
 }
-extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32,
-                                                  size_t n, const unsigned char* aggsig, size_t aggsig_len) {
-    if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "null engine");
-    if (!result || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail_arg("secp256k1_schnorrsig_aggverify_amd", "illegal argument (ARG_CHECK)");
-    *result = 0;
-    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 1;          // main_impl.h:122-125
-    std::lock_guard<std::recursive_mutex> lock(e->mu);
-    HIPCHK(hipSetDevice(e->device));
-    const size_t pkb = pk_format ? 64 : 32, nblocks = (3 * n) >> 1, nt = 2 * n + 1;
-    const msm_plan pl = msm_make_plan(nt);
-    const size_t own = ws_need({pkb * n + 64, 32 * n + 64, 32 * (n + 1), 128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16});
-    if (!engine_workspace(e, own + msm_ws_bytes(nt + 1, pl))) return 0;
-    ws_carver c{e->ws, 0};
-    unsigned char* d_pk = c.take<unsigned char>(pkb * n + 64); unsigned char* d_msg = c.take<unsigned char>(32 * n + 64);
-    unsigned char* d_agg = c.take<unsigned char>(32 * (n + 1)); unsigned char* d_pts = c.take<unsigned char>(128 * n + 64);
+static size_t ha_ws_bytes(size_t n) {
+    const size_t nblocks = (3 * n) >> 1, nt = 2 * n + 1;
+    return ws_need({128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16}) + msm_ws_bytes(nt + 1, msm_make_plan(nt));
+}
+// device pointers in, verdict to d_res[0]; aggsig_len already checked to be 32 (n + 1)
+static int ha_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res, const unsigned char* d_pk, int pk_format, const unsigned char* d_msg, size_t n,
+                     const unsigned char* d_agg) {
+    const size_t nblocks = (3 * n) >> 1;
+    unsigned char* d_pts = c.take<unsigned char>(128 * n + 64);
     unsigned char* d_pkx = c.take<unsigned char>(32 * n + 64); u32* d_wk = c.take<u32>(nblocks * 64 + 16); u32* d_states = c.take<u32>(nblocks * 8 + 16);
     unsigned char* d_sc = c.take<unsigned char>(64 * n + 64); unsigned char* d_g = c.take<unsigned char>(64); u32* d_flags = c.take<u32>(16);
-    int32_t* d_res = c.take<int32_t>(4);
-    hipStream_t st = e->stream;
-    if (n) {
-        HIPCHK(hipMemcpyAsync(d_pk, pubkeys, pkb * n, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_msg, msgs32, 32 * n, hipMemcpyHostToDevice, st));
-    }
-    HIPCHK(hipMemcpyAsync(d_agg, aggsig, 32 * (n + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_res, 0, 4, st));
     HIPCHK(hipMemsetAsync(d_flags, 0, 64, st));
     HIPCHK(hipEventRecord(e->ev[0], st));
     const unsigned bn = (unsigned)((n + 255) / 256);
@@ -1573,6 +1617,43 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     hipLaunchKernelGGL(k_ha_final, dim3(1), dim3(64), 0, st, d_res, d_flags, res28);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
+    return 1;
+}
+// every array in HBM, the verdict lands in result_dev[0] (stream-ordered)
+extern "C" int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, int32_t* result_dev, const unsigned char* pubkeys, int pk_format,
+                                                  const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_dev", "null engine");
+    if (!result_dev || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail_arg("secp256k1_schnorrsig_aggverify_dev", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) { HIPCHK(hipMemsetAsync(result_dev, 0, 4, st)); return 1; }     // main_impl.h:122-125
+    if (!engine_workspace(e, ha_ws_bytes(n))) return 0;
+    ws_carver c{e->ws, 0};
+    return ha_launch(e, st, c, result_dev, pubkeys, pk_format, msgs32, n, aggsig);
+}
+extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32,
+                                                  size_t n, const unsigned char* aggsig, size_t aggsig_len) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_amd", "null engine");
+    if (!result || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail_arg("secp256k1_schnorrsig_aggverify_amd", "illegal argument (ARG_CHECK)");
+    *result = 0;
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 1;          // main_impl.h:122-125
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    const size_t pkb = pk_format ? 64 : 32;
+    const size_t io = ws_need({pkb * n + 64, 32 * n + 64, 32 * (n + 1), 16});
+    if (!engine_workspace(e, ha_ws_bytes(n) + io)) return 0;
+    ws_carver c0{e->ws, ha_ws_bytes(n)};
+    unsigned char* d_pk = c0.take<unsigned char>(pkb * n + 64); unsigned char* d_msg = c0.take<unsigned char>(32 * n + 64);
+    unsigned char* d_agg = c0.take<unsigned char>(32 * (n + 1)); int32_t* d_res = c0.take<int32_t>(4);
+    hipStream_t st = e->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(d_pk, pubkeys, pkb * n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_msg, msgs32, 32 * n, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(d_agg, aggsig, 32 * (n + 1), hipMemcpyHostToDevice, st));
+    ws_carver c{e->ws, 0};
+    if (!ha_launch(e, st, c, d_res, d_pk, pk_format, d_msg, n, d_agg)) return 0;
     HIPCHK(hipMemcpyAsync(result, d_res, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
@@ -1599,12 +1680,14 @@ __global__ void k_pt_final(int32_t* results, const u32* sums28, const u32* off_l
     if (off_last[t + 1] > off_last[t]) inf = (int)sums28[(size_t)off_last[t] * 28 + 27];
     results[t] = inf && !bad[t];
 }
-extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off,
-                                                     const uint64_t* n_pos, size_t n_tallies) {
+// dev = 1: `results` and `commits33` are device pointers (the two small offset arrays always come from the host: the run
+// lengths of every partial-sum round are derived from them before anything is launched) and nothing is read back
+static int tally_impl(s2k_engine* e, void* stream, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off,
+                      const uint64_t* n_pos, size_t n_tallies, int dev) {
     if (!e) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "null engine");
     if (n_tallies == 0) return 1;
     if (!results || !tally_off || !n_pos) return s2k_fail_arg("secp256k1_pedersen_verify_tally_batch", "illegal argument (ARG_CHECK)");
-    memset(results, 0, sizeof(int32_t) * n_tallies);
+    if (!dev) memset(results, 0, sizeof(int32_t) * n_tallies);
     const size_t total = (size_t)tally_off[n_tallies];
     if (total >= ((size_t)1 << 32)) return s2k_fail("secp256k1_pedersen_verify_tally_batch", "more than 2^32 commitments in one call");
     for (size_t t = 0; t < n_tallies; t++)
@@ -1632,12 +1715,14 @@ extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* res
     unsigned long long* d_np = c.take<unsigned long long>(n_tallies + 1); int32_t* d_res = c.take<int32_t>(n_tallies); u32* d_bad = c.take<u32>(n_tallies + 1);
     std::vector<u32*> d_offs; for (size_t r = 0; r < offs.size(); r++) d_offs.push_back(c.take<u32>(n_tallies + 1));
     u32* bufA = c.take<u32>((total + 1) * 28); u32* bufB = c.take<u32>((half + 1) * 28);
-    hipStream_t st = e->stream;
-    if (total) HIPCHK(hipMemcpyAsync(d_c, commits33, 33 * total, hipMemcpyHostToDevice, st));
+    hipStream_t st = (dev && stream) ? (hipStream_t)stream : e->stream;
+    if (dev) { d_c = (unsigned char*)commits33; d_res = results; }
+    else if (total) HIPCHK(hipMemcpyAsync(d_c, commits33, 33 * total, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, tally_off, 8 * (n_tallies + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_np, n_pos, 8 * n_tallies, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_bad, 0, 4 * (n_tallies + 1), st));
     for (size_t r = 0; r < offs.size(); r++) HIPCHK(hipMemcpyAsync(d_offs[r], offs[r].data(), 4 * (n_tallies + 1), hipMemcpyHostToDevice, st));
+    if (dev) HIPCHK(hipEventRecord(e->ev_fork, st));           // the host-side offset arrays must have been consumed before this call returns
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
     if (total) hipLaunchKernelGGL(k_pt_load, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bufA, d_bad, d_c, d_off, d_np, n_tallies, total);
     HIPCHK(hipEventRecord(e->ev[3], st));
@@ -1650,9 +1735,18 @@ extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* res
     hipLaunchKernelGGL(k_pt_final, dim3((unsigned)((n_tallies + 255) / 256)), dim3(256), 0, st, d_res, pin, d_offs.back(), d_bad, n_tallies);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
+    if (dev) { HIPCHK(hipEventSynchronize(e->ev_fork)); return 1; }
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n_tallies, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
+}
+extern "C" int secp256k1_pedersen_verify_tally_batch(s2k_engine* e, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off,
+                                                     const uint64_t* n_pos, size_t n_tallies) {
+    return tally_impl(e, nullptr, results, commits33, tally_off, n_pos, n_tallies, 0);
+}
+extern "C" int secp256k1_pedersen_verify_tally_batch_dev(s2k_engine* e, void* stream, int32_t* results, const unsigned char* commits33, const uint64_t* tally_off_host,
+                                                         const uint64_t* n_pos_host, size_t n_tallies) {
+    return tally_impl(e, stream, results, commits33, tally_off_host, n_pos_host, n_tallies, 1);
 }
 
 // pre-size the workspace for batches of n_items rangeproofs (optional: every call grows it on demand)

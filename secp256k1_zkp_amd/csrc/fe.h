@@ -419,15 +419,18 @@ S2K_HD void fe_muladd(fe& r, const fe& a1_in, const fe& b1_in, const fe& a2_in, 
 }
 
 // ---- exponentiation chains ------------------------------------------------------------------------
-// r = x^(2^n) * y  -- the only place the chains below instantiate fe_sqr/fe_mul, kept out of line so that
-// an inversion costs ~15 calls instead of ~36 KB of inlined code.
-S2K_HD_NOINLINE void fe_sqrn_mul(fe& r, const fe& x, int n, const fe& y) {
+// r = x^(2^n) * y.  Inlined, with the run of squarings as a rolled loop: one fe_sqr body per call site (~1 KB of code each)
+// instead of a call whose register spills around it cost more than the squarings' own bookkeeping (the out-of-line form
+// left k_rp_lift with 448 bytes of scratch per lane).
+S2K_HD void fe_sqrn_mul(fe& r, const fe& x, int n, const fe& y) {
     fe t = x;
+#pragma unroll 1
     for (int i = 0; i < n; i++) fe_sqr(t, t);
     fe_mul(r, t, y);
 }
-S2K_HD_NOINLINE void fe_sqrn(fe& r, const fe& x, int n) {
+S2K_HD void fe_sqrn(fe& r, const fe& x, int n) {
     fe t = x;
+#pragma unroll 1
     for (int i = 0; i < n; i++) fe_sqr(t, t);
     r = t;
 }

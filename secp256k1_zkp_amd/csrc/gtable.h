@@ -3,10 +3,10 @@
 // Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
 // src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine with
 // 288 GB of HBM that would rather gather 64 bytes than execute doublings: entry (w, v) = v * 2^(B w) * G for every B-bit
-// value of every window of a scalar (B = S2K_GTAB_BITS = 20: 13 windows), as one aligned 64-byte sector of canonical words
-// (affine x, y), so ng*G is 13 mixed additions and zero doublings.  13 x 2^20 entries x 64 B = 872 MB; the gathers are issued one
+// value of every window of a scalar (B = S2K_GTAB_BITS = 24: 11 windows), as one aligned 64-byte sector of canonical words
+// (affine x, y), so ng*G is 11 mixed additions and zero doublings.  11 x 2^24 entries x 64 B = 11.8 GB; the gathers are issued one
 // addition ahead, so their HBM latency is covered.  The table is *computed on the device* when an engine is created (two
-// kernels, ~30 ms), never shipped as data.
+// kernels, ~0.4 s), never shipped as data.
 #pragma once
 #include "ecmult.h"
 

@@ -41,6 +41,8 @@ struct rp_ws {           // device pointers into the engine workspace
     rp_rec* rec;         // [n]
     u32* bases;          // [n][32][28]
     u32* pub0;           // [n][32][28]
+    u32* dbases;         // [n][32][28]  2^64 * B_i : the step of T = 2^64 * key from one ring position to the next (ecmult_lane_split)
+    u32* tcur;           // [n][32][28]  2^64 * (current key of the ring)
     unsigned char* lift_ok;   // [n][32]
     unsigned char* ring_out;  // [n][RP_RING_OUT_BYTES]: the rings' 33-byte outputs back to back, then room for m
     unsigned char* ring_ok;   // [n][32]
@@ -183,7 +185,7 @@ S2K_HD void rp_pp_hash(rp_rec& rec, const unsigned char* commit33, const unsigne
     for (int i = 0; i < 8; i++) rec.m[i] = s2k_load_be32(m + 4 * i);
 }
 // C: ring bases: base_0 = -(10^exp) H, base_{i+1} = 4 base_i   (pub_expand, rangeproof_impl.h:20-51)
-S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsigned char* gen64) {
+S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsigned char* gen64, u32* dbases = nullptr /*[32][28]*/) {
     if (!(rec.hdr & 1u)) return;
     const u32 rings = rec.rings;
     const int exp = (int)((rec.hdr >> 8) & 0xFFu) - 1;
@@ -195,25 +197,31 @@ S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsign
         gej_double(t2, base); gej_double(t8, t2); gej_double(s, t8);
         gej_add_var(base, s, t2);
     }
+    gej dcur = base;                         // 2^64 * B_0, then the same x4 chain: the keys' 2^64-multiples step by these
+    if (dbases) for (int k = 0; k < 64; k++) { gej t; gej_double(t, dcur); dcur = t; }
     for (u32 i = 0; i < rings; i++) {
         gej_store28_h(bases + RP_GEJ_WORDS * i, base);
-        if (i + 1 < rings) { gej t; gej_double(t, base); gej_double(base, t); }
+        if (dbases) gej_store28_h(dbases + RP_GEJ_WORDS * i, dcur);
+        if (i + 1 < rings) {
+            gej t; gej_double(t, base); gej_double(base, t);
+            if (dbases) { gej_double(t, dcur); gej_double(dcur, t); }
+        }
     }
 }
 S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value, const unsigned char* commit33,
-                               const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+                               const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64, u32* dbases = nullptr) {
     if (!(rec.hdr & 1u)) return;
     rp_pp_commit(rec, min_value, commit33, gen64);
     rp_pp_hash(rec, commit33, proof, extra, extra_len, gen64);
-    rp_pp_bases(rec, bases, gen64);
+    rp_pp_bases(rec, bases, gen64, dbases);
     rec.ok = 1;
 }
 
 // both halves back to back (host emulation, tests)
 S2K_HD void rp_prologue(rp_rec& rec, u32* bases, u64* min_value, u64* max_value, const unsigned char* commit33,
-                        const unsigned char* proof, u64 plen, const unsigned char* extra, u64 extra_len, const unsigned char* gen64) {
+                        const unsigned char* proof, u64 plen, const unsigned char* extra, u64 extra_len, const unsigned char* gen64, u32* dbases = nullptr) {
     rp_header(rec, min_value, max_value, proof, plen);
-    rp_prologue_points(rec, bases, *min_value, commit33, proof, extra, extra_len, gen64);
+    rp_prologue_points(rec, bases, *min_value, commit33, proof, extra, extra_len, gen64, dbases);
 }
 
 // ---- K1: lift the ring commitments (rangeproof_impl.h:609-626) ------------------------------------------------
@@ -300,8 +308,11 @@ S2K_HD void rp_hash_step(u32 out[8], u32 prefix, const u32 x[8], const u32 m[8],
 
 // ev_out (optional): the challenge e of each ring position, 4 x 8 big-endian words per ring -- the reference's `evalues`
 // (borromean_impl.h:80-83), which only rewinding needs (rangeproof_rewind.h)
+// dbase28 / t28 (optional, both or neither): 2^64 * base and a scratch record for 2^64 * key, which let the double multiplication
+// run in its two-piece form (ecmult_lane_split: half the doublings).  2^64 * (first key) costs one 64-doubling chain per ring here.
 S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
-                    const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm, u32* ev_out = nullptr) {
+                    const unsigned char* proof, u32 ring, int live, const u32* gtab, const lane_mem& lm, u32* ev_out = nullptr,
+                    const u32* dbase28 = nullptr, u32* t28 = nullptr) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
     u32 e[8];
@@ -320,6 +331,15 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
     // Nothing but flags and pointers stays live across ecmult_lane: the ring key is re-read from its scratch record and the
     // next key (key + base, pub_expand :43-45) is written back there before the multiplication starts.
     u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
+    if (t28) {
+        gej t; gej_load28_h(t, pub28);
+        const int tinf = t.inf; t.inf = 0;
+#pragma unroll 1
+        for (int k = 0; k < 64; k++) gej_double_lean(t, t);
+        fe_norm_weak(t.y);
+        t.inf = tinf;
+        if (live) gej_store28_h(t28, t);
+    }
     S2K_PROF_DECL;
 #pragma unroll 1
     for (u32 j = 0; j < 4; j++) {
@@ -332,14 +352,18 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
         gej pub; gej_load28_h(pub, pub28);
         int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens) & !pub.inf;
         if (!good) { sc_set_zero(ens); sc_set_zero(s); }            // dead lanes ride along with empty work
+        gej T; if (t28) gej_load28_h(T, t28);
         if (j + 1 < rsize) {
             gej base, nxt; gej_load28_h(base, base28);
             gej_add_var(nxt, pub, base);
             if (live) gej_store28_h(pub28, nxt);
+            if (t28) { gej_load28_h(base, dbase28); gej_add_var(nxt, T, base); if (live) gej_store28_h(t28, nxt); }
         }
         gej R;
         S2K_PROF_MARK(0);
-        ecmult_lane(R, pub, ens, s, 1, gtab, lm);
+        int split_done = 0;
+        if (t28) split_done = ecmult_lane_split(R, pub, T, ens, s, 1, gtab, lm);
+        if (!S2K_WAVE_ALL(split_done)) ecmult_lane(R, pub, ens, s, 1, gtab, lm);
         S2K_PROF_RESET;
         good &= !R.inf;
         ge a; ge_set_gej(a, R);

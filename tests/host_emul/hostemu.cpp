@@ -4,6 +4,8 @@
 // check every field/scalar/group/ecmult primitive against the reference before any GPU time is spent.
 // This library is never loaded by the product; the shipped path is HIP only.
 #define S2K_VERIFY 1
+static unsigned long long g_split_done = 0;
+#define S2K_ON_SPLIT_DONE() (g_split_done++)
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
@@ -81,7 +83,7 @@ int emu_ge_set_xquad(unsigned char* r64, const unsigned char* x32) {
 }
 
 static std::vector<u32> g_gtab;
-static u32 g_ptab[S2K_PTAB_WORDS];
+static u32 g_ptab[S2K_PTAB_WORDS];          // (two tables' worth: the split form of the double multiplication uses both)
 static u32 g_dig[S2K_DIG_WORDS];
 static const lane_mem g_lm{g_ptab, g_dig};
 // Host-only construction of the window table (this library is compiled with -DS2K_GTAB_BITS=12 to keep it small): same entries as gtable.h's device kernels, but built by running
@@ -132,16 +134,20 @@ void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
     sha256_stream c; sha256_stream_init(c); sha256_stream_write(c, msg, len); sha256_stream_finalize(c, out32);
 }
 
+unsigned long long emu_split_count(void) { return g_split_done; }
+
 // the five rangeproof stages of rangeproof.h run back to back for one proof
 int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
                           const unsigned char* extra, size_t extra_len, const unsigned char* gen64) {
-    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0); unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0);
+    unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
     u64 mn, mx;
-    rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, extra_len ? extra : nullptr, extra_len, gen64);
+    rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, extra_len ? extra : nullptr, extra_len, gen64, dbases.data());
     *min_value = mn; *max_value = mx;
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
-    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm);
+    for (u32 i = 0; i < 32; i++) rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, nullptr,
+                                         dbases.data() + 28 * i, tcur.data() + 28 * i);
     return rp_final(rec, ring_out, ring_ok, proof);
 }
 

@@ -129,9 +129,12 @@ def test_emu_rangeproof(emu, ref):
     rng = np.random.default_rng(3)
     vecs = _golden("rangeproof_vectors.json")["vectors"]
     gh = np.frombuffer(GENERATOR_H, np.uint8)
+    emu.emu_split_count.restype = ctypes.c_ulonglong
+    split0 = emu.emu_split_count()
     for v in vecs:
         r = _emu_rp(emu, np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8), bytes.fromhex(v["proof"]), gh)
         assert r == (v["result"], int(v["min_value"]), int(v["max_value"])), v["name"]
+    assert emu.emu_split_count() > split0          # the ring steps really took the two-piece form of the double multiplication (ecmult_lane_split)
     for (mb, exp, minv, n) in ((64, 0, 0, 1), (5, 2, 17, 1), (1, 0, 0, 1), (13, 3, 1000, 1)):
         commits, plist, gens, _ = ref.make_rangeproofs(n, rng, min_bits=mb, exp=exp, min_value=minv)
         res, mn, mx = ref.rangeproof_verify_many(commits, plist, gens)

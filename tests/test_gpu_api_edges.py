@@ -50,3 +50,27 @@ def test_reserve_and_reuse(engine, ref):
     a = engine.rangeproof_verify_batch(c, p, g)
     b = engine.rangeproof_verify_batch(c, p, g)                 # same buffers reused, same verdicts
     assert a[0].all() and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
+def test_wrong_shaped_host_arrays_raise(engine, ref):
+    """the host wrappers derive n from one array; every other array is checked against it before anything reaches hipMemcpy"""
+    rng = np.random.default_rng(6)
+    c, p, g, _ = ref.make_rangeproofs(3, rng, min_bits=8)
+    with pytest.raises(ValueError):
+        engine.rangeproof_verify_batch(c[:2], p, g)
+    with pytest.raises(ValueError):
+        engine.rangeproof_verify_batch(c, p, g[:, :63])
+    data, off = engine.pack(list(p)); off2 = off.copy(); off2[1], off2[2] = off[2], off[1]
+    with pytest.raises(ValueError):
+        engine.rangeproof_verify_batch(c, (data, off2), g)
+    with pytest.raises(ValueError):
+        engine.rangeproof_verify_batch(c, (data[:-5], off), g)
+    sigs, msgs, pks = ref.make_schnorr(4, rng)
+    with pytest.raises(ValueError):
+        engine.schnorrsig_verify_batch(sigs, msgs[:3], pks)
+    with pytest.raises(ValueError):
+        engine.schnorrsig_verify_batch(sigs, msgs, pks[:, :31])
+    with pytest.raises(ValueError):
+        engine.ecmult_multi(np.zeros((4, 32), np.uint8), np.zeros((3, 64), np.uint8))
+    with pytest.raises(ValueError):
+        engine.ecmult_batch(np.zeros((4, 64), np.uint8), np.zeros((4, 31), np.uint8))

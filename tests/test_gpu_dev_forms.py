@@ -1,0 +1,104 @@
+"""GPU tier: the `_dev` entry points (every array already in HBM, stream-ordered, nothing read back) of BP++ verify, BP++ commit,
+half-aggregate verify, Pedersen tallies and rangeproof rewind give exactly what the host forms give -- which the other GPU tests pin
+against the reference."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _d(a):
+    import torch
+    return torch.tensor(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def test_bppp_verify_and_commit_dev(engine, ref):
+    import torch
+    L = engine._lib
+    rng = np.random.default_rng(901)
+    proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(6, rng, 16, 4)
+    proofs[2, 80] ^= 1
+    exp = engine.bppp_norm_product_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits)
+    assert list(exp) == [1, 1, 0, 1, 1, 1]
+    res = torch.full((6,), 7, dtype=torch.int32, device="cuda")
+    dp, dt, dr, dg, dc, dm = _d(proofs), _d(trs), _d(rhos), _d(gens), _d(cvs), _d(commits)
+    torch.cuda.synchronize()
+    g_host = np.ascontiguousarray(gens)
+    ok = L.secp256k1_bppp_norm_product_verify_batch_dev(engine._h, None, _p(res), _p(dp), proofs.shape[1], _p(dt), _p(dr), _p(dg), g_host.ctypes.data_as(ctypes.c_void_p),
+                                                        gens.shape[0], gl, _p(dc), cvs.shape[1], _p(dm), 6)
+    assert ok == 1 and L.s2k_engine_sync(engine._h) == 1
+    assert np.array_equal(res.cpu().numpy(), exp)
+    # commit
+    sc = lambda *shape: (rng.integers(0, 256, shape + (32,), dtype=np.uint8) & np.array([0x7F] + [0xFF] * 31, np.uint8))
+    nv, lv, cv, mu = sc(5, 16), sc(5, 4), sc(5, 4), sc(5)
+    ehost, okh = engine.bppp_commit_batch(gens, 16, nv, lv, cv, mu)
+    out = torch.zeros(5 * 33, dtype=torch.uint8, device="cuda"); r2 = torch.zeros(5, dtype=torch.int32, device="cuda")
+    dn, dl, dcv, dmu = _d(nv), _d(lv), _d(cv), _d(mu)
+    torch.cuda.synchronize()
+    ok = L.secp256k1_bppp_commit_batch_dev(engine._h, None, _p(out), _p(r2), _p(dg), g_host.ctypes.data_as(ctypes.c_void_p), gens.shape[0], 16, _p(dn), _p(dl), _p(dcv), 4, _p(dmu), 5)
+    assert ok == 1 and L.s2k_engine_sync(engine._h) == 1
+    assert np.array_equal(out.cpu().numpy().reshape(5, 33), ehost) and r2.cpu().numpy().all() and okh.all()
+
+
+def test_halfagg_tally_rewind_dev(engine, ref):
+    import torch
+    L = engine._lib
+    rng = np.random.default_rng(902)
+    # half-aggregate
+    n = 40
+    sigs, msgs, pks = ref.make_schnorr(n, rng)
+    agg = ref.halfagg_aggregate(pks, msgs, sigs)
+    for mutate in (0, 1):
+        a = bytearray(agg)
+        if mutate:
+            a[37] ^= 1
+        a = bytes(a)
+        exp = engine.schnorrsig_aggverify(pks, msgs, a)
+        r = torch.full((4,), 9, dtype=torch.int32, device="cuda")
+        dpk, dm, da = _d(pks), _d(msgs), _d(np.frombuffer(a, np.uint8))
+        torch.cuda.synchronize()
+        assert L.secp256k1_schnorrsig_aggverify_dev(engine._h, None, _p(r), _p(dpk), 0, _p(dm), n, _p(da), len(a)) == 1
+        assert L.s2k_engine_sync(engine._h) == 1
+        assert int(r[0].item()) == exp == (0 if mutate else 1)
+    r = torch.full((4,), 9, dtype=torch.int32, device="cuda")
+    assert L.secp256k1_schnorrsig_aggverify_dev(engine._h, None, _p(r), _p(dpk), 0, _p(dm), n, _p(da), len(a) - 1) == 1      # wrong length: verdict 0
+    assert L.s2k_engine_sync(engine._h) == 1 and int(r[0].item()) == 0
+    # tallies
+    tallies = [ref.make_balanced_tally(rng, 2, 3), ref.make_balanced_tally(rng, 9, 1), ref.make_balanced_tally(rng, 1, 1)]
+    a_, b_ = ref.make_balanced_tally(rng, 2, 2); tallies.append((a_, b_[:1]))
+    exp = engine.pedersen_verify_tally_batch(tallies)
+    parts, off, npos = [], [0], []
+    for pos, neg in tallies:
+        parts += [pos, neg]; npos.append(pos.shape[0]); off.append(off[-1] + pos.shape[0] + neg.shape[0])
+    dcm = _d(np.concatenate(parts)); off = np.array(off, np.uint64); npos = np.array(npos, np.uint64)
+    r = torch.full((len(tallies),), 5, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert L.secp256k1_pedersen_verify_tally_batch_dev(engine._h, None, _p(r), _p(dcm), off.ctypes.data_as(ctypes.c_void_p), npos.ctypes.data_as(ctypes.c_void_p), len(tallies)) == 1
+    assert L.s2k_engine_sync(engine._h) == 1
+    assert np.array_equal(r.cpu().numpy(), exp) and list(exp) == [1, 1, 1, 0]
+    # rewind
+    commits, plist, gens, values, blinds, nonces, msgs_ = ref.make_rangeproofs_msg(5, rng, msg_len=40, min_bits=32)
+    nonces2 = nonces.copy(); nonces2[3, 0] ^= 1
+    eh = engine.rangeproof_rewind_batch(commits, plist, gens, nonces2, msg_capacity=128)
+    data, poff = engine.pack(plist)
+    m = len(plist)
+    res = torch.zeros(m, dtype=torch.int32, device="cuda"); bl = torch.zeros(m * 32, dtype=torch.uint8, device="cuda"); val = torch.zeros(m, dtype=torch.int64, device="cuda")
+    msg = torch.zeros(m * 128, dtype=torch.uint8, device="cuda"); ol = torch.full((m,), 128, dtype=torch.int64, device="cuda")
+    mn = torch.zeros(m, dtype=torch.int64, device="cuda"); mx = torch.zeros(m, dtype=torch.int64, device="cuda")
+    dno, dc, dpr, dgen = _d(nonces2), _d(commits), _d(np.concatenate([data, np.zeros(64, np.uint8)])), _d(gens)
+    doff = torch.tensor(poff.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    assert L.secp256k1_rangeproof_rewind_batch_dev(engine._h, None, _p(res), _p(bl), _p(val), _p(msg), _p(ol), 128, _p(dno), _p(mn), _p(mx), _p(dc), _p(dpr), _p(doff),
+                                                   None, None, _p(dgen), m) == 1
+    assert L.s2k_engine_sync(engine._h) == 1
+    r = res.cpu().numpy()
+    assert np.array_equal(r, eh[0]) and list(r) == [1, 1, 1, 0, 1]
+    assert np.array_equal(bl.cpu().numpy().reshape(m, 32), eh[1]) and np.array_equal(val.cpu().numpy().view(np.uint64), eh[2])
+    got_msgs = [msg.cpu().numpy().reshape(m, 128)[i, :int(ol[i].item())].tobytes() if r[i] else b"" for i in range(m)]
+    assert got_msgs == eh[3]

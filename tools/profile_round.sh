@@ -1,26 +1,54 @@
+# One round's evidence on the GPU box: rocprofv3 kernel stats, HBM-side traffic (separate --pmc passes), SQ issue counters
+# (separate --pmc passes), the plain default bench line, secondary throughputs and the MSM size sweep.
+#   usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...   (copy the summaries to profiles/<tag>_*)
 set -x
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01h
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2>$O/stats.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$O/fetch.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$O/write.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm > /dev/null 2>$O/fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm > /dev/null 2>$O/write.err
+i=0
+for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_FLAT" ; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/sq$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm > /dev/null 2>$O/sq$i.err
+done
 cd $R
-find gpurun_out/r01h -name "*.csv" | head -20
-cp $(find gpurun_out/r01h/stats -name "*kernel_stats.csv" | head -1) gpurun_out/r01h/kernel_stats.csv
-python - <<'PY'
-import csv, glob, json, collections
-out = {}
-for tag in ("fetch", "write"):
-    f = glob.glob("gpurun_out/r01h/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
-    if not f: print("no counter file", tag); continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in sorted(agg.items()):
-        if k.startswith("k_"): out["%s:%s" % (k, c)] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
-json.dump(out, open("gpurun_out/r01h/pmc_summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats.csv
+python - "$TAG" <<'PY'
+import csv, glob, json, collections, sys
+tag = sys.argv[1]
+def collect(pattern, prefix="k_"):
+    out = {}
+    for f in glob.glob(pattern, recursive=True):
+        agg = collections.defaultdict(list); dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "Start_Timestamp" in r: dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for (k, c), v in sorted(agg.items()):
+            if k.startswith(prefix): out.setdefault(k, {})[c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+        for k, v in dur.items():
+            if k.startswith(prefix) and k in out: out[k]["kernel_ns_under_profiler"] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+    return out
+mem = collect("gpurun_out/%s/pmc_*/**/*counter_collection.csv" % tag)
+rr = mem.get("k_rp_rings", {})
+if "FETCH_SIZE" in rr and "WRITE_SIZE" in rr:
+    f, w = rr["FETCH_SIZE"]["mean_per_launch"], rr["WRITE_SIZE"]["mean_per_launch"]
+    json.dump({"kernel": "k_rp_rings", "FETCH_SIZE_kb_per_launch": f, "WRITE_SIZE_kb_per_launch": w, "hbm_bytes_per_launch_raw": (f + w) * 1024,
+               "hbm_bytes_per_launch_fetch_x2": (2 * f + w) * 1024,
+               "note": "separate --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE can read half of a wide stream on gfx950 -> the x2 figure is the upper bound); counters include Infinity-Cache hits; batch of 16384 proofs"},
+              open("gpurun_out/%s/pmc_rp_rings.json" % tag, "w"), indent=1)
+sq = collect("gpurun_out/%s/sq*/**/*counter_collection.csv" % tag)
+json.dump(sq, open("gpurun_out/%s/sq_counters.json" % tag, "w"), indent=1)
+r = sq.get("k_rp_rings", {})
+if "GRBM_GUI_ACTIVE" in r and "kernel_ns_under_profiler" in r:
+    print("effective clock GHz:", r["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 / r["kernel_ns_under_profiler"]["mean_per_launch"])
+print(json.dumps(r, indent=1)[:2500])
 PY
-timeout 400 python bench.py > gpurun_out/r01h/bench_default.json 2> gpurun_out/r01h/bench_default.err; tail -1 gpurun_out/r01h/bench_default.json | cut -c1-1500
+timeout 600 python bench.py > gpurun_out/$TAG/bench_default.json 2> gpurun_out/$TAG/bench_default.err; tail -1 gpurun_out/$TAG/bench_default.json | cut -c1-600
+timeout 600 python tests/tools/throughput.py > gpurun_out/$TAG/throughput.json 2> gpurun_out/$TAG/throughput.err; tail -5 gpurun_out/$TAG/throughput.json
+timeout 300 python tests/tools/msm_sweep.py > gpurun_out/$TAG/msm_sweep.txt 2>&1; tail -20 gpurun_out/$TAG/msm_sweep.txt
