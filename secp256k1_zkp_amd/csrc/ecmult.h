@@ -52,6 +52,13 @@ S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
 // is exactly ONE aligned 64-byte gather (the per-lane tables of all resident waves live in the Infinity Cache, not L2:
 // every gather crosses the fabric, so sectors are what is paid for).  During construction the same 128 bytes hold the
 // 27 limbs (x, y, z-ratio) of the not-yet-rescaled entry.
+// S2K_PTAB_TWINS = 0 (default): only [ x | y ] is kept and an operand for the lambda half costs one multiplication by beta when it
+// is decoded.  The finished tables of a lane are then 16 sectors = 1 KB (two-piece form) instead of 2 KB, i.e. 134 MB instead of
+// 268 MB for the 131 072 resident lanes of a rangeproof launch -- inside the 256 MB Infinity Cache instead of just beyond it -- and
+// the rescaling pass saves one product, one normalisation and half of its stores per entry.  S2K_PTAB_TWINS = 1 keeps [ beta*x | y ].
+#ifndef S2K_PTAB_TWINS
+#define S2K_PTAB_TWINS 0
+#endif
 #define S2K_PTAB_ENTRIES 8
 #define S2K_PTAB_ENTRY_WORDS 32
 #define S2K_PTAB_TABLE_WORDS (S2K_PTAB_ENTRIES * S2K_PTAB_ENTRY_WORDS)
@@ -102,17 +109,19 @@ S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) {
     ziso = zc;
 }
 S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
-    fe beta; fe_set_beta(beta);
     fe zs; if (zs0) zs = *zs0; else fe_set_int(zs, 1);
-    // the parked entry of step i-1 is requested before the arithmetic of step i (each is a dependent round trip to L2 otherwise)
+    // The parked entry of step i-1 is requested before the arithmetic of step i and taken over after it (the first use of the loaded
+    // words is where the wait lands; x, y, h are a second register set, so no copy of in-flight data sits at the loop head).  Exactly
+    // 27 words are loaded: a 28th, dead, destination register would be recycled by the allocator while the load is in flight, and
+    // the write-after-write hazard then puts a full wait right behind the request.
     u32 nraw[27];
+    fe x, y, h;
 #pragma unroll
     for (int k = 0; k < 27; k++) nraw[k] = tab[(S2K_PTAB_ENTRIES - 1) * S2K_PTAB_ENTRY_WORDS + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
     for (int i = S2K_PTAB_ENTRIES - 1; i >= 0; i--) {
         u32* e = tab + i * S2K_PTAB_ENTRY_WORDS;
-        fe x, y, h, bx;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
         if (i > 0) {
 #pragma unroll
             for (int k = 0; k < 27; k++) nraw[k] = e[k - S2K_PTAB_ENTRY_WORDS];
@@ -121,13 +130,27 @@ S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
             fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
             fe_mul(x, x, zs2); fe_mul(y, y, zs3);
         }
-        fe_mul(bx, x, beta);
-        fe_normalize(x); fe_normalize(y); fe_normalize(bx);
-        u32 wx[8], wy[8], wb[8];
-        fe_to_words(wx, x); fe_to_words(wy, y); fe_to_words(wb, bx);
+        fe_normalize(x); fe_normalize(y);
+        u32 wx[8], wy[8];
+        fe_to_words(wx, x); fe_to_words(wy, y);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { e[k] = wx[k]; e[8 + k] = wy[k]; e[16 + k] = wb[k]; e[24 + k] = wy[k]; }
+        for (int k = 0; k < 8; k++) { e[k] = wx[k]; e[8 + k] = wy[k]; }
+#if S2K_PTAB_TWINS
+        {
+            fe beta, bx; fe_set_beta(beta);
+            fe_mul(bx, x, beta); fe_normalize(bx);
+            u32 wb[8]; fe_to_words(wb, bx);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { e[16 + k] = wb[k]; e[24 + k] = wy[k]; }
+        }
+#endif
         fe_mul(zs, zs, h);             // ratio z_i / z_{i-1} joins the running product for the entries below
+        if (i > 0) {
+#pragma unroll
+            for (int k = 0; k < 27; k++) S2K_CHAIN(nraw[k]);
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
+        }
     }
 }
 // Builds the table for a finite Jacobian A (magnitudes <= (5,3,1)); returns the factor that takes the accumulator's Z
@@ -145,9 +168,11 @@ S2K_HD void ptab_load_ziso(fe& zi, const u32* ptab) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define S2K_WAVE_ANY(p) (__any(p))
 #define S2K_WAVE_ALL(p) (__all(p))
+#define S2K_UNIFORM(x) (__builtin_amdgcn_readfirstlane(x))       /* a value known to be the same in every lane, as a scalar */
 #else
 #define S2K_WAVE_ANY(p) (p)
 #define S2K_WAVE_ALL(p) (p)
+#define S2K_UNIFORM(x) (x)
 #endif
 
 // Per-lane memory handed to ecmult_lane: the table slice in HBM and the digit stream in LDS.  The digit stream is what the
@@ -234,8 +259,8 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
     // the record of addition a+1 is *requested* (16 words into `raw`, no use of the data) before the arithmetic of addition a
     // and *decoded* into limbs after it, so the gather's latency lies under ~1800 instructions instead of in front of them.
     // A lane that does not advance in a trip simply requests the same record again: no per-lane select ever waits on the data.
-    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
-        addr = ptab; valid = 0; neg = 0;
+    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int& lam, int idx) {
+        addr = ptab; valid = 0; neg = 0; lam = 0;
         if (idx < S2K_ADD_G0) {
             const int h = idx & 1;
             const int hn = h ? hneg1 : hneg0;
@@ -243,7 +268,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             if (idx >= 2 && idx < S2K_ADDS_P) v = (dig[(idx >> 3) * S2K_DIG_STRIDE] >> ((idx & 7) * 4)) & 15u;
             neg = (v < 8u) ^ flip;
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
-            addr = ptab + e * S2K_PTAB_ENTRY_WORDS + (h ? 16 : 0);
+            addr = ptab + e * S2K_PTAB_ENTRY_WORDS + ((h && S2K_PTAB_TWINS) ? 16 : 0); lam = h && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
             const int g = idx - S2K_ADD_G0;
             const int b = g * S2K_GTAB_BITS, w = b >> 5;
@@ -252,29 +277,33 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
         }
     };
-    auto op_decode = [&](ge& o, const u32 raw[16], int neg) {
+    auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
         fe y, yn;
         fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
+        if (S2K_WAVE_ANY(lam)) {                                    // twin-less tables: the lambda half's x is beta * x
+            fe beta, bx; fe_set_beta(beta); fe_mul(bx, o.x, beta);
+            fe_select(o.x, bx, o.x, lam);
+        }
         fe_neg(yn, y, 1);
         fe_select(o.y, yn, y, neg);
     };
-    const u32* nxt_addr; int nxt_valid, nxt_neg;
+    const u32* nxt_addr; int nxt_valid, nxt_neg, nxt_lam;
     u32 raw[16];
     ge cur; int cur_valid;
-    op_locate(nxt_addr, nxt_valid, nxt_neg, a);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, a);
 #pragma unroll
     for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-    op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+    op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
     gej_set_infinity(R);
     if (p_active) {                                 // addition 0 would add the top digit of half 0 to infinity: just take it
         gej_set_ge(R, cur);
         a = 1;
-        op_locate(nxt_addr, nxt_valid, nxt_neg, a);
+        op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, a);
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
+        op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
     }
-    op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, a + 1);
     // Lock-step fast path.  When every lane of the wavefront multiplies a live point (and the lanes agree on whether there is a
     // generator part) they all sit at the same place of the same micro-program, so the schedule is a plain loop: no per-lane
     // program counter, no select after every point operation, lean formulas (group.h).  A lane that meets an operand with its
@@ -297,8 +326,8 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             if (au < S2K_ADDS_P) R = t;                                         // regular digits are never zero
             else if (cur_valid) R = t;                                          // generator windows: a zero window adds nothing (per lane)
             au++;
-            op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
-            op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+            op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
+            op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 1);
         }
         if (au == S2K_ADD_G0 && !zfixed) { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); zfixed = 1; }      // no generator part
         a = au;
@@ -320,13 +349,13 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
 #pragma unroll
             for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
             gej t; const int f = gej_add_ge(t, R, cur);
-            ge nx; op_decode(nx, raw, nxt_neg);
+            ge nx; op_decode(nx, raw, nxt_neg, nxt_lam);
             if (do_add) {
                 if (cur_valid) { R = t; pending = (f == GEJ_ADD_NEEDS_DOUBLE); }
                 a++;
                 cur = nx; cur_valid = nxt_valid;
                 dbl_left = (a >= 2 && a < S2K_ADDS_P && !(a & 1)) ? 4 : 0;
-                op_locate(nxt_addr, nxt_valid, nxt_neg, a + 1);
+                op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, a + 1);
             }
         }
         // leaving the isomorphic curve: after the last digit, before the generator additions
@@ -381,6 +410,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     const int g_active = has_ng & (!sc_is_zero(ng));
     if (!(S2K_WAVE_ALL(p_active) && (S2K_WAVE_ALL(g_active) || !S2K_WAVE_ANY(g_active)))) return 0;
     u32 sneg = 0;                                                    // bit st: stream st is negative
+    S2K_PROF_DECL;
     {
         half_scalar h0, h1; sc_split_lambda_odd(h0, h1, na);
         piece65 pc[4]; sc_split_pieces(pc, h0, h1);
@@ -404,18 +434,21 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #pragma unroll
         for (int i = 0; i < 8; i++) dig[(8 + i) * S2K_DIG_STRIDE] = ng.d[i];
         fe za, zt, ziso;
+        S2K_PROF_MARK(1);
         ptab_build_raw(za, ptab, A);
         ptab_build_raw(zt, ptab + S2K_PTAB_TABLE_WORDS, T);
+        S2K_PROF_MARK(8);
         ptab_rescale(ptab, &zt);
         ptab_rescale(ptab + S2K_PTAB_TABLE_WORDS, &za);
+        S2K_PROF_MARK(9);
         fe_mul(ziso, za, zt);
 #pragma unroll
         for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
     }
     const int a_g0 = S2K_SPLIT_ADDS_P;
     const int a_end = g_active ? a_g0 + S2K_GTAB_WINDOWS : a_g0;
-    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
-        addr = ptab; valid = 0; neg = 0;
+    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int& lam, int idx) {
+        addr = ptab; valid = 0; neg = 0; lam = 0;
         if (idx < a_g0) {
             const int st = idx & 3;
             u32 v = 8u;                                                                     // the fixed top digit +1
@@ -423,7 +456,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
             valid = 1;
             neg = (v < 8u) ^ (int)((sneg >> st) & 1u);
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
-            addr = ptab + (st >> 1) * S2K_PTAB_TABLE_WORDS + e * S2K_PTAB_ENTRY_WORDS + ((st & 1) ? 16 : 0);
+            addr = ptab + (st >> 1) * S2K_PTAB_TABLE_WORDS + e * S2K_PTAB_ENTRY_WORDS + (((st & 1) && S2K_PTAB_TWINS) ? 16 : 0); lam = (st & 1) && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
             const int g = idx - a_g0;
             const int b = g * S2K_GTAB_BITS, w = b >> 5;
@@ -432,25 +465,26 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
             if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
         }
     };
-    auto op_decode = [&](ge& o, const u32 raw[16], int neg) {
+    auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
         fe y, yn;
         fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
+        if (S2K_UNIFORM(lam)) { fe beta; fe_set_beta(beta); fe_mul(o.x, o.x, beta); }          // every lane is at the same stream: a scalar branch
         fe_neg(yn, y, 1);
         fe_select(o.y, yn, y, neg);
     };
-    const u32* nxt_addr; int nxt_valid, nxt_neg;
+    const u32* nxt_addr; int nxt_valid, nxt_neg, nxt_lam;
     u32 raw[16];
     ge cur; int cur_valid;
-    op_locate(nxt_addr, nxt_valid, nxt_neg, 0);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 0);
 #pragma unroll
     for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-    op_decode(cur, raw, nxt_neg);
+    op_decode(cur, raw, nxt_neg, nxt_lam);
     gej_set_ge(R, cur);
-    op_locate(nxt_addr, nxt_valid, nxt_neg, 1);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-    op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
-    op_locate(nxt_addr, nxt_valid, nxt_neg, 2);
+    op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
+    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 2);
     // variable part: additions 1..67, in place (a lane that meets its own x coordinate makes the caller start over with ecmult_lane,
     // so the accumulator of before the addition need not survive it)
     int au = 1;
@@ -458,14 +492,15 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
         if (au >= 4 && !(au & 3)) {
 #pragma unroll 1
             for (int k = 0; k < 4; k++) gej_double_lean(R, R);
+            S2K_PROF_MARK(6);
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
         const int same_x = gej_add_ge_lean(R, R, cur);
         if (S2K_WAVE_ANY(same_x)) return 0;
         au++;
-        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
-        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+        op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 1);
     }
     { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); }             // back to the real curve
     // generator part: a zero window adds nothing (per lane), so these additions are committed by select
@@ -476,9 +511,10 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
         if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
         if (cur_valid) R = t;
         au++;
-        op_decode(cur, raw, nxt_neg); cur_valid = nxt_valid;
-        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+        op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 1);
     }
+    S2K_PROF_MARK(10);
 #ifdef S2K_ON_SPLIT_DONE
     S2K_ON_SPLIT_DONE();                                                                      // host test build: count completed split runs
 #endif

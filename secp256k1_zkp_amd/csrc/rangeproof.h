@@ -331,6 +331,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
     // Nothing but flags and pointers stays live across ecmult_lane: the ring key is re-read from its scratch record and the
     // next key (key + base, pub_expand :43-45) is written back there before the multiplication starts.
     u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
+    S2K_PROF_DECL;
     if (t28) {
         gej t; gej_load28_h(t, pub28);
         const int tinf = t.inf; t.inf = 0;
@@ -340,7 +341,7 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
         t.inf = tinf;
         if (live) gej_store28_h(t28, t);
     }
-    S2K_PROF_DECL;
+    S2K_PROF_MARK(11);
 #pragma unroll 1
     for (u32 j = 0; j < 4; j++) {
         const int step_live = ok & (j < rsize);

@@ -7,7 +7,7 @@ import ctypes, os, subprocess, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "secp256k1_zkp_amd", "libsecp256k1_zkp_amd_prof.so")
+lib = os.environ.get("S2K_LIB") or os.path.join(ROOT, "secp256k1_zkp_amd", "libsecp256k1_zkp_amd_prof.so")   # S2K_LIB: a -DS2K_PROF build made elsewhere
 if not os.path.exists(lib):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-DS2K_PROF",
                            "-fvisibility=hidden", "-o", lib, os.path.join(ROOT, "secp256k1_zkp_amd", "csrc", "engine.hip")])
@@ -28,9 +28,11 @@ pr(buf)
 res, mn, mx = eng.rangeproof_verify_batch(commits, proofs, gens)
 pr(buf)
 v = np.array(list(buf), dtype=np.float64)
-names = ["step prologue (key load, next key)", "ecmult: split + digits", "ecmult: table build", "ecmult: main loop (rest: first operand, general loop)", "to-affine (inversion)",
-         "hash + bookkeeping", "main loop: 4 lean doublings", "main loop: lean addition + operand decode/locate"]
-tot = v[:8].sum()
-out = {names[i]: {"wave_cycles": v[i], "share": v[i] / tot, "cycles_per_wave_step": v[i] / (n * 32 * 4 / 64)} for i in range(8)}
-out["steps"] = n * 32 * 4 / 64
+names = ["step prologue (key load, next key, T update)", "ecmult: split + digits", "ecmult_lane only: table build", "ecmult_lane only: main loop rest", "to-affine (inversion)",
+         "hash + bookkeeping", "main loop: 4 lean doublings", "main loop: lean addition + operand decode/locate", "split: 2 x co-Z table construction",
+         "split: 2 x table rescale", "split: generator additions + leaving the isomorphic curve", "ring: 2^64 * key chain (64 doublings)"]
+tot = v[:12].sum()
+steps = n * 32 * 4 / 64
+out = {names[i]: {"wave_cycles": v[i], "share": round(v[i] / tot, 4), "cycles_per_wave_step": round(v[i] / steps)} for i in range(12)}
+out["steps"] = steps
 print(json.dumps(out, indent=1))

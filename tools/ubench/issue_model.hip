@@ -71,6 +71,27 @@ KB(k_mac1_fill)
    "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_and_b32 %1, %2, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_and_b32 %1, %2, %1\n"
    : "+v"(a0),"+v"(b0) : "v"(x0),"v"(x1) : "vcc");
 KE
+
+// data dependence of the MAC rate (board power management): the same 8-chain stream with all-zero operands and with full-width
+// pseudo-random operands (k_mac8 above multiplies ~10-bit values)
+#define KBV(name, X0, X1) __global__ void __launch_bounds__(256) name(uint32_t* out, uint32_t seed, int iters) { \
+  uint32_t x0=(X0), x1=(X1); \
+  uint64_t a0=x0,a1=x1,a2=x0^x1,a3=x0+x1,a4=(uint64_t)x0*x1,a5=a4^x0,a6=a4+x1,a7=a4*3; \
+  if (seed == 0xdeadbeef) dyn_lds[threadIdx.x] = 1; \
+  for (int it=0; it<iters; ++it) { \
+  asm volatile( \
+   "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n" \
+   "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n" \
+   "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n" \
+   "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n" \
+   : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x0),"v"(x1) : "vcc"); \
+  } \
+  uint64_t s=a0^a1^a2^a3^a4^a5^a6^a7; if ((uint32_t)s == 0x12345) out[threadIdx.x]=1; }
+KBV(k_mac8_zero, seed >> 31, seed >> 30)
+KBV(k_mac8_rand, (threadIdx.x + seed) * 2654435761u ^ 0x9e3779b9u, (threadIdx.x * 40503u + seed) * 2246822519u ^ 0x85ebca6bu)
+KBV(k_mac8_29bit, ((threadIdx.x + seed) * 2654435761u ^ 0x9e3779b9u) & 0x1fffffffu, ((threadIdx.x * 40503u + seed) * 2246822519u ^ 0x85ebca6bu) & 0x1fffffffu)
+KBV(k_mac8_x256, ((threadIdx.x + seed) * 2654435761u ^ 0x9e3779b9u) & 0x1fffffffu, 256u + (seed >> 31))
+
 KB(k_add8)
   asm volatile(
    "v_add_u32 %0, %8, %0\n v_add_u32 %1, %8, %1\n v_add_u32 %2, %8, %2\n v_add_u32 %3, %8, %3\n"
@@ -138,6 +159,45 @@ FB(k_gej_add_ge_lean) gej p; ge q; fe_seed(p.x, threadIdx.x + seed); fe_seed(p.y
   fe_add(p.x, p.y); fe_add(p.x, p.z); p.x.n[0] += acc;
 FE_END(p.x)
 
+
+// fe_mul with the fold's second multiply-accumulate (256 * u_{k-1}) treated three ways: MODE 0 as shipped, 1 dropped (what a free
+// fold term would buy; wrong results), 2 replaced by one v_lshl_add_u64 (what a shift-and-add fold of a mixed-radix layout would cost)
+template <int MODE>
+__device__ __forceinline__ void fe_mul_variant(fe& r, const fe& a_in, const fe& b_in) {
+    u32 a[FE_LIMBS], b[FE_LIMBS];
+#pragma unroll
+    for (int i = 0; i < FE_LIMBS; i++) { a[i] = a_in.n[i]; b[i] = b_in.n[i]; }
+    S2K_OPAQUE(a[8]); S2K_OPAQUE(b[8]);
+    u32 k256 = 256u; S2K_OPAQUE(k256);
+    u64 c = 0, d = 0; u32 u = 0; u64 uprev = 0;
+#pragma unroll
+    for (int k = 0; k < FE_LIMBS; k++) {
+#pragma unroll
+        for (int t = 0; t < FE_LIMBS; t++) {
+            if (k < 8 && k + 1 + t < FE_LIMBS) { const int i = k + 1 + t, j = 9 + k - i; d += (u64)a[i] * b[j]; S2K_CHAIN(d); }
+            if (t <= k) { const int i = t, j = k - t; c += (u64)a[i] * b[j]; S2K_CHAIN(c); }
+        }
+        if (k < 8) { u = (u32)d & FE_M; d >>= FE_BITS; } else u = (u32)d;
+        c += (u64)u * 31264u; S2K_CHAIN(c);
+        if (k > 0) {
+            if (MODE == 0) { c += (u64)(u32)uprev * k256; S2K_CHAIN(c); }
+            if (MODE == 2) { asm volatile("v_lshl_add_u64 %0, %1, 4, %0" : "+v"(c) : "v"(uprev)); }
+        }
+        uprev = u;
+        r.n[k] = (u32)c & FE_M; c >>= FE_BITS;
+    }
+    fe_mul_tail(r, c, u);
+}
+FB(k_fe_mul_v0) fe x, y; fe_seed(x, threadIdx.x + seed); fe_seed(y, threadIdx.x * 7 + 3);
+  for (int it = 0; it < iters; ++it) fe_mul_variant<0>(x, x, y);
+FE_END(x)
+FB(k_fe_mul_v1) fe x, y; fe_seed(x, threadIdx.x + seed); fe_seed(y, threadIdx.x * 7 + 3);
+  for (int it = 0; it < iters; ++it) fe_mul_variant<1>(x, x, y);
+FE_END(x)
+FB(k_fe_mul_v2) fe x, y; fe_seed(x, threadIdx.x + seed); fe_seed(y, threadIdx.x * 7 + 3);
+  for (int it = 0; it < iters; ++it) fe_mul_variant<2>(x, x, y);
+FE_END(x)
+
 typedef void (*kern_t)(uint32_t*, uint32_t, int);
 struct entry { const char* name; kern_t k; double ops_per_iter; double approx_cyc_per_iter; };
 
@@ -150,9 +210,11 @@ int main(int argc, char** argv) {
     entry es[] = {
         {"v_mad_u64_u32 x8 chains", k_mac8, 8, 36}, {"v_mad_u64_u32 x4 chains", k_mac4, 8, 36}, {"v_mad_u64_u32 x2 chains", k_mac2, 8, 40},
         {"v_mad_u64_u32 1 chain + s_nop 0", k_mac1_nop, 8, 60}, {"v_mad_u64_u32 1 chain + v_and fill", k_mac1_fill, 8, 60},
+        {"mac8 zero operands", k_mac8_zero, 8, 36}, {"mac8 random 32-bit operands", k_mac8_rand, 8, 36}, {"mac8 random 29-bit operands", k_mac8_29bit, 8, 36}, {"mac8 29-bit x 256", k_mac8_x256, 8, 36},
         {"v_add_u32 x8", k_add8, 8, 20}, {"v_lshrrev_b64 x8", k_shr64_8, 8, 36}, {"column mix 6 mac+and+shr64", k_mix_col, 8, 36},
         {"fe_mul (fe.h)", k_fe_mul, 1, 800}, {"fe_sqr (fe.h)", k_fe_sqr, 1, 600}, {"fe_mul2 lockstep (per product)", k_fe_mul2, 2, 1500},
         {"fe_sqr2 lockstep (per product)", k_fe_sqr2, 2, 1100}, {"gej_double", k_gej_double, 1, 5000}, {"gej_add_ge", k_gej_add_ge, 1, 8000},
+        {"variant0 fe_mul as shipped", k_fe_mul_v0, 1, 800}, {"variant1 fe_mul without the x256 MACs", k_fe_mul_v1, 1, 800}, {"variant2 fe_mul x256 as v_lshl_add_u64", k_fe_mul_v2, 1, 800},
         {"fe_muladd (product + square, one reduction)", k_fe_muladd, 1, 1100}, {"gej_double_lean", k_gej_double_lean, 1, 4500}, {"gej_add_ge_lean", k_gej_add_ge_lean, 1, 7500}};
     const char* only = (argc > 2) ? argv[2] : nullptr;
     const double target_ms = (argc > 1) ? atof(argv[1]) : 12.0;
