@@ -157,6 +157,8 @@ def main():
     d_proofs = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
     d_res = torch.zeros(n, dtype=torch.int32, device=dev); d_min = torch.zeros(n, dtype=torch.int64, device=dev); d_max = torch.zeros(n, dtype=torch.int64, device=dev)
     stream = None                         # the engine's own stream (HIP events for the roofline are recorded on it)
+    if os.environ.get("S2K_BENCH_PIPELINE", "0") != "0":
+        eng.set_option(Engine.OPT_RP_INPUTS_READY, 1)
     torch.cuda.synchronize()              # ...which is not ordered against torch's streams: inputs must be resident first
 
     def step():
@@ -169,13 +171,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern_ms = []
+    # The K steps are queued back to back and waited for once (stream-ordered `_dev` calls: no host round trip between steps); every
+    # step does all of its work inside the timed region.  With S2K_BENCH_PIPELINE=1 the engine's S2K_OPT_RP_INPUTS_READY contract is
+    # switched on as well (first stage of step k+1 on side streams underneath the ring kernel of step k): measured equal within noise
+    # on a power-capped MI355X (profiles/r02q_*), and it blurs the per-kernel timing, so the default leaves it off.
     for _ in range(args.steps):
         step()
-        torch.cuda.synchronize()          # one batch in flight at a time (a step is one pass over one batch)
-        kern_ms.append(eng.last_ms(1))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kern_ms = [eng.last_ms(16 + k) for k in range(min(args.steps, 32))]          # HIP events around k_rp_rings on the launch stream
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -281,7 +285,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit), 32x32->64 integer MAC", "data": data_desc,
             "config": {"workload": "secp256k1_rangeproof_verify, batch of %d 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)" % n,
-                       "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)"},
+                       "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)",
+                       "calls_in_flight": ("K steps queued back to back, first stage of step k+1 on side streams under step k's ring kernel "
+                                           "(S2K_OPT_RP_INPUTS_READY: inputs resident and untouched)") if os.environ.get("S2K_BENCH_PIPELINE", "0") != "0"
+                                          else "same queueing, engine default: the first stage of a call waits for the call before it"},
             # the binding roofline of this path is the integer VALU: exact 256-bit modular arithmetic, no MFMA, ~0.05 % of HBM
             "roofline": {"bound": "valu", "kernel": "k_rp_rings", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK / 1e12,
                          "unit": "T lane-MAC/s (v_mad_u64_u32, 32x32+64)", "frac": mad_rate / MAD32_PEAK, "frac_of_architectural_peak": mad_rate / MAD32_PEAK_ARCH,

@@ -44,6 +44,17 @@ S2K_API const char* s2k_last_error(void);
 #define S2K_STATUS_ILLEGAL_ARGUMENT 2 /* what the reference's ARG_CHECK would have rejected */
 S2K_API int s2k_last_status(void);
 S2K_API void s2k_clear_status(void);
+/* Engine options.
+ * S2K_OPT_RP_INPUTS_READY (default 0): the rangeproof `_dev` entry points run their first stage (header parse, message hash, ring
+ *   bases, commitment lifts: latency bound) on side streams, two calls deep, underneath the previous call's ring kernel.  By default
+ *   that stage still waits for everything queued on the caller's stream before the call, because the inputs may be produced there.
+ *   Setting the option to 1 is the caller's promise that the input arrays of a `_dev` call are complete when the call is made (and
+ *   stay untouched until its results are consumed); min_value/max_value may then be written before the stream reaches the call.
+ *   Results are unaffected; host-buffer entry points ignore the option.
+ * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results). */
+#define S2K_OPT_RP_INPUTS_READY 1
+#define S2K_OPT_RP_SPLIT 2
+S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
 /* Make sure the per-batch HBM workspace can hold `n_items` rangeproofs (optional; calls grow it on demand). */
 S2K_API int s2k_engine_reserve(s2k_engine* e, size_t n_items);
 /* Block until everything queued on the engine's stream has finished. */
@@ -51,7 +62,8 @@ S2K_API int s2k_engine_sync(s2k_engine* e);
 /* Device pointer + size (bytes) of the generator table, for tests. */
 S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
 /* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
- * `which`: 0 = whole call, 1 = dominant kernel only.  Valid after s2k_engine_sync(). */
+ * `which`: 0 = whole call, 1 = dominant kernel only; 16 + k = dominant kernel of the k-th most recent rangeproof call (k < 32:
+ * several calls may be in flight, see S2K_OPT_RP_INPUTS_READY).  Valid after s2k_engine_sync(). */
 S2K_API float s2k_engine_last_ms(s2k_engine* e, int which);
 /* 1 if the most recent MSM launch on this engine overflowed a bucket region and took the exact bucket-free path (diagnostics /
  * tests; synchronises the device). */

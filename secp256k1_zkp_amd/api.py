@@ -75,6 +75,12 @@ class Engine:
     def sync(self):
         self._check(self._lib.s2k_engine_sync(self._h), "s2k_engine_sync")
 
+    OPT_RP_INPUTS_READY = 1      # include/secp256k1_zkp_amd.h: S2K_OPT_*
+    OPT_RP_SPLIT = 2
+
+    def set_option(self, option, value):
+        self._check(self._lib.s2k_engine_set_option(self._h, int(option), int(value)), "s2k_engine_set_option")
+
     def last_ms(self, which=0):
         return float(self._lib.s2k_engine_last_ms(self._h, which))
 

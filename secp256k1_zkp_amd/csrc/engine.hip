@@ -64,6 +64,14 @@ struct s2k_engine {
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
     int rp_split;              // rangeproof rings use the two-piece double multiplication (ecmult_lane_split); $S2K_RP_SPLIT=0 turns it off
+    // Rangeproof pipeline (rp_launch): two sets of per-proof scratch records, so that the header / prologue / lift / key-sum stage of
+    // one chunk (side streams, latency bound) runs underneath the rings kernel of the chunk before it (caller's stream).
+    unsigned char* rp_mem[2]; size_t rp_mem_bytes;
+    hipStream_t stream_pre;
+    hipEvent_t ev_rp_in, ev_rp_fork[2], ev_rp_join[2], ev_rp_pre[2], ev_rp_done[2];
+    int rp_done_valid[2]; unsigned rp_seq;
+    hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
+    int rp_inputs_ready;       // S2K_OPT_RP_INPUTS_READY: the side-stream stage need not wait for earlier work of the caller's stream
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
@@ -178,6 +186,11 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     s2k_engine* e = new s2k_engine();
     e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr;
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
+    for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
+    e->ring_seq = 0;
+    e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
+    for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
+    if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
@@ -193,6 +206,15 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < 32; i++) { S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][0])); S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][1])); }
+    S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_fork[i], hipEventDisableTiming));
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_join[i], hipEventDisableTiming));
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_pre[i], hipEventDisableTiming));
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_done[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < 4; i++) S2K_CREATE_CHK(hipEventCreate(&e->ev[i]));
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
     S2K_CREATE_CHK(hipMalloc((void**)&e->dev_flags, 64));
@@ -217,6 +239,16 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->host_flags) hipHostFree(e->host_flags);
     if (e->dev_flags) hipFree(e->dev_flags);
     for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 2; i++) {
+        if (e->rp_mem[i]) hipFree(e->rp_mem[i]);
+        if (e->ev_rp_fork[i]) hipEventDestroy(e->ev_rp_fork[i]);
+        if (e->ev_rp_join[i]) hipEventDestroy(e->ev_rp_join[i]);
+        if (e->ev_rp_pre[i]) hipEventDestroy(e->ev_rp_pre[i]);
+        if (e->ev_rp_done[i]) hipEventDestroy(e->ev_rp_done[i]);
+    }
+    for (int i = 0; i < 32; i++) for (int j = 0; j < 2; j++) if (e->ev_ring[i][j]) hipEventDestroy(e->ev_ring[i][j]);
+    if (e->ev_rp_in) hipEventDestroy(e->ev_rp_in);
+    if (e->stream_pre) { hipStreamSynchronize(e->stream_pre); hipStreamDestroy(e->stream_pre); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
@@ -252,6 +284,13 @@ extern "C" float s2k_engine_last_ms(s2k_engine* e, int which) {
     float ms = -1.0f;
     if (!e) return ms;
     hipSetDevice(e->device);
+    if (which >= 16 && which < 48) {                   // dominant kernel of the (which-16)-th most recent rangeproof call
+        const unsigned back = (unsigned)(which - 16);
+        if (back >= e->ring_seq) return ms;
+        const unsigned i = (e->ring_seq - 1u - back) & 31u;
+        if (hipEventElapsedTime(&ms, e->ev_ring[i][0], e->ev_ring[i][1]) != hipSuccess) { (void)hipGetLastError(); ms = -1.0f; }
+        return ms;
+    }
     if (which == 0) { if (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) != hipSuccess) ms = -1.0f; }
     else            { if (hipEventElapsedTime(&ms, e->ev[2], e->ev[3]) != hipSuccess) ms = -1.0f; }
     return ms;
@@ -450,31 +489,58 @@ static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
     w.ring_out = c.take<unsigned char>(n * RP_RING_OUT_BYTES);
     w.ring_ok = c.take<unsigned char>(n * RP_MAX_RINGS);
 }
-// launches the five stages; `w` must already point into device memory
+// the two scratch sets of the pipeline, each for `nw` proofs
+static int engine_rp_slots(s2k_engine* e, size_t nw) {
+    const size_t bytes = (rp_ws_bytes(nw) + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+    if (bytes <= e->rp_mem_bytes) return 1;
+    HIPCHK(hipDeviceSynchronize());                 // earlier launches may still use the old records
+    for (int i = 0; i < 2; i++) { if (e->rp_mem[i]) HIPCHK(hipFree(e->rp_mem[i])); e->rp_mem[i] = nullptr; e->rp_done_valid[i] = 0; }
+    e->rp_mem_bytes = 0;
+    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void**)&e->rp_mem[i], bytes));
+    e->rp_mem_bytes = bytes;
+    return 1;
+}
+// Launches the five stages, chunk by chunk (RP_CHUNK proofs), as a two-deep pipeline:
+//   side streams   : header -> { prologue (1 lane/proof, latency bound) || lift (1 lane/ring, lowest priority) } -> key sum
+//   caller's stream: rings (the 98 %) -> final [-> rewind]
+// Chunk i+1's side-stream stage runs while chunk i's rings kernel owns the machine; the scratch records alternate between two sets and a
+// set is reused only after the rings/final that read it.  By default the side-stream stage of a call also waits for everything the
+// caller had queued on `st` before the call (its inputs may still be in the making); with S2K_OPT_RP_INPUTS_READY the caller
+// promises the input arrays are complete when the call is made, and the first stage of call k+1 then also runs under call k's rings.
 #define RP_CHUNK (e->max_lanes / RP_MAX_RINGS)     /* proofs per launch group */
-static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
-                     const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr) {
-    if (!engine_ptab(e, ((std::min(n, RP_CHUNK) * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
+                     const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr, int inputs_on_stream = 0) {
+    const size_t nw = std::min(n, RP_CHUNK);
+    if (!engine_rp_slots(e, nw)) return 0;
+    if (!engine_ptab(e, ((nw * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
-    // the scratch records `w` hold one chunk; chunks run back to back on the stream and reuse them
+    const hipStream_t sp = e->stream_pre;
+    if (inputs_on_stream || !e->rp_inputs_ready) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); }
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
         const size_t m = std::min(n - p0, RP_CHUNK);
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
-        hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, min_value + p0, max_value + p0, proofs, proof_off + p0, m);
-        // fork: the per-proof point work (one lane per proof, latency bound) and the per-ring lifts (throughput bound) are independent
-        HIPCHK(hipEventRecord(e->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        const int slot = (int)(e->rp_seq++ & 1u);
+        ws_carver c{e->rp_mem[slot], 0}; rp_ws w; rp_ws_carve(w, c, nw);
+        // ---- side streams
+        if (e->rp_done_valid[slot]) HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_done[slot], 0));
+        hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, sp, w, min_value + p0, max_value + p0, proofs, proof_off + p0, m);
+        HIPCHK(hipEventRecord(e->ev_rp_fork[slot], sp));
+        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_rp_fork[slot], 0));
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(192), 0, st, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
+        HIPCHK(hipEventRecord(e->ev_rp_join[slot], e->stream2));
+        hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(192), 0, sp, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
                            extra_off ? extra_off + p0 : nullptr, gens64 + 64 * p0, m);
-        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
-        hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, st, w, m);
-        if (p0 == 0) HIPCHK(hipEventRecord(e->ev[2], st));
+        HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_join[slot], 0));
+        hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, sp, w, m);
+        HIPCHK(hipEventRecord(e->ev_rp_pre[slot], sp));
+        // ---- caller's stream
+        HIPCHK(hipStreamWaitEvent(st, e->ev_rp_pre[slot], 0));
+        const unsigned rq = e->ring_seq & 31u;
+        if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[2], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][0], st)); }
         hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
-        if (p0 == 0) HIPCHK(hipEventRecord(e->ev[3], st));
+        if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
         if (rewind) {
             rp_rewind_args ra = *rewind;                      // scratch is per chunk, the caller's arrays are per batch
@@ -484,6 +550,8 @@ static int rp_launch(s2k_engine* e, hipStream_t st, const rp_ws& w, int32_t* res
             hipLaunchKernelGGL(k_rp_rewind, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, ra, results + p0, min_value + p0, proofs, proof_off + p0,
                                gens64 + 64 * p0, e->gtab, e->ptab, m);
         }
+        HIPCHK(hipEventRecord(e->ev_rp_done[slot], st));
+        e->rp_done_valid[slot] = 1;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[1], st));
@@ -497,9 +565,8 @@ extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t nw = std::min(n, RP_CHUNK);
-    if (!engine_workspace(e, rp_ws_bytes(nw))) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
-    return rp_launch(e, stream ? (hipStream_t)stream : e->stream, w, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
+    (void)nw;
+    return rp_launch(e, stream ? (hipStream_t)stream : e->stream, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
 }
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
@@ -512,8 +579,8 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
     const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n});
     const size_t nw = std::min(n, RP_CHUNK);
-    if (!engine_workspace(e, rp_ws_bytes(nw) + io)) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
+    if (!engine_workspace(e, io)) return 0;
+    ws_carver c{e->ws, 0}; (void)nw;
     int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
     unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
     uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
@@ -525,7 +592,7 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     if (ebytes) { HIPCHK(hipMemcpyAsync(d_ex, extra, ebytes, hipMemcpyHostToDevice, st)); }
     if (extra && extra_off) HIPCHK(hipMemcpyAsync(d_eoff, extra_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_gen, gens64, 64 * n, hipMemcpyHostToDevice, st));
-    if (!rp_launch(e, st, w, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n)) return 0;
+    if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, nullptr, 1)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
@@ -547,8 +614,8 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     const size_t nw = std::min(n, RP_CHUNK), mbytes = message_out ? msg_stride * n : 0;
     const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n, 32 * n, 32 * n, 8 * n, 8 * n, mbytes + 64,
                                nw * 4096, nw * 4096, nw * 1024});
-    if (!engine_workspace(e, rp_ws_bytes(nw) + io)) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
+    if (!engine_workspace(e, io)) return 0;
+    ws_carver c{e->ws, 0}; (void)nw;
     int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
     unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
     uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
@@ -567,7 +634,7 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipMemcpyAsync((void*)ra.nonces, nonces, 32 * n, hipMemcpyHostToDevice, st));
     if (message_out) { HIPCHK(hipMemcpyAsync(ra.outlen, outlen, 8 * n, hipMemcpyHostToDevice, st)); HIPCHK(hipMemsetAsync(ra.msg_out, 0, mbytes, st)); }
     else HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
-    if (!rp_launch(e, st, w, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, &ra)) return 0;
+    if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, &ra, 1)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
@@ -590,14 +657,14 @@ extern "C" int secp256k1_rangeproof_rewind_batch_dev(s2k_engine* e, void* stream
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const size_t nw = std::min(n, RP_CHUNK);
-    if (!engine_workspace(e, rp_ws_bytes(nw) + ws_need({8 * n, nw * 4096, nw * 4096, nw * 1024}))) return 0;
-    ws_carver c{e->ws, 0}; rp_ws w; rp_ws_carve(w, c, nw);
+    if (!engine_workspace(e, ws_need({8 * n, nw * 4096, nw * 4096, nw * 1024}))) return 0;
+    ws_carver c{e->ws, 0};
     rp_rewind_args ra;
     ra.nonces = nonces; ra.blind_out = blind_out; ra.value_out = value_out; ra.msg_out = message_out; ra.msg_stride = msg_stride;
     ra.outlen = message_out ? outlen : c.take<uint64_t>(n);
     ra.ev = c.take<u32>(nw * 1024); ra.prep = c.take<u32>(nw * 1024); ra.secs = c.take<u32>(nw * 256);
     if (!message_out) HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
-    return rp_launch(e, st, w, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n, &ra);
+    return rp_launch(e, st, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n, &ra);
 }
 // single-item forms with the reference's argument lists.  A 0 from these means "invalid" only while s2k_last_status() is
 // S2K_STATUS_OK; an engine-level failure also returns 0 (never 1) and leaves S2K_STATUS_ENGINE_FAILURE for the caller's
@@ -1749,11 +1816,21 @@ extern "C" int secp256k1_pedersen_verify_tally_batch_dev(s2k_engine* e, void* st
     return tally_impl(e, stream, results, commits33, tally_off_host, n_pos_host, n_tallies, 1);
 }
 
+// engine options (include/secp256k1_zkp_amd.h)
+extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
+    if (!e) return s2k_fail("s2k_engine_set_option", "null engine");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    switch (option) {
+    case S2K_OPT_RP_INPUTS_READY: e->rp_inputs_ready = value != 0; return 1;
+    case S2K_OPT_RP_SPLIT: e->rp_split = value != 0; return 1;
+    default: return s2k_fail_arg("s2k_engine_set_option", "unknown option");
+    }
+}
 // pre-size the workspace for batches of n_items rangeproofs (optional: every call grows it on demand)
 extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) {
     if (!e) return s2k_fail("s2k_engine_reserve", "null engine");
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t nw = std::min(n_items, RP_CHUNK);
-    return engine_workspace(e, rp_ws_bytes(nw) + n_items * 5400) && engine_ptab(e, nw * RP_MAX_RINGS);
+    return engine_workspace(e, n_items * 5400) && engine_rp_slots(e, nw) && engine_ptab(e, nw * RP_MAX_RINGS);
 }

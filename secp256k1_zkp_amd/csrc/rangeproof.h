@@ -197,15 +197,14 @@ S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsign
         gej_double(t2, base); gej_double(t8, t2); gej_double(s, t8);
         gej_add_var(base, s, t2);
     }
-    gej dcur = base;                         // 2^64 * B_0, then the same x4 chain: the keys' 2^64-multiples step by these
-    if (dbases) for (int k = 0; k < 64; k++) { gej t; gej_double(t, dcur); dcur = t; }
-    for (u32 i = 0; i < rings; i++) {
-        gej_store28_h(bases + RP_GEJ_WORDS * i, base);
-        if (dbases) gej_store28_h(dbases + RP_GEJ_WORDS * i, dcur);
-        if (i + 1 < rings) {
-            gej t; gej_double(t, base); gej_double(base, t);
-            if (dbases) { gej_double(t, dcur); gej_double(dcur, t); }
-        }
+    // One chain: base_{i+1} = 4 base_i, and 2^64 * base_i is simply base_{i+32} -- the steps of the keys' 2^64-multiples (dbases) are
+    // the continuation of the same chain, 2 * (rings + 31) doublings in all.
+    fe_norm_weak(base.x); fe_norm_weak(base.y);
+    const u32 total = dbases ? rings + 32 : rings;
+    for (u32 i = 0; i < total; i++) {
+        if (i < rings) gej_store28_h(bases + RP_GEJ_WORDS * i, base);
+        if (dbases && i >= 32) gej_store28_h(dbases + RP_GEJ_WORDS * (i - 32), base);
+        if (i + 1 < total) { gej_double_lean(base, base); gej_double_lean(base, base); }
     }
 }
 S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value, const unsigned char* commit33,

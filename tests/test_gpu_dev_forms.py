@@ -102,3 +102,42 @@ def test_halfagg_tally_rewind_dev(engine, ref):
     assert np.array_equal(bl.cpu().numpy().reshape(m, 32), eh[1]) and np.array_equal(val.cpu().numpy().view(np.uint64), eh[2])
     got_msgs = [msg.cpu().numpy().reshape(m, 128)[i, :int(ol[i].item())].tobytes() if r[i] else b"" for i in range(m)]
     assert got_msgs == eh[3]
+
+
+def test_rangeproof_dev_calls_in_flight(engine, ref):
+    """S2K_OPT_RP_INPUTS_READY: several `_dev` calls queued back to back (first stage of call k+1 underneath the ring kernel of call
+    k, two scratch sets alternating) give, call by call, what the host form gives; mixed valid / corrupted proofs."""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(77)
+    batches = []
+    for b in range(5):
+        n = 64 + 32 * b
+        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64 if b % 2 == 0 else 16, threads=8)
+        proofs = [bytearray(p) for p in proofs]
+        for i in range(0, n, 7 + b):
+            proofs[i][len(proofs[i]) // 2 + b] ^= 0x10
+        proofs = [bytes(p) for p in proofs]
+        want, wmin, wmax = engine.rangeproof_verify_batch(commits, proofs, gens)
+        assert 0 < int(want.sum()) < n
+        pdata, poff = Engine.pack(proofs)
+        d = dict(n=n, want=want, wmin=wmin, wmax=wmax, commits=_d(commits), gens=_d(np.ascontiguousarray(gens)),
+                 proofs=_d(np.concatenate([pdata, np.zeros(64, np.uint8)])), off=torch.tensor(poff.astype(np.int64)).cuda(),
+                 res=torch.full((n,), 7, dtype=torch.int32, device="cuda"), mn=torch.zeros(n, dtype=torch.int64, device="cuda"),
+                 mx=torch.zeros(n, dtype=torch.int64, device="cuda"))
+        batches.append(d)
+    torch.cuda.synchronize()
+    engine.set_option(Engine.OPT_RP_INPUTS_READY, 1)
+    try:
+        for rep in range(3):
+            for d in batches:
+                engine.rangeproof_verify_batch_dev(d["res"], d["mn"], d["mx"], d["commits"], d["proofs"], d["off"], d["gens"], d["n"])
+        engine.sync()
+    finally:
+        engine.set_option(Engine.OPT_RP_INPUTS_READY, 0)
+    for d in batches:
+        got = d["res"].cpu().numpy()
+        assert (got == d["want"]).all()
+        ok = d["want"] == 1
+        assert (d["mn"].cpu().numpy().astype(np.uint64)[ok] == np.asarray(d["wmin"], dtype=np.uint64)[ok]).all()
+        assert (d["mx"].cpu().numpy().astype(np.uint64)[ok] == np.asarray(d["wmax"], dtype=np.uint64)[ok]).all()
