@@ -468,7 +468,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
         fe y, yn;
         fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
-        if (S2K_UNIFORM(lam)) { fe beta; fe_set_beta(beta); fe_mul(o.x, o.x, beta); }          // every lane is at the same stream: a scalar branch
+        if (lam) { fe beta; fe_set_beta(beta); fe_mul(o.x, o.x, beta); }          // `lam` is a compile-time constant at every call site
         fe_neg(yn, y, 1);
         fe_select(o.y, yn, y, neg);
     };
@@ -478,16 +478,13 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 0);
 #pragma unroll
     for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-    op_decode(cur, raw, nxt_neg, nxt_lam);
-    gej_set_ge(R, cur);
+    op_decode(cur, raw, nxt_neg, 0);
     op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 1);
-#pragma unroll
-    for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-    op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
-    op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, 2);
-    // variable part: additions 1..67, in place (a lane that meets its own x coordinate makes the caller start over with ecmult_lane,
-    // so the accumulator of before the addition need not survive it)
-    int au = 1;
+    // Variable part: additions 0..67 as 34 (plain stream, lambda stream) pairs -- the trip holds both additions, so which operand
+    // takes the beta product is static and the accumulator can alternate between two register sets instead of being copied back at
+    // every loop edge.  Addition 0 adds to infinity: it just takes its operand.  In place: a lane that meets its own x coordinate
+    // makes the caller start over with ecmult_lane, so the accumulator of before the addition need not survive it.
+    int au = 0;
     while (au < a_g0) {
         if (au >= 4 && !(au & 3)) {
 #pragma unroll 1
@@ -496,10 +493,15 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
-        const int same_x = gej_add_ge_lean(R, R, cur);
-        if (S2K_WAVE_ANY(same_x)) return 0;
-        au++;
-        op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
+        if (au == 0) gej_set_ge(R, cur);
+        else { const int same_x = gej_add_ge_lean(R, R, cur); if (S2K_WAVE_ANY(same_x)) return 0; }
+        op_decode(cur, raw, nxt_neg, !S2K_PTAB_TWINS);                      // operand of the lambda stream
+        op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 2);           // (au = 66: the first generator window, if any)
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+        { const int same_x = gej_add_ge_lean(R, R, cur); if (S2K_WAVE_ANY(same_x)) return 0; }
+        au += 2;
+        op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
         op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 1);
     }
     { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); }             // back to the real curve

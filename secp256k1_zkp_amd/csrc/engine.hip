@@ -71,6 +71,7 @@ struct s2k_engine {
     hipEvent_t ev_rp_in, ev_rp_fork[2], ev_rp_join[2], ev_rp_pre[2], ev_rp_done[2];
     int rp_done_valid[2]; unsigned rp_seq;
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
+    hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
     int rp_inputs_ready;       // S2K_OPT_RP_INPUTS_READY: the side-stream stage need not wait for earlier work of the caller's stream
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
@@ -79,6 +80,17 @@ struct s2k_engine {
     std::recursive_mutex mu;
 };
 
+// The workspace and the table arena are shared by every call of an engine.  Calls on ONE stream are ordered by the stream; a call on
+// a different stream than the call before it first waits for that call's last work (an event recorded when every entry point leaves).
+struct stream_guard {
+    s2k_engine* e; hipStream_t st;
+    stream_guard(s2k_engine* e_, hipStream_t st_) : e(e_), st(st_) {
+        if (e->last_stream_valid && e->last_stream != st) { if (hipStreamWaitEvent(st, e->ev_last, 0) != hipSuccess) (void)hipGetLastError(); }
+    }
+    ~stream_guard() {
+        if (hipEventRecord(e->ev_last, st) == hipSuccess) { e->last_stream = st; e->last_stream_valid = 1; } else (void)hipGetLastError();
+    }
+};
 // per-lane table scratch for `lanes` concurrent ecmult_lane callers (lane = global thread index of the launch)
 static int engine_ptab(s2k_engine* e, size_t lanes) {
     lanes = (lanes + 255) & ~size_t(255);
@@ -188,6 +200,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
     for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
     e->ring_seq = 0;
+    e->last_stream = nullptr; e->last_stream_valid = 0; e->ev_last = nullptr;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
@@ -207,6 +220,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 32; i++) { S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][0])); S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][1])); }
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
@@ -247,6 +261,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
         if (e->ev_rp_done[i]) hipEventDestroy(e->ev_rp_done[i]);
     }
     for (int i = 0; i < 32; i++) for (int j = 0; j < 2; j++) if (e->ev_ring[i][j]) hipEventDestroy(e->ev_ring[i][j]);
+    if (e->ev_last) hipEventDestroy(e->ev_last);
     if (e->ev_rp_in) hipEventDestroy(e->ev_rp_in);
     if (e->stream_pre) { hipStreamSynchronize(e->stream_pre); hipStreamDestroy(e->stream_pre); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -318,6 +333,7 @@ extern "C" int s2k_ecmult_batch_dev(s2k_engine* e, void* stream, unsigned char* 
     HIPCHK(hipSetDevice(e->device));
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipEventRecord(e->ev[2], st));
@@ -566,7 +582,9 @@ extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream
     HIPCHK(hipSetDevice(e->device));
     const size_t nw = std::min(n, RP_CHUNK);
     (void)nw;
-    return rp_launch(e, stream ? (hipStream_t)stream : e->stream, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
+    return rp_launch(e, st, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
 }
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
@@ -586,6 +604,7 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
     unsigned char* d_gen = c.take<unsigned char>(64 * n);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     HIPCHK(hipMemcpyAsync(d_com, commits33, 33 * n, hipMemcpyHostToDevice, st));
     if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
@@ -625,6 +644,7 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     ra.outlen = c.take<uint64_t>(n); ra.msg_out = message_out ? c.take<unsigned char>(mbytes + 64) : nullptr; ra.msg_stride = msg_stride;
     ra.ev = c.take<u32>(nw * 1024); ra.prep = c.take<u32>(nw * 1024); ra.secs = c.take<u32>(nw * 256);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     HIPCHK(hipMemcpyAsync(d_com, commits33, 33 * n, hipMemcpyHostToDevice, st));
     if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
@@ -656,6 +676,7 @@ extern "C" int secp256k1_rangeproof_rewind_batch_dev(s2k_engine* e, void* stream
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     const size_t nw = std::min(n, RP_CHUNK);
     if (!engine_workspace(e, ws_need({8 * n, nw * 4096, nw * 4096, nw * 1024}))) return 0;
     ws_carver c{e->ws, 0};
@@ -767,6 +788,7 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
     HIPCHK(hipSetDevice(e->device));
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
@@ -1166,6 +1188,7 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
     const msm_plan pl = msm_make_plan(nt ? nt : 1);
     if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
@@ -1182,6 +1205,7 @@ extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, 
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
     const msm_plan pl = msm_make_plan(nt ? nt : 1);
     if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
@@ -1198,6 +1222,7 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
     const msm_plan pl = msm_make_plan(nt ? nt : 1);
     if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
@@ -1215,6 +1240,7 @@ extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy,
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if (!engine_workspace(e, ws_need({(count / 1024 + 64) * 28 * 4, (count / 1024 + 64) * 28 * 4}))) return 0;
     ws_carver c{e->ws, 0};
     u32* bufA = c.take<u32>((count / 1024 + 64) * 28); u32* bufB = c.take<u32>((count / 1024 + 64) * 28);
@@ -1237,6 +1263,7 @@ extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
     unsigned char* d_sc = c.take<unsigned char>(32 * n + 64); unsigned char* d_pt = c.take<unsigned char>(64 * n + 64); unsigned char* d_inf = c.take<unsigned char>(n + 64);
     unsigned char* d_g = c.take<unsigned char>(64); unsigned char* d_r = c.take<unsigned char>(64); int32_t* d_ri = c.take<int32_t>(4);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     if (n) {
         HIPCHK(hipMemcpyAsync(d_sc, sc, 32 * n, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_pt, pt_xy, 64 * n, hipMemcpyHostToDevice, st));
@@ -1382,6 +1409,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch_dev(s2k_engine* e, void*
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     bp_shape sh;
     if (!bp_make_shape(sh, g_len, c_vec_len, n_gens, proof_len)) { HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st)); return 1; }   // :446-461
     const size_t per = std::max<size_t>(1, e->max_lanes / sh.n_terms);        // proofs per launch group
@@ -1413,6 +1441,7 @@ extern "C" int secp256k1_bppp_norm_product_verify_batch(s2k_engine* e, int32_t* 
     unsigned char* d_rho = c.take<unsigned char>(32 * n); unsigned char* d_g33 = c.take<unsigned char>(33 * n_gens);
     unsigned char* d_cv = c.take<unsigned char>(32 * c_vec_len * n); unsigned char* d_cm = c.take<unsigned char>(33 * n);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     HIPCHK(hipMemcpyAsync(d_pr, proofs, n * proof_len, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_tr, transcripts, 104 * n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_rho, rho, 32 * n, hipMemcpyHostToDevice, st));
@@ -1507,6 +1536,7 @@ extern "C" int secp256k1_bppp_commit_batch_dev(s2k_engine* e, void* stream, unsi
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     const size_t per = std::max<size_t>(1, e->max_lanes / (n_gens + 1));
     if (!engine_workspace(e, bpc_ws_bytes(std::min(n, per), n_gens))) return 0;
     for (size_t i0 = 0; i0 < n; i0 += per) {
@@ -1530,6 +1560,7 @@ extern "C" int secp256k1_bppp_commit_batch(s2k_engine* e, unsigned char* commits
     const size_t io = ws_need({33 * n, 4 * n, 33 * n_gens, 32 * g_len * n, 32 * h_len * n, 32 * h_len * n, 32 * n});
     if (!engine_workspace(e, bpc_ws_bytes(std::min(n, per), n_gens) + io)) return 0;
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     ws_carver c0{e->ws, bpc_ws_bytes(std::min(n, per), n_gens)};
     unsigned char* d_out = c0.take<unsigned char>(33 * n); int32_t* d_res = c0.take<int32_t>(n); unsigned char* d_g33 = c0.take<unsigned char>(33 * n_gens);
     unsigned char* d_nv = c0.take<unsigned char>(32 * g_len * n); unsigned char* d_lv = c0.take<unsigned char>(32 * h_len * n);
@@ -1570,6 +1601,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* s
     HIPCHK(hipSetDevice(e->device));
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
@@ -1595,6 +1627,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch(s2k_engine* e, int32_t* re
     int32_t* d_res = w.take<int32_t>(n); unsigned char* d_pr = w.take<unsigned char>(pbytes + 64); uint64_t* d_po = w.take<uint64_t>(n + 1);
     unsigned char* d_in = w.take<unsigned char>(64 * ntags + 64); uint64_t* d_to = w.take<uint64_t>(n + 1); unsigned char* d_out = w.take<unsigned char>(64 * n);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_po, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
     if (ntags) HIPCHK(hipMemcpyAsync(d_in, input_tags64, 64 * ntags, hipMemcpyHostToDevice, st));
@@ -1694,6 +1727,7 @@ extern "C" int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, i
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) { HIPCHK(hipMemsetAsync(result_dev, 0, 4, st)); return 1; }     // main_impl.h:122-125
     if (!engine_workspace(e, ha_ws_bytes(n))) return 0;
     ws_carver c{e->ws, 0};
@@ -1714,6 +1748,7 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     unsigned char* d_pk = c0.take<unsigned char>(pkb * n + 64); unsigned char* d_msg = c0.take<unsigned char>(32 * n + 64);
     unsigned char* d_agg = c0.take<unsigned char>(32 * (n + 1)); int32_t* d_res = c0.take<int32_t>(4);
     hipStream_t st = e->stream;
+    stream_guard sg(e, st);
     if (n) {
         HIPCHK(hipMemcpyAsync(d_pk, pubkeys, pkb * n, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_msg, msgs32, 32 * n, hipMemcpyHostToDevice, st));
@@ -1783,6 +1818,7 @@ static int tally_impl(s2k_engine* e, void* stream, int32_t* results, const unsig
     std::vector<u32*> d_offs; for (size_t r = 0; r < offs.size(); r++) d_offs.push_back(c.take<u32>(n_tallies + 1));
     u32* bufA = c.take<u32>((total + 1) * 28); u32* bufB = c.take<u32>((half + 1) * 28);
     hipStream_t st = (dev && stream) ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
     if (dev) { d_c = (unsigned char*)commits33; d_res = results; }
     else if (total) HIPCHK(hipMemcpyAsync(d_c, commits33, 33 * total, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_off, tally_off, 8 * (n_tallies + 1), hipMemcpyHostToDevice, st));

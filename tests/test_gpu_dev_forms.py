@@ -141,3 +141,30 @@ def test_rangeproof_dev_calls_in_flight(engine, ref):
         ok = d["want"] == 1
         assert (d["mn"].cpu().numpy().astype(np.uint64)[ok] == np.asarray(d["wmin"], dtype=np.uint64)[ok]).all()
         assert (d["mx"].cpu().numpy().astype(np.uint64)[ok] == np.asarray(d["wmax"], dtype=np.uint64)[ok]).all()
+
+
+def test_dev_calls_on_two_streams_share_the_scratch_safely(engine, ref):
+    """The workspace and the table arena are per engine: `_dev` calls issued alternately on two caller streams must be ordered by the
+    engine itself (stream_guard in engine.hip), so that each result equals the reference's whatever the interleaving."""
+    import torch
+    from tests.refapi import G_XY
+    rng = np.random.default_rng(5)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    jobs = []
+    for k in range(6):
+        n = 3000 + 517 * k
+        a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        base, _ = ref.ecmult_batch(np.tile(np.frombuffer(G_XY, np.uint8), (n, 1)), a)
+        na = rng.integers(0, 256, (n, 32), dtype=np.uint8); ng = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        want, winf = ref.ecmult_batch(base, na, ng=ng)
+        jobs.append(dict(n=n, a=_d(base), na=_d(na), ng=_d(ng), want=want, winf=winf,
+                         r=torch.zeros(64 * n, dtype=torch.uint8, device="cuda"), inf=torch.full((n,), 9, dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for k, j in enumerate(jobs):
+            st = (s1, s2)[k & 1]
+            engine.ecmult_batch_dev(j["r"], j["inf"], j["a"], j["na"], ng=j["ng"], stream=ctypes.c_void_p(st.cuda_stream))
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert (j["inf"].cpu().numpy() == np.asarray(j["winf"]).reshape(-1)).all()
+        assert (j["r"].cpu().numpy().reshape(-1, 64) == np.asarray(j["want"]).reshape(-1, 64)).all()
