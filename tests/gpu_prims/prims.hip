@@ -66,6 +66,22 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         fe_normalize(r1); fe_normalize(r2);
         fe_get_b32(out + 64 * i, r1); fe_get_b32(out + 64 * i + 32, r2);
     } break;
+    case 38: {   // two-piece double multiplication (ecmult_lane_split) given A (random Z from c) and T = 2^64 A, with the caller's fallback to
+                 // ecmult_lane; a = points, b = (na || ng) 64 bytes per item; flag = 2 * took_split + infinity
+        __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+        ge p; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32);
+        gej A, T, R; gej_set_ge(A, p);
+        { fe zz, z2, z3; fe_set_b32_mod(zz, c + 32 * i); fe_norm_weak(zz); fe_sqr(z2, zz); fe_mul(z3, z2, zz); fe_mul(A.x, A.x, z2); fe_mul(A.y, A.y, z3); A.z = zz; }
+        T = A; for (int k = 0; k < 64; k++) { gej t; gej_double(t, T); T = t; }
+        scalar na, ng; sc_set_b32(na, b + 64 * i, nullptr); sc_set_b32(ng, b + 64 * i + 32, nullptr);
+        u32* ptab = (u32*)flag + n + (size_t)i * S2K_PTAB_WORDS;          // scratch behind the flags (the test allocates it)
+        const lane_mem lm{ptab, S2K_LANE_DIG(s_dig)};
+        const int done = ecmult_lane_split(R, A, T, na, ng, 1, gtab, lm);
+        if (!S2K_WAVE_ALL(done)) ecmult_lane(R, A, na, ng, 1, gtab, lm);
+        ge r; r.x = R.x; r.y = R.y; if (!R.inf) ge_set_gej(r, R);
+        flag[i] = 2 * (S2K_WAVE_ALL(done) ? 1 : 0) + (R.inf ? 1 : 0);
+        fe_normalize(r.x); fe_normalize(r.y); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
+    } break;
     case 37: {   // lean point operations (group.h) against the general ones: double, then add b, from an affine start
         ge p, q; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_set_b32_mod(q.x, b + 64 * i); fe_set_b32_mod(q.y, b + 64 * i + 32);
         gej j; gej_set_ge(j, p);

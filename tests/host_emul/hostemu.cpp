@@ -130,6 +130,21 @@ int emu_ecmult(unsigned char* r64, const unsigned char* a64, int ainf, const uns
     ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host(), lm);
     return gej_to_b64(r64, R);
 }
+// the two-piece form (ecmult_lane_split) given A and T = 2^64 A, falling back to ecmult_lane exactly as rangeproof.h does; *took_split = 1
+// when the two-piece form produced the result
+int emu_ecmult_split(unsigned char* r64, int* took_split, const unsigned char* a64, const unsigned char* na32, const unsigned char* ng32, const unsigned char* z32) {
+    ge a; gej A, T, R; scalar na, ng; ge_from_b64(a, a64);
+    gej_set_ge(A, a);
+    if (z32) { fe z, z2, z3; fe_from_b32(z, z32); fe_norm_weak(z); fe_sqr(z2, z); fe_mul(z3, z2, z); fe_mul(A.x, A.x, z2); fe_mul(A.y, A.y, z3); A.z = z; }
+    T = A; for (int k = 0; k < 64; k++) { gej t; gej_double(t, T); T = t; }
+    sc_set_b32(na, na32, 0);
+    if (ng32) sc_set_b32(ng, ng32, 0); else sc_set_zero(ng);
+    u32 dig[S2K_DIG_WORDS]; const lane_mem lm{g_ptab, dig};
+    const int done = ecmult_lane_split(R, A, T, na, ng, ng32 != 0, gtab_host(), lm);
+    if (!done) ecmult_lane(R, A, na, ng, ng32 != 0, gtab_host(), lm);
+    *took_split = done;
+    return gej_to_b64(r64, R);
+}
 void emu_sha256(unsigned char* out32, const unsigned char* msg, size_t len) {
     sha256_stream c; sha256_stream_init(c); sha256_stream_write(c, msg, len); sha256_stream_finalize(c, out32);
 }

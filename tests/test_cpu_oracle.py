@@ -119,6 +119,32 @@ def test_emu_group_ecmult(emu, ref):
             assert e1 == _call(emu, "emu_ecmult", [64], a, ai, na, ng, z)
 
 
+LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+SPLIT_EDGE_SCALARS = [1, 2, 3, 15, 16, 17, 2**64 - 1, 2**64, 2**64 + 1, 2**65, 2**65 - 1, 2**127, 2**128, 2**128 + 2**64, 2**129 - 1, N - 1, N - 2, (N - 1) // 2,
+                      LAMBDA, LAMBDA + 1, N - LAMBDA, (LAMBDA * 2**64) % N, 2**255, N - 2**64, 0]
+
+
+def test_emu_ecmult_two_piece_form(emu, ref):
+    """ecmult_lane_split (given T = 2^64 A; used by the rangeproof rings) with its fallback, on edge scalars of the piece split --
+    multiples of 2^64, the lambda values, 0 (no variable part: the form refuses and the caller falls back) -- and random ones."""
+    rng = np.random.default_rng(44)
+    pts = [ref.rand_point(rng) for _ in range(6)] + [G_XY]
+    took = ctypes.c_int(0)
+    n_split = 0
+    scal = [_b(v) for v in SPLIT_EDGE_SCALARS] + [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(12)]
+    for i, na in enumerate(scal):
+        a = pts[i % len(pts)]
+        for ng in (bytes(rng.integers(0, 256, 32, dtype=np.uint8)), _b(0), None):
+            e1 = _call(ref.lib, "ref_ecmult", [64], a, 0, na, ng)
+            z = bytes(rng.integers(0, 256, 32, dtype=np.uint8)) if i % 2 else None
+            got = _call(emu, "emu_ecmult_split", [64], ctypes.byref(took), a, na, ng, z)
+            assert got == e1, (i, ng is None)
+            n_split += took.value
+            if int.from_bytes(na, "big") == 0:
+                assert took.value == 0
+    assert n_split >= 2 * len(scal)          # the two-piece form itself produced (nearly) all of these
+
+
 def _emu_rp(emu, c, p, g, extra=b""):
     mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0)
     r = emu.emu_rangeproof_verify(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)), g.tobytes())

@@ -21,15 +21,15 @@ def prims(engine):
     gsz = ctypes.c_size_t(0)
     gtab = engine._lib.s2k_engine_gtable(engine._h, ctypes.byref(gsz))
 
-    def run(op, n, out_bytes, a=None, b=None, c=None):
+    def run(op, n, out_bytes, a=None, b=None, c=None, scratch_words=0):
         dev = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x, np.uint8).reshape(-1)).cuda()
         ta, tb, tc = dev(a), dev(b), dev(c)
-        out = torch.zeros(n * out_bytes, dtype=torch.uint8, device="cuda"); flag = torch.zeros(n, dtype=torch.int32, device="cuda")
+        out = torch.zeros(n * out_bytes, dtype=torch.uint8, device="cuda"); flag = torch.zeros(n + scratch_words, dtype=torch.int32, device="cuda")
         ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         torch.cuda.synchronize()
         ok = lib.s2k_test_prim(op, ptr(out), ptr(flag), ptr(ta), ptr(tb), ptr(tc), ctypes.c_void_p(gtab), n)
         assert ok == 1
-        return out.cpu().numpy().reshape(n, out_bytes), flag.cpu().numpy()
+        return out.cpu().numpy().reshape(n, out_bytes), flag.cpu().numpy()[:n]
     return run
 
 
@@ -244,3 +244,32 @@ def test_lean_point_ops(prims, ref):
         r1 = ref.call("ref_ge_add", [64], g4[i].tobytes(), 0, B[i].tobytes(), 0)[1][0]
         r2 = ref.call("ref_ge_double", [64], r1, 0)[1][0]
         assert got[i].tobytes() == r2, i
+
+
+def test_two_piece_double_multiplication_on_device(prims, ref):
+    """ecmult_lane_split (the rangeproof rings' form: T = 2^64 A given) with the caller's fallback, one class of scalar per wavefront so
+    that the lock-step form really runs: edge values of the piece split (multiples of 2^64, lambda, n-1, ...), 0 (the form refuses, the
+    wavefront falls back) and random scalars; random Jacobian Z on the inputs; against the reference's secp256k1_ecmult."""
+    from tests.test_cpu_oracle import SPLIT_EDGE_SCALARS
+    rng = np.random.default_rng(45)
+    classes = SPLIT_EDGE_SCALARS + [None] * 7
+    n = 64 * len(classes)
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    A, _ = ref.ecmult_batch(np.tile(np.frombuffer(G_XY, np.uint8), (n, 1)), base)
+    na = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for k, v in enumerate(classes):
+        if v is not None:
+            na[64 * k:64 * (k + 1)] = np.frombuffer(_b(v), np.uint8)
+    ng = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for k in range(0, len(classes), 5):
+        ng[64 * k:64 * (k + 1)] = 0                     # a whole wavefront without a generator part (the form wants the lanes to agree)
+    z = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    want, winf = ref.ecmult_batch(A, na, ng=ng)
+    got, flag = prims(38, n, 64, A, np.concatenate([na, ng], axis=1), z, scratch_words=n * 544 + 64)
+    took = flag >> 1
+    for k, v in enumerate(classes):
+        sl = slice(64 * k, 64 * (k + 1))
+        assert ((flag[sl] & 1) == winf[sl]).all(), k
+        ok = winf[sl] == 0
+        assert (got[sl][ok] == want[sl][ok]).all(), k
+        assert took[sl].all() == (v != 0), (k, v)        # the two-piece form produced every class but na = 0
