@@ -995,13 +995,14 @@ k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunk
     }
     if (t == 0) for (int i = 0; i < 28; i++) out28[(size_t)blockIdx.x * 28 + i] = sh[i];
 }
-// Horner over the share's windows (~c*windows sequential doublings: the latency floor of one MSM).  One lane; its own launch
-// bounds so that the whole point state stays in registers.
+// Horner over the share's windows (~c*windows sequential doublings: the latency floor of one MSM).  One wavefront, all 64 lanes
+// running the same point through msm_combine: the runs of doublings spread each field element over the lanes (cofield.h), the
+// additions in between are the serial code executed redundantly.  Its own launch bounds so that the point state stays in registers.
 __global__ void __launch_bounds__(64)
 k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
-    if (threadIdx.x || blockIdx.x) return;
+    if (blockIdx.x) return;
     gej r; msm_combine(r, wsum28, pl);
-    gej_store28(out28, r);
+    if (threadIdx.x == 0) gej_store28(out28, r);
 }
 // exact path: final <- exact result when the binning pass overflowed a bucket region
 __global__ void k_msm_pick(u32* final28, const u32* exact28, const u32* flags) {

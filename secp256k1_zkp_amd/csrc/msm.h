@@ -27,6 +27,7 @@
 // points (:55, :848-855).
 #pragma once
 #include "gtable.h"
+#include "cofield.h"
 
 #define MSM_SMALL_N 192
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
@@ -232,16 +233,26 @@ S2K_HD void msm_scale(gej& out, const gej& in, u32 weight) {
 }
 
 // ---- final combine: r = sum_{w in [w0, w0+wn)} 2^(c w) S_w ; window_sums28 holds the wn local sums --------------------------
+// Horner: ~c * windows dependent doublings of one point -- the latency floor of an MSM.  On the device the runs of doublings go
+// through the wave-cooperative form (cofield.h: limb l in lane l, ~2.2x fewer instructions on the critical path); every lane of the
+// wavefront must call this with the same arguments (k_msm_combine runs all 64).
+S2K_HD void msm_double_n(gej& acc, u32 count) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    gej_double_n_cooperative(acc, count);
+#else
+    if (!acc.inf) for (u32 k = 0; k < count; k++) { gej s; gej_double(s, acc); acc = s; }
+#endif
+}
 S2K_HD void msm_combine(gej& r, const u32* window_sums28, const msm_plan& pl) {
     gej acc; gej_set_infinity(acc);
     for (int w = (int)pl.wn - 1; w >= 0; w--) {
-        if (!acc.inf) for (u32 k = 0; k < pl.c; k++) { gej s; gej_double(s, acc); acc = s; }
+        msm_double_n(acc, pl.c);
         gej sw;
         for (int i = 0; i < 9; i++) { sw.x.n[i] = window_sums28[28 * w + i]; sw.y.n[i] = window_sums28[28 * w + 9 + i]; sw.z.n[i] = window_sums28[28 * w + 18 + i]; }
         sw.inf = (int)window_sums28[28 * w + 27];
         gej s; gej_add_var(s, acc, sw); acc = s;
     }
-    if (!acc.inf) for (u32 k = 0; k < pl.c * pl.w0; k++) { gej s; gej_double(s, acc); acc = s; }
+    msm_double_n(acc, pl.c * pl.w0);
     r = acc;
 }
 

@@ -3,6 +3,7 @@
 // (role of the reference's per-primitive unit tests, src/tests.c:3375-4213).  Not part of the product library.
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
+#include "../../secp256k1_zkp_amd/csrc/cofield.h"
 #include <hip/hip_runtime.h>
 
 __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned char* a, const unsigned char* b, const unsigned char* c, const u32* gtab, int n) {
@@ -65,6 +66,29 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         else { fe_sqr2(r1, u, r2, w); }                                         // a^2, c^2
         fe_normalize(r1); fe_normalize(r2);
         fe_get_b32(out + 64 * i, r1); fe_get_b32(out + 64 * i + 32, r2);
+    } break;
+    case 39: {   // wave-cooperative field arithmetic (cofield.h) against the integers / the reference: one item per WAVEFRONT (n = 64 * items,
+                 // 64-lane blocks).  a, b: 9 raw limbs each (lazy magnitudes chosen by the test), c: an affine point.
+                 // out (192 bytes per item, written by lane 0): a*b | a*b + b*b | b - 3a/2 | 2^13 * c (x, y)
+        const int it = i >> 6;
+        fe fa, fb; for (int k = 0; k < 9; k++) { fa.n[k] = ((const u32*)a)[9 * it + k]; fb.n[k] = ((const u32*)b)[9 * it + k]; }
+        cfe ca, cb, r1, r2, r3; cfe_from_fe(ca, fa); cfe_from_fe(cb, fb);
+        cfe_mul(r1, ca, cb);
+        cfe_muladd(r2, ca, cb, cb, cb);
+        r3 = ca; cfe_mul_int(r3, 3); cfe_half(r3); cfe_norm_weak(r3); cfe_neg(r3, r3, 1); cfe_add(r3, cb); cfe_norm_weak(r3);
+        ge p; fe_set_b32_mod(p.x, c + 64 * it); fe_set_b32_mod(p.y, c + 64 * it + 32);
+        gej j; gej_set_ge(j, p); gej_double_n_cooperative(j, 13);
+        ge o; ge_set_gej(o, j);
+        fe q1, q2, q3; cfe_to_fe(q1, r1); cfe_to_fe(q2, r2); cfe_to_fe(q3, r3);
+        // lanes >= 9 must still hold zero
+        const u32 stray = (co_lane() >= 9) ? (r1.v | r2.v | r3.v) : 0u;
+        const int clean = !__any((int)(stray != 0u));
+        if ((i & 63) == 0) {
+            unsigned char* w = out + 192 * it;
+            fe_normalize(q1); fe_get_b32(w, q1); fe_normalize(q2); fe_get_b32(w + 32, q2); fe_normalize(q3); fe_get_b32(w + 64, q3);
+            fe_normalize(o.x); fe_normalize(o.y); fe_get_b32(w + 96, o.x); fe_get_b32(w + 128, o.y);
+            flag[i] = clean;
+        }
     } break;
     case 38: {   // two-piece double multiplication (ecmult_lane_split) given A (random Z from c) and T = 2^64 A, with the caller's fallback to
                  // ecmult_lane; a = points, b = (na || ng) 64 bytes per item; flag = 2 * took_split + infinity

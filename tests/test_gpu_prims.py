@@ -273,3 +273,41 @@ def test_two_piece_double_multiplication_on_device(prims, ref):
         ok = winf[sl] == 0
         assert (got[sl][ok] == want[sl][ok]).all(), k
         assert took[sl].all() == (v != 0), (k, v)        # the two-piece form produced every class but na = 0
+
+
+def test_cooperative_field_arithmetic(prims, ref):
+    """cofield.h (one field element spread over the lanes of a wavefront: DPP lane shifts, v_readlane, ds_bpermute) against the
+    integers and the reference group law, with lazily reduced inputs up to the magnitude contract's limits (product of magnitudes 7
+    for a product, 6-7 for the fused pair) and all-ones limbs."""
+    rng = np.random.default_rng(91)
+    M29, TOP = (1 << 29) - 1, (1 << 24) - 1
+    plimbs = [(P >> (29 * i)) & M29 for i in range(9)]
+
+    def rep(v, mag, full=False):
+        if full:
+            return [mag * M29] * 8 + [mag * TOP]
+        return [((v >> (29 * i)) & M29) + (mag - 1) * plimbs[i] for i in range(9)]
+    val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))
+    items = 256
+    A = np.zeros((items, 9), np.uint32); B = np.zeros((items, 9), np.uint32); want = []
+    pts = np.frombuffer(b"".join(ref.rand_point(rng) for _ in range(items)), np.uint8).reshape(items, 64)
+    mags = [(1, 1), (2, 1), (1, 2), (2, 1), (1, 1), (1, 2)]
+    for it in range(items):
+        ma, mb = mags[it % len(mags)]
+        assert ma * mb + mb * mb <= 7 and 3 * ma <= 7
+        a = int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "big") % P
+        b = int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "big") % P
+        if it < 8:
+            a, b = [(0, 0), (1, 1), (P - 1, P - 1), (P - 1, 1), (2**255, 2**255), (0, P - 1), (2**224 - 1, 2**232), (977, 2**32)][it]
+        la, lb = rep(a, ma, full=(it % 16 == 9)), rep(b, mb, full=(it % 16 == 9 or it % 16 == 10))
+        A[it] = la; B[it] = lb
+        a, b = val(la) % P, val(lb) % P
+        want.append((a * b % P, (a * b + b * b) % P, (b - 3 * a * pow(2, -1, P)) % P))
+    dbl, _ = ref.ecmult_batch(pts, np.tile(np.frombuffer(_b(2**13), np.uint8), (items, 1)))
+    got, flag = prims(39, 64 * items, 3, A.view(np.uint8), B.view(np.uint8), pts)
+    got = got.reshape(-1)[:192 * items].reshape(items, 192)
+    assert (flag[::64] == 1).all()                       # lanes >= 9 still hold zero after every routine
+    for it in range(items):
+        for k in range(3):
+            assert got[it, 32 * k:32 * k + 32].tobytes() == _b(want[it][k]), (it, k)
+        assert got[it, 96:160].tobytes() == dbl[it].tobytes(), it
