@@ -133,6 +133,45 @@ S2K_D void cgej_double(cgej& p) {
     cfe_neg(y3, y3, 1);
     p.x = x3; p.y = y3; p.z = z3;
 }
+// exact zero test of a cooperative element: through the serial sequential normalisation, every lane redundantly (cold: once or
+// twice per addition)
+S2K_D int cfe_is_zero(const cfe& a) { fe t; cfe_to_fe(t, a); return fe_normalizes_to_zero(t); }
+// p <- p + q, both finite Jacobian points in cooperative form (12M + 4S, the formulas of gej_add_var); complete: p == q doubles, p == -q
+// returns 1 (the sum is the point at infinity, p is then meaningless).  Magnitudes in: up to (5, 3, 1); out: (1, 1, 1).
+S2K_D int cgej_add(cgej& p, const cgej& q) {
+    cfe z22, z12, u1, u2, s1, s2, h, i, zz, h2, i2, h3, t, x3, tn, nh3, y3, z3;
+    cfe_sqr(z22, q.z); cfe_sqr(z12, p.z);
+    cfe_mul(u1, p.x, z22); cfe_mul(u2, q.x, z12);
+    cfe_mul(s1, p.y, z22); cfe_mul(s2, q.y, z12);
+    cfe_mul(s1, s1, q.z); cfe_mul(s2, s2, p.z);
+    cfe_neg(h, u1, 1); cfe_add(h, u2);                         // (3)
+    cfe_neg(i, s1, 1); cfe_add(i, s2);                         // (3)
+    if (cfe_is_zero(h)) {
+        if (!cfe_is_zero(i)) return 1;                         // p == -q
+        cfe_norm_weak(p.x); cfe_norm_weak(p.y);
+        cgej_double(p);                                        // p == q
+        return 0;
+    }
+    cfe_norm_weak(h); cfe_norm_weak(i);
+    cfe_mul(zz, p.z, q.z); cfe_sqr(h2, h);
+    cfe_mul(z3, zz, h); cfe_sqr(i2, i);
+    cfe_mul(h3, h, h2); cfe_mul(t, u1, h2);
+    cfe_neg(x3, h3, 1); cfe_neg(tn, t, 1);
+    cfe_add(x3, tn); cfe_add(x3, tn); cfe_add(x3, i2);         // X3 = i^2 - h^3 - 2t   (7)
+    cfe_norm_weak(x3);
+    cfe_neg(tn, x3, 1); cfe_add(tn, t);                        // t - X3                (3)
+    cfe_neg(nh3, h3, 1);                                       // -h^3                  (2)
+    cfe_muladd(y3, tn, i, nh3, s1);                            // Y3 = i (t - X3) - s1 h^3 : 3*1 + 2*1
+    p.x = x3; p.y = y3; p.z = z3;
+    return 0;
+}
+// the 28-word record of a Jacobian point (limbs x, y, z, infinity flag), straight into cooperative form: lane l loads limb l
+S2K_D int cgej_load28(cgej& r, const u32* p28) {
+    const u32 l = co_lane();
+    r.x.v = (l < 9) ? p28[l] : 0u; r.y.v = (l < 9) ? p28[9 + l] : 0u; r.z.v = (l < 9) ? p28[18 + l] : 0u;
+    cfe_norm_weak(r.x); cfe_norm_weak(r.y);
+    return (int)p28[27];
+}
 // r <- 2^count * r for a serial point r that is the same in every lane of the wavefront (all 64 lanes must be here)
 S2K_D void gej_double_n_cooperative(gej& r, u32 count) {
     if (r.inf || count == 0) return;

@@ -19,7 +19,7 @@
 //   msm_finish   1 lane / bucket : the bucket's own weight  b * B_b  by a short double-and-add (replaces the reference's
 //                                  serial running sum :581-588, which has no parallelism inside a window)
 //   gej_reduce   tree sums       : per-window totals S_w
-//   msm_combine  1 lane          : Horner over windows  r = sum_w 2^(c w) S_w   (c*W ~ 136 doublings)
+//   msm_combine  1 wavefront     : Horner over windows  r = sum_w 2^(c w) S_w   (c*W ~ 136 doublings, wave-cooperative: cofield.h)
 //
 // Any order of additions gives the same group element, so the atomics-driven bucket order does not affect the
 // (bit-exact) serialised result.  Small inputs (n < MSM_SMALL_N) skip the bucket machinery: one full
@@ -233,27 +233,46 @@ S2K_HD void msm_scale(gej& out, const gej& in, u32 weight) {
 }
 
 // ---- final combine: r = sum_{w in [w0, w0+wn)} 2^(c w) S_w ; window_sums28 holds the wn local sums --------------------------
-// Horner: ~c * windows dependent doublings of one point -- the latency floor of an MSM.  On the device the runs of doublings go
-// through the wave-cooperative form (cofield.h: limb l in lane l, ~2.2x fewer instructions on the critical path); every lane of the
-// wavefront must call this with the same arguments (k_msm_combine runs all 64).
-S2K_HD void msm_double_n(gej& acc, u32 count) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    gej_double_n_cooperative(acc, count);
-#else
-    if (!acc.inf) for (u32 k = 0; k < count; k++) { gej s; gej_double(s, acc); acc = s; }
-#endif
+// Horner: ~c * windows dependent doublings of one point -- the latency floor of an MSM.  On the device the runs of doublings
+// and the additions between them run in the wave-cooperative form (cofield.h: limb l in lane l, ~2.2x fewer instructions on the
+// critical path); every lane of the wavefront must call this with the same arguments (k_msm_combine runs all 64).
+#if defined(__HIPCC__)
+S2K_D void msm_combine_cooperative(gej& r, const u32* window_sums28, const msm_plan& pl) {
+    cgej acc; int acc_inf = 1;
+    acc.x.v = acc.y.v = acc.z.v = 0;
+    for (int w = (int)pl.wn - 1; w >= 0; w--) {
+        if (!acc_inf) {
+#pragma unroll 1
+            for (u32 k = 0; k < pl.c; k++) cgej_double(acc);
+        }
+        cgej sw;
+        if (!cgej_load28(sw, window_sums28 + 28 * w)) {
+            if (acc_inf) { acc = sw; acc_inf = 0; }
+            else acc_inf = cgej_add(acc, sw);
+        }
+    }
+    if (!acc_inf) {
+#pragma unroll 1
+        for (u32 k = 0; k < pl.c * pl.w0; k++) cgej_double(acc);
+        cgej_to_gej(r, acc);
+    } else gej_set_infinity(r);
 }
+#endif
 S2K_HD void msm_combine(gej& r, const u32* window_sums28, const msm_plan& pl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    msm_combine_cooperative(r, window_sums28, pl);
+#else
     gej acc; gej_set_infinity(acc);
     for (int w = (int)pl.wn - 1; w >= 0; w--) {
-        msm_double_n(acc, pl.c);
+        if (!acc.inf) for (u32 k = 0; k < pl.c; k++) { gej s; gej_double(s, acc); acc = s; }
         gej sw;
         for (int i = 0; i < 9; i++) { sw.x.n[i] = window_sums28[28 * w + i]; sw.y.n[i] = window_sums28[28 * w + 9 + i]; sw.z.n[i] = window_sums28[28 * w + 18 + i]; }
         sw.inf = (int)window_sums28[28 * w + 27];
         gej s; gej_add_var(s, acc, sw); acc = s;
     }
-    msm_double_n(acc, pl.c * pl.w0);
+    if (!acc.inf) for (u32 k = 0; k < pl.c * pl.w0; k++) { gej s; gej_double(s, acc); acc = s; }
     r = acc;
+#endif
 }
 
 // ---- the part of a scalar that a window share sees -------------------------------------------------------------------------

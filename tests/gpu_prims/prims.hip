@@ -79,6 +79,21 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         ge p; fe_set_b32_mod(p.x, c + 64 * it); fe_set_b32_mod(p.y, c + 64 * it + 32);
         gej j; gej_set_ge(j, p); gej_double_n_cooperative(j, 13);
         ge o; ge_set_gej(o, j);
+        // cooperative addition: 2^13 c + c (generic), c + c (doubling branch), c + (-c) (infinity): flag bits 1..3
+        int addok = 0;
+        {
+            cgej cj, cp, cn; gej t1, pj; gej_set_ge(pj, p);
+            cgej_from_gej(cj, j); cgej_from_gej(cp, pj);
+            const int inf1 = cgej_add(cj, cp); cgej_to_gej(t1, cj);
+            gej want; gej_add_var(want, j, pj);
+            ge g1, g2; ge_set_gej(g1, t1); ge_set_gej(g2, want);
+            addok |= (!inf1 && fe_equal(g1.x, g2.x) && fe_equal(g1.y, g2.y)) ? 2 : 0;
+            cgej_from_gej(cj, pj); const int inf2 = cgej_add(cj, cp); cgej_to_gej(t1, cj);
+            gej d2; gej_double(d2, pj); ge_set_gej(g1, t1); ge_set_gej(g2, d2);
+            addok |= (!inf2 && fe_equal(g1.x, g2.x) && fe_equal(g1.y, g2.y)) ? 4 : 0;
+            gej nj = pj; fe_neg(nj.y, nj.y, 1); fe_norm_weak(nj.y); cgej_from_gej(cn, nj); cgej_from_gej(cj, pj);
+            addok |= cgej_add(cj, cn) ? 8 : 0;
+        }
         fe q1, q2, q3; cfe_to_fe(q1, r1); cfe_to_fe(q2, r2); cfe_to_fe(q3, r3);
         // lanes >= 9 must still hold zero
         const u32 stray = (co_lane() >= 9) ? (r1.v | r2.v | r3.v) : 0u;
@@ -87,7 +102,7 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
             unsigned char* w = out + 192 * it;
             fe_normalize(q1); fe_get_b32(w, q1); fe_normalize(q2); fe_get_b32(w + 32, q2); fe_normalize(q3); fe_get_b32(w + 64, q3);
             fe_normalize(o.x); fe_normalize(o.y); fe_get_b32(w + 96, o.x); fe_get_b32(w + 128, o.y);
-            flag[i] = clean;
+            flag[i] = clean | addok;
         }
     } break;
     case 38: {   // two-piece double multiplication (ecmult_lane_split) given A (random Z from c) and T = 2^64 A, with the caller's fallback to
