@@ -1,3 +1,4 @@
+# Four MSM calls of n terms under rocprofv3 (--kernel-trace --stats) give the per-kernel breakdown in profiles/r02u_msm_*: python tools/msm_kernel_breakdown.py <n>
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
