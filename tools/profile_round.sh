@@ -53,7 +53,7 @@ timeout 600 python bench.py > gpurun_out/$TAG/bench_default.json 2> gpurun_out/$
 timeout 600 python tests/tools/throughput.py > gpurun_out/$TAG/throughput.json 2> gpurun_out/$TAG/throughput.err; tail -5 gpurun_out/$TAG/throughput.json
 timeout 300 python tests/tools/msm_sweep.py > gpurun_out/$TAG/msm_sweep.txt 2>&1; tail -20 gpurun_out/$TAG/msm_sweep.txt
 # board power and shader clock under the sustained workload (sampled next to a separate 60-step run, never next to the bench line above)
-(while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -e 's/=//g' | tr "\n" " "; echo; sleep 0.25; done) > gpurun_out/$TAG/power_clock.txt 2>&1 &
+(set +x; while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -e 's/=//g' | tr "\n" " "; echo; sleep 0.25; done) > gpurun_out/$TAG/power_clock.txt 2>&1 &
 SMI=$!
 timeout 300 python bench.py --steps 60 --warmup 2 --no-cpu-baseline --no-msm > gpurun_out/$TAG/bench_60_steps_with_smi_sampling.json 2>/dev/null
 kill $SMI
