@@ -839,7 +839,15 @@ k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned cha
 // refs layout: bucket k owns refs[k*cap .. k*cap + cap); gcnt[k] ends up as the bucket's full size even when it overflows.
 // The top window only has 128 - c*(windows-1) live bits (both GLV halves are below 2^128, scalar_impl.h:183-285), so its
 // few buckets are proportionally fuller: they get their own capacity.  Bucket k = w*nb + b starts at msm_region(k).
-struct msm_layout { u32 cap, cap_top, top_used; };     // top_used: buckets 0..top_used-1 of the top window have a region
+// The top window's few values would put n/2 points into each of a handful of buckets, and the depth of the partial-sum rounds follows
+// the fullest region: so every value v of the top window is SPREAD over `sub` buckets, (v - 1) * sub + (term index mod sub) + 1 --
+// all with the weight v (msm_bucket_weight) -- which brings the top window's regions down to the size of the others.
+struct msm_layout { u32 cap, cap_top, top_used, sub; };     // top_used: buckets 0..top_used-1 of the top window have a region; sub: power of two
+__host__ __device__ __forceinline__ u32 msm_bucket_weight(const msm_layout& L, const msm_plan& pl, u32 k) {      // k = w * nb + b, w local to the share
+    const u32 b = k % pl.nb;
+    const int top = (pl.w0 + k / pl.nb + 1 == pl.windows);
+    return (top && b) ? (b - 1u) / L.sub + 1u : b;
+}
 // (w = window index inside the launch's share [pl.w0, pl.w0 + pl.wn); the top window, if the share has it, is its last one)
 __device__ __forceinline__ size_t msm_region(const msm_layout& L, const msm_plan& pl, u32 w, u32 b) {
     return (pl.w0 + w + 1 < pl.windows) ? ((size_t)w * pl.nb + b) * L.cap : (size_t)(pl.wn - 1) * pl.nb * L.cap + (size_t)b * L.cap_top;
@@ -857,6 +865,8 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     // sweep: digit of every half-scalar of the chunk, rank inside the workgroup from the LDS histogram; the (bucket, rank, sign)
     // of the at most 8 terms x 2 halves a thread owns stay in registers (chunk <= 8 * MSM_BIN_THREADS)
     u32 kv[8][2];
+    int over = 0;
+    const int top = (pl.w0 + w + 1 == pl.windows);
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         kv[it][0] = 0; kv[it][1] = 0;
@@ -869,7 +879,14 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
-                if (key) { const u32 bkt = key >> 1, rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank; }
+                if (key) {
+                    u32 bkt = key >> 1;
+                    if (top) {                                           // value v -> one of its `sub` buckets, by term index
+                        if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }      // a value the top window cannot hold for a reduced half
+                        bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
+                    }
+                    const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                }
             }
         }
     }
@@ -879,8 +896,6 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
         s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;          // one global atomic per non-empty (workgroup, bucket)
     }
     __syncthreads();
-    int over = 0;
-    const int top = (pl.w0 + w + 1 == pl.windows);
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
@@ -962,10 +977,10 @@ k_msm_roundN(u32* out28, const u32* in28, const u32* off_in, const u32* off_out,
     gej_store28(out28 + (size_t)m * 28, acc);
 }
 __global__ void __launch_bounds__(256, 2)
-k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, msm_plan pl) {
+k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, msm_plan pl, msm_layout L) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nk) return;
-    const u32 b = k % pl.nb;
+    const u32 b = msm_bucket_weight(L, pl, k);                   // the bucket's digit value (the top window's values own several buckets each)
     gej v, o; gej_set_infinity(v);
     if (b != 0 && off_last[k + 1] > off_last[k]) gej_load28(v, in28 + (size_t)off_last[k] * 28);
     msm_scale(o, v, b);
@@ -1061,14 +1076,20 @@ static u32 msm_cap_for(double mean) {
 }
 static msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
     msm_layout L;
-    L.cap = msm_cap_for(2.0 * (double)nt / (double)(pl.nb - 1));
+    const double mean = 2.0 * (double)nt / (double)(pl.nb - 1);
+    L.cap = msm_cap_for(mean);
     const u32 top_bits = 128u - pl.c * (pl.windows - 1);              // live bits of the top window (0: only the carry reaches it)
     const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
-    L.top_used = top_vals + 1;
     // |k1| and |k2| stay below ~2^127.4 and ~2^126.9 (the GLV lattice bounds), so the top window's values are not uniform:
     // the low ones carry up to ~1.9x the uniform share.  4x (never more than every reference) leaves the same margin as below.
     double mean_top = 8.0 * (double)nt / (double)top_vals; if (mean_top > 2.0 * (double)nt) mean_top = 2.0 * (double)nt;
-    L.cap_top = msm_cap_for(mean_top);
+    // spread every value over `sub` buckets (see msm_layout) until its regions are about as full as the other windows', as far as the
+    // window's nb - 1 bucket slots go
+    u32 sub = 1;
+    while (sub * 2 * top_vals <= pl.nb - 1 && mean_top / (double)sub > 1.5 * mean) sub *= 2;
+    L.sub = sub;
+    L.top_used = top_vals * sub + 1;
+    L.cap_top = msm_cap_for(mean_top / (double)sub);
     return L;
 }
 static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
@@ -1172,7 +1193,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
         u32* t;
         t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
     }
-    hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl);
+    hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl, L);
     const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
     // exact path, un-gated only by the overflow flag

@@ -22,14 +22,15 @@
 //   msm_combine  1 wavefront     : Horner over windows  r = sum_w 2^(c w) S_w   (c*W ~ 136 doublings, wave-cooperative: cofield.h)
 //
 // Any order of additions gives the same group element, so the atomics-driven bucket order does not affect the
-// (bit-exact) serialised result.  Small inputs (n < MSM_SMALL_N) skip the bucket machinery: one full
-// double-and-add per lane (ecmult.h) and a tree sum -- the analogue of the reference switching to Strauss below 88
-// points (:55, :848-855).
+// (bit-exact) serialised result.  Very small inputs (n < MSM_SMALL_N) skip the bucket machinery: one full
+// double multiplication per lane (ecmult.h) and a tree sum -- the analogue of the reference switching to Strauss below 88
+// points (:55, :848-855).  The switch sits much lower here (32): one double multiplication is ~0.6 ms of latency on a single
+// wavefront, more than the whole bucket pipeline's ~0.8 ms floor leaves over (measured: profiles/r02x_msm_sweep.txt).
 #pragma once
 #include "gtable.h"
 #include "cofield.h"
 
-#define MSM_SMALL_N 192
+#define MSM_SMALL_N 32
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
 #define MSM_TERM_WORDS 28           // x[9], beta*x[9], y[9], flags
 

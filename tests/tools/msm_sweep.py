@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 eng.ecmult_batch_dev(pts, pinf, gpts, z, ks); torch.cuda.synchronize()
 scs = torch.tensor(rng.integers(0, 256, (nmax, 32), dtype=np.uint8)).to(dev)
 be = parallel.EngineBackend(eng)
-for n in (64, 128, 191, 192, 256, 512, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20, 1 << 22):
+for n in (16, 31, 32, 64, 128, 256, 512, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20, 1 << 22):
     parallel.msm_sharded(be, scs[:n], pts[:n]); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(3): parallel.msm_sharded(be, scs[:n], pts[:n])
