@@ -72,6 +72,7 @@ struct s2k_engine {
     int rp_done_valid[2]; unsigned rp_seq;
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
     hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
+    hipEvent_t ev_msm_fork, ev_msm_join;   // the MSM's gated exact path runs on the side stream, next to the bucket pipeline
     int rp_inputs_ready;       // S2K_OPT_RP_INPUTS_READY: the side-stream stage need not wait for earlier work of the caller's stream
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
@@ -200,7 +201,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
     for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
     e->ring_seq = 0;
-    e->last_stream = nullptr; e->last_stream_valid = 0; e->ev_last = nullptr;
+    e->last_stream = nullptr; e->last_stream_valid = 0; e->ev_last = nullptr; e->ev_msm_fork = nullptr; e->ev_msm_join = nullptr;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
@@ -221,6 +222,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 32; i++) { S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][0])); S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][1])); }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_fork, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_join, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
@@ -262,6 +265,8 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     }
     for (int i = 0; i < 32; i++) for (int j = 0; j < 2; j++) if (e->ev_ring[i][j]) hipEventDestroy(e->ev_ring[i][j]);
     if (e->ev_last) hipEventDestroy(e->ev_last);
+    if (e->ev_msm_fork) hipEventDestroy(e->ev_msm_fork);
+    if (e->ev_msm_join) hipEventDestroy(e->ev_msm_join);
     if (e->ev_rp_in) hipEventDestroy(e->ev_rp_in);
     if (e->stream_pre) { hipStreamSynchronize(e->stream_pre); hipStreamDestroy(e->stream_pre); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -1172,6 +1177,13 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
+    // empty) launches do not sit behind the Horner tail of every call
+    HIPCHK(hipEventRecord(e->ev_msm_fork, st));
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_msm_fork, 0));
+    hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, e->stream2, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
+    const u32* ex = launch_gej_reduce(e->stream2, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
+    HIPCHK(hipEventRecord(e->ev_msm_join, e->stream2));
     hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl);
     // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
     const int has_top = (pl.w0 + pl.wn == pl.windows);
@@ -1196,9 +1208,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl, L);
     const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
-    // exact path, un-gated only by the overflow flag
-    hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, st, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
-    const u32* ex = launch_gej_reduce(st, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
+    HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
     hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags);
     hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
     HIPCHK(hipGetLastError());
