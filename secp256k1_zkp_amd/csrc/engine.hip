@@ -991,21 +991,25 @@ k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, ms
     msm_scale(o, v, b);
     gej_store28(bucket_out28 + (size_t)k * 28, o);
 }
-// segmented tree sum: block (seg, chunk) adds up items [chunk*per_block, ...) of segment `seg` (seg_len items each)
-__global__ void __launch_bounds__(256)
+// segmented tree sum: block (seg, chunk) adds up items [chunk*per_block, ...) of segment `seg` (seg_len items each).  BS lanes per block:
+// 256 for long segments; 64 (one wavefront, six tree levels instead of eight, a quarter of the LDS) when a segment has at most 256
+// items -- the per-proof sums of the BP++ verifier (~80 terms), the per-window sums of a small MSM -- where most of a 256-lane
+// block would run its tree levels on points at infinity.
+template <int BS>
+__global__ void __launch_bounds__(BS)
 k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunks, const u32* gate) {
-    __shared__ u32 sh[256 * 28];
+    __shared__ u32 sh[BS * 28];
     if (gate && *gate == 0) return;                  // exact-path launches do nothing unless the overflow flag is up
     const u32 seg = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, t = threadIdx.x;
     const u32 lo = chunk * per_block, hi = min(lo + per_block, seg_len);
     gej acc; gej_set_infinity(acc);
-    for (u32 k = lo + t; k < hi; k += 256) {
+    for (u32 k = lo + t; k < hi; k += BS) {
         gej v; gej_load28(v, in28 + ((size_t)seg * seg_len + k) * 28);
         gej s; gej_add_var(s, acc, v); acc = s;
     }
     gej_store28(sh + t * 28, acc);
     __syncthreads();
-    for (u32 d = 128; d >= 1; d >>= 1) {
+    for (u32 d = BS / 2; d >= 1; d >>= 1) {
         if (t < d) {
             gej a, b, s; gej_load28(a, sh + t * 28); gej_load28(b, sh + (t + d) * 28);
             gej_add_var(s, a, b);
@@ -1068,7 +1072,8 @@ static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u3
     const u32* cur = in; u32* dst = bufA;
     while (seg_len > 1) {
         const u32 per_block = 1024, nchunks = (seg_len + per_block - 1) / per_block;
-        hipLaunchKernelGGL(k_gej_reduce, dim3(nseg * nchunks), dim3(256), 0, st, dst, cur, seg_len, per_block, nchunks, gate);
+        if (seg_len <= 256) hipLaunchKernelGGL(k_gej_reduce<64>, dim3(nseg * nchunks), dim3(64), 0, st, dst, cur, seg_len, per_block, nchunks, gate);
+        else hipLaunchKernelGGL(k_gej_reduce<256>, dim3(nseg * nchunks), dim3(256), 0, st, dst, cur, seg_len, per_block, nchunks, gate);
         cur = dst; dst = (dst == bufA) ? bufB : bufA; seg_len = nchunks;
     }
     return cur;
