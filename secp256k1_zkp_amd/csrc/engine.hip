@@ -78,6 +78,7 @@ struct s2k_engine {
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
     u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
+    int bp_gens_ok;            // every generator of the cached set parsed (what k_bp_gens found when the table was built)
     std::recursive_mutex mu;
 };
 
@@ -197,7 +198,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr; e->bp_gens_ok = 0;
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
     for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
     e->ring_seq = 0;
@@ -1384,9 +1385,12 @@ __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof
 // fixed-base table of a generator set: built on first use, kept for the following calls (a deployment has one set).
 // Sets too large for the table (> 256 generators = 19 GB) take the general path (*fixed = 0).  gens18: the set's affine points on
 // the device (k_bp_gens already queued on st); gens33: the serialised set on the HOST (the cache key).
-static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, const unsigned char* gens33, size_t n_gens, int* fixed) {
+static int bp_table_cached(const s2k_engine* e, const unsigned char* gens33, size_t n_gens) {
+    return n_gens <= 256 && e->bp_tab && e->bp_key.size() == 33 * n_gens && memcmp(e->bp_key.data(), gens33, 33 * n_gens) == 0;
+}
+static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, const int* gens_ok_dev, const unsigned char* gens33, size_t n_gens, int* fixed) {
     *fixed = n_gens <= 256;
-    if (*fixed && (e->bp_key.size() != 33 * n_gens || memcmp(e->bp_key.data(), gens33, 33 * n_gens) != 0)) {
+    if (*fixed && !bp_table_cached(e, gens33, n_gens)) {
         HIPCHK(hipStreamSynchronize(st));
         if (e->bp_tab) { hipFree(e->bp_tab); e->bp_tab = nullptr; }
         e->bp_key.clear();
@@ -1396,7 +1400,10 @@ static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, con
             hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
             hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
             HIPCHK(hipGetLastError());
+            int ok_host = 0;
+            HIPCHK(hipMemcpyAsync(&ok_host, gens_ok_dev, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));             // the key is only remembered for a table whose build is known to have completed
+            e->bp_gens_ok = ok_host;
             e->bp_key.assign(gens33, gens33 + 33 * n_gens);
         }
     }
@@ -1415,11 +1422,16 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
     u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
     if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemsetAsync(d_res, 0, sizeof(int32_t) * n, st));
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
     HIPCHK(hipEventRecord(e->ev[0], st));
-    hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
     int fixed = 0;
-    if (!bp_ensure_table(e, st, gens18, gens33_host, n_gens, &fixed)) return 0;
+    if (bp_table_cached(e, gens33_host, n_gens)) {             // the set's table is there: its generators need not be decompressed again
+        fixed = 1;
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, (u32)e->bp_gens_ok);
+    } else {
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
+        hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
+        if (!bp_ensure_table(e, st, gens18, gens_ok, gens33_host, n_gens, &fixed)) return 0;
+    }
     hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
     {
@@ -1546,7 +1558,7 @@ static int bpc_launch(s2k_engine* e, hipStream_t st, ws_carver& c, unsigned char
     HIPCHK(hipEventRecord(e->ev[0], st));
     hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
     int fixed = 0;
-    if (!bp_ensure_table(e, st, gens18, gens33_host, n_gens, &fixed)) return 0;
+    if (!bp_ensure_table(e, st, gens18, gens_ok, gens33_host, n_gens, &fixed)) return 0;
     if (!fixed && !engine_ptab(e, ((n * T + 255) / 256) * 256)) return 0;
     hipLaunchKernelGGL(k_bpc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, v8, d_nv, d_lv, d_cv, d_mu, (u32)g_len, (u32)h_len, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
