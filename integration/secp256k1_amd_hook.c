@@ -178,6 +178,31 @@ int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *res
 #endif
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * secp256k1_schnorrsig_aggverify (reference include/secp256k1_schnorrsig_halfagg.h:94-101) with the reference's own argument
+ * list: the engine checks the half-aggregate as ONE (2n+1)-term multi-scalar multiplication (the reference: 2n single
+ * multiplications); the array of secp256k1_xonly_pubkey objects is handed over as it lies in memory (pk_format 1).
+ * Returns the verdict; an engine that cannot give one leaves the call to the CPU.
+ * --------------------------------------------------------------------------------------------------------------- */
+#ifdef ENABLE_MODULE_SCHNORRSIG_HALFAGG
+int secp256k1_amd_schnorrsig_aggverify(const secp256k1_context *ctx, const secp256k1_xonly_pubkey *pubkeys, const unsigned char *msgs32, size_t n,
+        const unsigned char *aggsig, size_t aggsig_len) {
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(pubkeys != NULL || n == 0);
+    ARG_CHECK(msgs32 != NULL || n == 0);
+    ARG_CHECK(aggsig != NULL);
+    if (secp256k1_amd_be.schnorrsig_aggverify != NULL && n != 0) {
+        int32_t verdict = 0;
+        if (secp256k1_amd_be.schnorrsig_aggverify(secp256k1_amd_be.engine, &verdict, (const unsigned char*)pubkeys, 1, msgs32, n, aggsig, aggsig_len)) {
+            secp256k1_amd_served++;
+            return verdict != 0;
+        }
+        secp256k1_amd_fell_back++;
+    }
+    return secp256k1_schnorrsig_aggverify(ctx, pubkeys, msgs32, n, aggsig, aggsig_len);
+}
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Batch form of secp256k1_surjectionproof_verify (reference include/secp256k1_surjectionproof.h:256).
  * Item i: proofs[i], input_tags[i][0 .. n_input_tags[i]), output_tags[i].
  * --------------------------------------------------------------------------------------------------------------- */

@@ -48,6 +48,8 @@ typedef int (*secp256k1_amd_surjectionproof_verify_batch_fn)(void *engine, int32
 typedef int (*secp256k1_amd_pedersen_verify_tally_batch_fn)(void *engine, int32_t *results, const unsigned char *commits33,
         const uint64_t *tally_off, const uint64_t *n_pos, size_t n_tallies);
 
+typedef int (*secp256k1_amd_schnorrsig_aggverify_fn)(void *engine, int32_t *result, const unsigned char *pubkeys, int pk_format,
+                                                    const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len);
 typedef struct secp256k1_amd_backend {
     void *engine;
     secp256k1_amd_rangeproof_verify_batch_fn rangeproof_verify_batch;            /* may be NULL: that call stays on the CPU */
@@ -55,6 +57,7 @@ typedef struct secp256k1_amd_backend {
     secp256k1_amd_schnorrsig_verify_batch_fn schnorrsig_verify_batch;
     secp256k1_amd_surjectionproof_verify_batch_fn surjectionproof_verify_batch;
     secp256k1_amd_pedersen_verify_tally_batch_fn pedersen_verify_tally_batch;
+    secp256k1_amd_schnorrsig_aggverify_fn schnorrsig_aggverify;                   /* secp256k1_schnorrsig_aggverify_amd */
 } secp256k1_amd_backend;
 
 /* Install (copy) a backend table; NULL restores the pure CPU library.  Not thread-safe against concurrent verification

@@ -14,12 +14,13 @@ MSM_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz)
 SCH_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _sz, _vp, _int, _sz)
 SJ_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz)
 TALLY_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _sz)
+AGG_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _int, _vp, _sz, _vp, _sz)
 
 
 class Backend(ctypes.Structure):
     """struct secp256k1_amd_backend (integration/secp256k1_amd_hook.h)"""
     _fields_ = [("engine", _vp), ("rangeproof_verify_batch", _vp), ("ecmult_multi", _vp), ("schnorrsig_verify_batch", _vp),
-                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp)]
+                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp)]
 
 
 def fnptr(cfunc):
@@ -47,21 +48,22 @@ class Hooked:
         L.secp256k1_amd_schnorrsig_verify_batch.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp, _sz]
         L.secp256k1_amd_surjectionproof_verify_batch.argtypes = [_vp] * 6 + [_sz]
         L.secp256k1_amd_pedersen_verify_tally_batch.argtypes = [_vp] * 6 + [_sz]
+        L.secp256k1_amd_schnorrsig_aggverify.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz]
         L.secp256k1_surjectionproof_parse.argtypes = [_vp, _vp, ctypes.c_char_p, _sz]
         L.hook_test_ecmult_multi.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, ctypes.POINTER(_sz)]
         L.ref_bppp_norm_verify.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, _sz, ctypes.c_char_p, _sz, ctypes.c_char_p]
         self.ctx = L.secp256k1_context_create(self.SECP256K1_CONTEXT_NONE)
         self._keep = None
 
-    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None):
+    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None):
         """install function pointers (ctypes callbacks or raw addresses); all None -> CPU library"""
         def addr(f):
             return f if isinstance(f, int) or f is None else fnptr(f)
-        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally)):
+        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify)):
             self.lib.secp256k1_amd_set_backend(None); self._keep = None
             return
-        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally))
-        self._keep = (b, rangeproof, msm, schnorr, surjection, tally)
+        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify))
+        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify)
         self.lib.secp256k1_amd_set_backend(ctypes.byref(b))
 
     def stats(self):
@@ -94,6 +96,13 @@ class Hooked:
                                                            _ptr_array([pk_objs[i] for i in range(n)]), n)
         assert r == 1
         return np.array(list(res), np.int32)
+
+    def schnorrsig_aggverify(self, pk_objs, msgs32, aggsig):
+        """secp256k1_schnorrsig_aggverify's own argument list: an array of xonly_pubkey objects, n*32 message bytes, the aggregate"""
+        pk_objs = np.ascontiguousarray(pk_objs, np.uint8).reshape(-1, 64); n = pk_objs.shape[0]
+        msgs32 = np.ascontiguousarray(msgs32, np.uint8).reshape(n, 32)
+        agg = np.frombuffer(bytes(aggsig), np.uint8).copy()
+        return int(self.lib.secp256k1_amd_schnorrsig_aggverify(self.ctx, pk_objs.ctypes.data, msgs32.ctypes.data, n, agg.ctypes.data, agg.size))
 
     def surjectionproof_verify_batch(self, items):
         """items: list of (serialised proof, input tags (k,64), output tag (64,)); proofs that do not parse are the caller's problem"""

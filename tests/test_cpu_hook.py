@@ -275,3 +275,34 @@ def test_schnorr_surjection_tally_adapters(hk, ref):
         assert np.array_equal(hk.pedersen_verify_tally_batch(tallies), expt)
     assert seen == [5] and list(expt) == [1, 1, 1, 0, 1]
     hk.set_backend()
+
+
+def test_halfagg_adapter(hk, ref):
+    """secp256k1_amd_schnorrsig_aggverify: the reference's argument list; no backend / failing backend / checking backend all give
+    the reference's verdict, the checking backend sees the xonly_pubkey objects and the aggregate exactly as handed in."""
+    rng = np.random.default_rng(505)
+    n = 6
+    sigs, msgs, pks = ref.make_schnorr(n, rng)
+    agg = ref.halfagg_aggregate(pks, msgs, sigs)
+    objs = ref.xonly_objects(pks)
+    bad = bytearray(agg); bad[40] ^= 1
+    seen = []
+
+    def chk(engine, result, pk, fmt, m, cnt, a, alen):
+        assert fmt == 1 and cnt == n
+        assert np.array_equal(_arr(pk, 64 * n).reshape(n, 64), objs) and np.array_equal(_arr(m, 32 * n).reshape(n, 32), msgs)
+        abytes = _arr(a, alen).tobytes()
+        _arr(result, 4, np.int32)[0] = ref.halfagg_verify(pks, msgs, abytes)
+        seen.append(abytes)
+        return 1
+    for be in (None, _failing(hookapi.AGG_FN), hookapi.AGG_FN(chk)):
+        hk.set_backend(aggverify=be)
+        f0 = hk.stats()
+        assert hk.schnorrsig_aggverify(objs, msgs, agg) == 1
+        assert hk.schnorrsig_aggverify(objs, msgs, bytes(bad)) == 0
+        assert hk.schnorrsig_aggverify(objs, msgs, agg[:-1]) == 0                  # wrong length: the reference's verdict is 0
+        if be is not None:
+            d = (hk.stats()[0] - f0[0], hk.stats()[1] - f0[1])
+            assert d == ((3, 0) if seen else (0, 3))
+    assert seen == [agg, bytes(bad), agg[:-1]]
+    hk.set_backend()

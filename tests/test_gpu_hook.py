@@ -30,7 +30,7 @@ def _install(hk, engine, handle):
     addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
     hk.set_backend(engine=handle, rangeproof=addr("secp256k1_rangeproof_verify_batch"), msm=addr("s2k_ecmult_multi"),
                    schnorr=addr("secp256k1_schnorrsig_verify_batch"), surjection=addr("secp256k1_surjectionproof_verify_batch"),
-                   tally=addr("secp256k1_pedersen_verify_tally_batch"))
+                   tally=addr("secp256k1_pedersen_verify_tally_batch"), aggverify=addr("secp256k1_schnorrsig_aggverify_amd"))
 
 
 def _workload(ref, rng):
@@ -165,3 +165,22 @@ def test_single_item_forms_have_the_reference_argument_lists(engine, ref):
         e = ref.surjection_verify(ser, tags, out)
         assert L.secp256k1_surjectionproof_verify_amd(None, obj, np.ascontiguousarray(tags).ctypes.data_as(ctypes.c_void_p), k,
                                                       np.ascontiguousarray(out).ctypes.data_as(ctypes.c_void_p)) == e == (0 if flip else 1)
+
+
+def test_halfagg_through_the_hook(hk, engine, ref):
+    """secp256k1_amd_schnorrsig_aggverify (the reference's argument list) on the real engine -- one (2n+1)-term MSM -- and, with the
+    engine handle withheld, on the CPU: the reference's verdicts either way."""
+    rng = np.random.default_rng(605)
+    n = 300
+    sigs, msgs, pks = ref.make_schnorr(n, rng)
+    agg = ref.halfagg_aggregate(pks, msgs, sigs)
+    objs = ref.xonly_objects(pks)
+    bad = bytearray(agg); bad[32 * 7 + 3] ^= 4
+    m2 = msgs.copy(); m2[100, 1] ^= 1
+    for handle in (engine._h, None):
+        _install(hk, engine, handle)
+        s0 = hk.stats()
+        assert hk.schnorrsig_aggverify(objs, msgs, agg) == 1 == ref.halfagg_verify(pks, msgs, agg)
+        assert hk.schnorrsig_aggverify(objs, msgs, bytes(bad)) == 0 == ref.halfagg_verify(pks, msgs, bytes(bad))
+        assert hk.schnorrsig_aggverify(objs, m2, agg) == 0 == ref.halfagg_verify(pks, m2, agg)
+        assert hk.stats() == ((s0[0] + 3, s0[1]) if handle else (s0[0], s0[1] + 3))
