@@ -92,6 +92,106 @@ int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *res
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Batch form of secp256k1_rangeproof_rewind (reference include/secp256k1_rangeproof.h:102-130): wallet-side scanning.
+ * Per item i: results[i] = the single call's return value; for results[i] == 1, blind_out[32 i ..], value_out[i],
+ * min_value[i], max_value[i] and -- when message_out is given -- message_out[i][0 .. outlen[i]) are what the single call
+ * writes (outlen[i] in: capacity of message_out[i], out: bytes recovered).  For results[i] == 0 the reference leaves its
+ * outputs unspecified; this form zeroes blind_out / value_out and sets outlen[i] = 0 on both paths.
+ * --------------------------------------------------------------------------------------------------------------- */
+int secp256k1_amd_rangeproof_rewind_batch(const secp256k1_context *ctx, int *results, unsigned char *blind_out, uint64_t *value_out,
+        unsigned char *const *message_out, size_t *outlen, const unsigned char *const *nonces, uint64_t *min_value, uint64_t *max_value,
+        const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
+        const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
+    size_t i;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(blind_out != NULL);
+    ARG_CHECK(value_out != NULL);
+    ARG_CHECK(message_out == NULL || outlen != NULL);
+    ARG_CHECK(nonces != NULL);
+    ARG_CHECK(min_value != NULL);
+    ARG_CHECK(max_value != NULL);
+    ARG_CHECK(commits != NULL);
+    ARG_CHECK(proofs != NULL);
+    ARG_CHECK(plens != NULL);
+    ARG_CHECK(gens != NULL);
+    ARG_CHECK(extra_commits == NULL || extra_commit_lens != NULL);
+    for (i = 0; i < n; i++) {
+        ARG_CHECK(nonces[i] != NULL);
+        ARG_CHECK(commits[i] != NULL);
+        ARG_CHECK(proofs[i] != NULL);
+        ARG_CHECK(gens[i] != NULL);
+        ARG_CHECK(message_out == NULL || message_out[i] != NULL || outlen[i] == 0);
+        ARG_CHECK(extra_commits == NULL || extra_commits[i] != NULL || extra_commit_lens[i] == 0);
+    }
+    if (n == 0) return 1;
+    if (secp256k1_amd_be.rangeproof_rewind_batch != NULL) {
+        size_t pbytes = 0, ebytes = 0, po = 0, eo = 0, stride = 0;
+        unsigned char *c33, *pbuf, *ebuf, *g64, *nn, *msg = NULL;
+        uint64_t *poff, *eoff, *olen = NULL;
+        int32_t *res32;
+        int ok;
+        for (i = 0; i < n; i++) {
+            pbytes += plens[i];
+            if (extra_commits != NULL) ebytes += extra_commit_lens[i];
+            if (message_out != NULL && outlen[i] > stride) stride = outlen[i];
+        }
+        c33 = (unsigned char*)checked_malloc(&ctx->error_callback, 33 * n);
+        g64 = (unsigned char*)checked_malloc(&ctx->error_callback, 64 * n);
+        nn = (unsigned char*)checked_malloc(&ctx->error_callback, 32 * n);
+        pbuf = (unsigned char*)checked_malloc(&ctx->error_callback, pbytes + 1);
+        ebuf = (unsigned char*)checked_malloc(&ctx->error_callback, ebytes + 1);
+        poff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        eoff = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * (n + 1));
+        res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n);
+        ok = c33 != NULL && g64 != NULL && nn != NULL && pbuf != NULL && ebuf != NULL && poff != NULL && eoff != NULL && res32 != NULL;
+        if (ok && message_out != NULL) {
+            msg = (unsigned char*)checked_malloc(&ctx->error_callback, stride * n + 1);
+            olen = (uint64_t*)checked_malloc(&ctx->error_callback, sizeof(uint64_t) * n);
+            ok = msg != NULL && olen != NULL;
+        }
+        if (ok) {
+            for (i = 0; i < n; i++) {
+                memcpy(c33 + 33 * i, commits[i]->data, 33);
+                memcpy(g64 + 64 * i, gens[i]->data, 64);
+                memcpy(nn + 32 * i, nonces[i], 32);
+                poff[i] = po; memcpy(pbuf + po, proofs[i], plens[i]); po += plens[i];
+                eoff[i] = eo;
+                if (extra_commits != NULL && extra_commit_lens[i] != 0) { memcpy(ebuf + eo, extra_commits[i], extra_commit_lens[i]); eo += extra_commit_lens[i]; }
+                res32[i] = 0;
+                if (olen != NULL) olen[i] = (uint64_t)outlen[i];
+            }
+            poff[n] = po; eoff[n] = eo;
+            ok = secp256k1_amd_be.rangeproof_rewind_batch(secp256k1_amd_be.engine, res32, blind_out, value_out, msg, olen, stride, nn, min_value, max_value,
+                                                          c33, pbuf, poff, extra_commits != NULL ? ebuf : NULL, extra_commits != NULL ? eoff : NULL, g64, n);
+            if (ok) {
+                for (i = 0; i < n; i++) {
+                    results[i] = res32[i] != 0;
+                    if (message_out != NULL) {
+                        const size_t got = results[i] ? (size_t)olen[i] : 0;
+                        if (got != 0) memcpy(message_out[i], msg + stride * i, got);
+                        outlen[i] = got;
+                    }
+                }
+            }
+        }
+        if (nn != NULL) memset(nn, 0, 32 * n);                      /* nonces are secrets */
+        free(c33); free(g64); free(nn); free(pbuf); free(ebuf); free(poff); free(eoff); free(res32); free(msg); free(olen);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;
+    }
+    for (i = 0; i < n; i++) {
+        size_t ol = message_out != NULL ? outlen[i] : 0;
+        results[i] = secp256k1_rangeproof_rewind(ctx, blind_out + 32 * i, &value_out[i], message_out != NULL ? message_out[i] : NULL, message_out != NULL ? &ol : NULL,
+                                                 nonces[i], &min_value[i], &max_value[i], commits[i], proofs[i], plens[i],
+                                                 extra_commits != NULL ? extra_commits[i] : NULL, extra_commits != NULL ? extra_commit_lens[i] : 0, gens[i]);
+        if (!results[i]) { memset(blind_out + 32 * i, 0, 32); value_out[i] = 0; ol = 0; }
+        if (message_out != NULL) outlen[i] = ol;
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
  * The MSM seam: same signature and contract as the static secp256k1_ecmult_multi_var (reference src/ecmult.h:62,
  * ecmult_impl.h:823-867): R = inp_g_sc*G + sum sc_i*pt_i; inp_g_sc may be NULL; a callback that returns 0 makes the call
  * return 0; the result may be infinity.  The pull-callback (src/ecmult.h:49) is drained into arrays on the host.

@@ -50,6 +50,10 @@ typedef int (*secp256k1_amd_pedersen_verify_tally_batch_fn)(void *engine, int32_
 
 typedef int (*secp256k1_amd_schnorrsig_aggverify_fn)(void *engine, int32_t *result, const unsigned char *pubkeys, int pk_format,
                                                     const unsigned char *msgs32, size_t n, const unsigned char *aggsig, size_t aggsig_len);
+typedef int (*secp256k1_amd_rangeproof_rewind_batch_fn)(void *engine, int32_t *results, unsigned char *blind_out, uint64_t *value_out, unsigned char *message_out,
+                                                       uint64_t *outlen, size_t msg_stride, const unsigned char *nonces, uint64_t *min_value, uint64_t *max_value,
+                                                       const unsigned char *commits33, const unsigned char *proofs, const uint64_t *proof_off,
+                                                       const unsigned char *extra, const uint64_t *extra_off, const unsigned char *gens64, size_t n);
 typedef struct secp256k1_amd_backend {
     void *engine;
     secp256k1_amd_rangeproof_verify_batch_fn rangeproof_verify_batch;            /* may be NULL: that call stays on the CPU */
@@ -58,6 +62,7 @@ typedef struct secp256k1_amd_backend {
     secp256k1_amd_surjectionproof_verify_batch_fn surjectionproof_verify_batch;
     secp256k1_amd_pedersen_verify_tally_batch_fn pedersen_verify_tally_batch;
     secp256k1_amd_schnorrsig_aggverify_fn schnorrsig_aggverify;                   /* secp256k1_schnorrsig_aggverify_amd */
+    secp256k1_amd_rangeproof_rewind_batch_fn rangeproof_rewind_batch;             /* secp256k1_rangeproof_rewind_batch */
 } secp256k1_amd_backend;
 
 /* Install (copy) a backend table; NULL restores the pure CPU library.  Not thread-safe against concurrent verification

@@ -15,12 +15,13 @@ SCH_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _sz, _vp, _int, _sz)
 SJ_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz)
 TALLY_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _sz)
 AGG_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _int, _vp, _sz, _vp, _sz)
+REWIND_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz)
 
 
 class Backend(ctypes.Structure):
     """struct secp256k1_amd_backend (integration/secp256k1_amd_hook.h)"""
     _fields_ = [("engine", _vp), ("rangeproof_verify_batch", _vp), ("ecmult_multi", _vp), ("schnorrsig_verify_batch", _vp),
-                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp)]
+                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp)]
 
 
 def fnptr(cfunc):
@@ -49,21 +50,22 @@ class Hooked:
         L.secp256k1_amd_surjectionproof_verify_batch.argtypes = [_vp] * 6 + [_sz]
         L.secp256k1_amd_pedersen_verify_tally_batch.argtypes = [_vp] * 6 + [_sz]
         L.secp256k1_amd_schnorrsig_aggverify.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz]
+        L.secp256k1_amd_rangeproof_rewind_batch.argtypes = [_vp] * 15 + [_sz]
         L.secp256k1_surjectionproof_parse.argtypes = [_vp, _vp, ctypes.c_char_p, _sz]
         L.hook_test_ecmult_multi.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, ctypes.POINTER(_sz)]
         L.ref_bppp_norm_verify.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, _sz, ctypes.c_char_p, _sz, ctypes.c_char_p]
         self.ctx = L.secp256k1_context_create(self.SECP256K1_CONTEXT_NONE)
         self._keep = None
 
-    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None):
+    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None):
         """install function pointers (ctypes callbacks or raw addresses); all None -> CPU library"""
         def addr(f):
             return f if isinstance(f, int) or f is None else fnptr(f)
-        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify)):
+        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind)):
             self.lib.secp256k1_amd_set_backend(None); self._keep = None
             return
-        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify))
-        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify)
+        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind))
+        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind)
         self.lib.secp256k1_amd_set_backend(ctypes.byref(b))
 
     def stats(self):
@@ -87,6 +89,28 @@ class Hooked:
         r = self.lib.secp256k1_amd_rangeproof_verify_batch(self.ctx, res, mn.ctypes.data, mx.ctypes.data, cp, pp, plens, ep, el, gp, n)
         assert r == 1
         return np.array(list(res), np.int32), mn, mx
+
+    def rangeproof_rewind_batch(self, commits33, plist, gens64, nonces, msg_capacity=4096):
+        """-> (results, blinds (n,32), values, messages list, min, max): per item what secp256k1_rangeproof_rewind returns and writes"""
+        n = len(plist)
+        cobj = np.zeros((n, 64), np.uint8); cobj[:, :33] = np.ascontiguousarray(commits33, np.uint8).reshape(n, 33)
+        gobj = np.ascontiguousarray(gens64, np.uint8).reshape(n, 64).copy()
+        nn = np.ascontiguousarray(nonces, np.uint8).reshape(n, 32).copy()
+        pbufs = [np.frombuffer(p if len(p) else b"\0", np.uint8).copy() for p in plist]
+        plens = (_sz * n)(*[len(p) for p in plist])
+        res = (_int * n)(); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        blind = np.full((n, 32), 0xAA, np.uint8); val = np.full(n, 77, np.uint64)
+        mbufs = [np.zeros(max(msg_capacity, 1), np.uint8) for _ in range(n)]
+        ol = (_sz * n)(*([msg_capacity] * n))
+        r = self.lib.secp256k1_amd_rangeproof_rewind_batch(self.ctx, res, blind.ctypes.data, val.ctypes.data, _ptr_array(mbufs) if msg_capacity else None,
+                                                           ol if msg_capacity else None, _ptr_array([nn[i] for i in range(n)]), mn.ctypes.data, mx.ctypes.data,
+                                                           _ptr_array([cobj[i] for i in range(n)]), _ptr_array(pbufs), plens, None, None, _ptr_array([gobj[i] for i in range(n)]), n)
+        assert r == 1
+        res = np.array(list(res), np.int32)
+        msgs = [mbufs[i][:ol[i]].tobytes() if (res[i] and msg_capacity) else b"" for i in range(n)]
+        if msg_capacity:
+            assert all(ol[i] == 0 for i in range(n) if not res[i])
+        return res, blind, val, msgs, mn, mx
 
     def schnorrsig_verify_batch(self, sigs, msgs, pk_objs, msglen=32):
         sigs = np.ascontiguousarray(sigs, np.uint8).reshape(-1, 64); n = sigs.shape[0]

@@ -306,3 +306,26 @@ def test_halfagg_adapter(hk, ref):
             assert d == ((3, 0) if seen else (0, 3))
     assert seen == [agg, bytes(bad), agg[:-1]]
     hk.set_backend()
+
+
+def test_rewind_adapter_cpu_paths(hk, ref):
+    """secp256k1_amd_rangeproof_rewind_batch without a backend and with a backend that fails: per item what
+    secp256k1_rangeproof_rewind returns and writes (right nonce, wrong nonce, corrupted proof; with and without a message buffer)."""
+    rng = np.random.default_rng(506)
+    commits, plist, gens, values, blinds, nonces, msgs = ref.make_rangeproofs_msg(5, rng, msg_len=48, min_bits=32)
+    nn = nonces.copy(); nn[1, 0] ^= 1                                  # wrong nonce: the reference rejects
+    pl = list(plist); b = bytearray(pl[3]); b[len(b) // 2] ^= 2; pl[3] = bytes(b)
+    for cap in (4096, 0):
+        exp = ref.rangeproof_rewind_many(commits, pl, gens, nn, msg_capacity=cap)
+        for be in (None, _failing(hookapi.REWIND_FN)):
+            hk.set_backend(rewind=be)
+            got = hk.rangeproof_rewind_batch(commits, pl, gens, nn, msg_capacity=cap)
+            assert np.array_equal(got[0], exp[0]) and list(exp[0]) == [1, 0, 1, 0, 1]
+            ok = exp[0] == 1
+            assert np.array_equal(got[1][ok], exp[1][ok]) and np.array_equal(got[2][ok], exp[2][ok])
+            assert not got[1][~ok].any() and not got[2][~ok].any()            # rejected items: zeroed outputs
+            assert got[3] == exp[3]
+            assert np.array_equal(got[4][ok], exp[4][ok]) and np.array_equal(got[5][ok], exp[5][ok])
+            if cap:
+                assert all(got[3][i][:48] == msgs[i].tobytes() for i in range(5) if ok[i])
+    hk.set_backend()

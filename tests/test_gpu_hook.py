@@ -30,7 +30,7 @@ def _install(hk, engine, handle):
     addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
     hk.set_backend(engine=handle, rangeproof=addr("secp256k1_rangeproof_verify_batch"), msm=addr("s2k_ecmult_multi"),
                    schnorr=addr("secp256k1_schnorrsig_verify_batch"), surjection=addr("secp256k1_surjectionproof_verify_batch"),
-                   tally=addr("secp256k1_pedersen_verify_tally_batch"), aggverify=addr("secp256k1_schnorrsig_aggverify_amd"))
+                   tally=addr("secp256k1_pedersen_verify_tally_batch"), aggverify=addr("secp256k1_schnorrsig_aggverify_amd"), rewind=addr("secp256k1_rangeproof_rewind_batch"))
 
 
 def _workload(ref, rng):
@@ -184,3 +184,27 @@ def test_halfagg_through_the_hook(hk, engine, ref):
         assert hk.schnorrsig_aggverify(objs, msgs, bytes(bad)) == 0 == ref.halfagg_verify(pks, msgs, bytes(bad))
         assert hk.schnorrsig_aggverify(objs, m2, agg) == 0 == ref.halfagg_verify(pks, m2, agg)
         assert hk.stats() == ((s0[0] + 3, s0[1]) if handle else (s0[0], s0[1] + 3))
+
+
+def test_rewind_through_the_hook(hk, engine, ref):
+    """secp256k1_amd_rangeproof_rewind_batch on the real engine and, with the handle withheld, on the CPU: results, blinds, values,
+    messages, min/max of every item as secp256k1_rangeproof_rewind gives them (right / wrong nonce, corrupted proof, mixed shapes)."""
+    rng = np.random.default_rng(606)
+    c1, p1, g1, _, _, n1, m1 = ref.make_rangeproofs_msg(20, rng, msg_len=64, min_bits=64)
+    c2, p2, g2, _, _, n2, m2 = ref.make_rangeproofs_msg(12, rng, msg_len=16, min_bits=10, exp=1, min_value=3)
+    commits = np.concatenate([c1, c2]); plist = list(p1) + list(p2); gens = np.concatenate([g1, g2]); nonces = np.concatenate([n1, n2])
+    nonces[4, 31] ^= 1; nonces[25, 0] ^= 0x80
+    b = bytearray(plist[9]); b[200] ^= 1; plist[9] = bytes(b)
+    for cap in (4096, 0):
+        exp = ref.rangeproof_rewind_many(commits, plist, gens, nonces, msg_capacity=cap)
+        ok = exp[0] == 1
+        assert 0 < ok.sum() < len(plist)
+        for handle in (engine._h, None):
+            _install(hk, engine, handle)
+            s0 = hk.stats()
+            got = hk.rangeproof_rewind_batch(commits, plist, gens, nonces, msg_capacity=cap)
+            assert hk.stats() == ((s0[0] + 1, s0[1]) if handle else (s0[0], s0[1] + 1))
+            assert np.array_equal(got[0], exp[0])
+            assert np.array_equal(got[1][ok], exp[1][ok]) and np.array_equal(got[2][ok], exp[2][ok]) and got[3] == exp[3]
+            assert not got[1][~ok].any() and not got[2][~ok].any()
+            assert np.array_equal(got[4][ok], exp[4][ok]) and np.array_equal(got[5][ok], exp[5][ok])
