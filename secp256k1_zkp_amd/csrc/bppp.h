@@ -46,8 +46,13 @@ S2K_HD void bp_load_transcript(sha256_stream& h, const unsigned char* t104) {
 }
 
 // One lane per proof.  term_sc: n_terms scalars (8 words each, little-endian limbs).  Returns the proof's ok flag.
+// sg_factors (optional, 8 x 8 words): when given, the g_len - 1 scalars s_g[1..] are NOT computed here -- their recurrence
+// s_g[i] = s_g[i - 2^b] * gamma_b * rho^-(2^b)  (b = top bit of i) is the product over the set bits of i of the factors
+// f_b = gamma_b * rho^-(2^b), which are left in sg_factors for bp_sg_entry: one lane per (proof, i) instead of 2 (g_len - 1)
+// dependent scalar products on the proof's single lane (40 % of this latency-bound stage at g_len 64).
+#define BP_MAX_LOG_G 8
 S2K_HD int bp_prologue(u32* term_sc, const bp_shape& sh, const unsigned char* proof, const unsigned char* transcript104,
-                       const unsigned char* rho32, const unsigned char* c_vec32) {
+                       const unsigned char* rho32, const unsigned char* c_vec32, u32* sg_factors = nullptr) {
     int ov;
     scalar n, l, rho;
     sc_set_b32(n, proof + 65 * sh.n_rounds, &ov); if (ov) return 0;
@@ -75,6 +80,15 @@ S2K_HD int bp_prologue(u32* term_sc, const bp_shape& sh, const unsigned char* pr
         for (int k = 0; k < 8; k++) term_sc[k] = s0.d[k];
         scalar pw = rho_inv;                       // rho_inv^(2^log_i)
         u32 log_i = 0;
+        if (sg_factors) {
+            for (u32 b = 0; b < sh.log_g; b++) {
+                if (b) sc_sqr(pw, pw);
+                scalar gm, f;
+                for (int k = 0; k < 8; k++) gm.d[k] = term_sc[8 * (base2 + 1 + 2 * b) + k];
+                sc_mul(f, gm, pw);
+                for (int k = 0; k < 8; k++) sg_factors[8 * b + k] = f.d[k];
+            }
+        } else
         for (u32 i = 1; i < sh.g_len; i++) {
             if (i == (2u << log_i)) { log_i++; sc_sqr(pw, pw); }
             const u32 p2 = 1u << log_i;
@@ -125,6 +139,15 @@ S2K_HD int bp_prologue(u32* term_sc, const bp_shape& sh, const unsigned char* pr
     return 1;
 }
 
+// s_g[i], 1 <= i < g_len, from s_g[0] and the factors bp_prologue left (see there)
+S2K_HD void bp_sg_entry(u32* term_sc, const u32* sg_factors, const bp_shape& sh, u32 i) {
+    scalar acc;
+    for (int k = 0; k < 8; k++) acc.d[k] = term_sc[k];
+    for (u32 b = 0; b < sh.log_g; b++) {
+        if ((i >> b) & 1u) { scalar f; for (int k = 0; k < 8; k++) f.d[k] = sg_factors[8 * b + k]; sc_mul(acc, acc, f); }
+    }
+    for (int k = 0; k < 8; k++) term_sc[8 * i + k] = acc.d[k];
+}
 // compressed point (0x02/0x03 || x) -> affine; cf. secp256k1_eckey_pubkey_parse (src/eckey_impl.h:18-22)
 S2K_HD int bp_parse33(ge& p, const unsigned char* in33) {
     if (in33[0] != 2 && in33[0] != 3) return 0;

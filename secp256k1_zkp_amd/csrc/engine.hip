@@ -1333,10 +1333,19 @@ __global__ void k_bp_gens(u32* gens18, int* gens_ok, const unsigned char* gens33
 }
 __global__ void __launch_bounds__(64)
 k_bp_prologue(u32* term_sc, int* proof_ok, bp_shape sh, const unsigned char* proofs, size_t proof_len, const unsigned char* transcripts,
-              const unsigned char* rho, const unsigned char* c_vec, size_t n) {
+              const unsigned char* rho, const unsigned char* c_vec, u32* sg_factors, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    proof_ok[p] = bp_prologue(term_sc + p * sh.n_terms * 8, sh, proofs + p * proof_len, transcripts + p * 104, rho + 32 * p, c_vec + p * sh.h_len * 32);
+    proof_ok[p] = bp_prologue(term_sc + p * sh.n_terms * 8, sh, proofs + p * proof_len, transcripts + p * 104, rho + 32 * p, c_vec + p * sh.h_len * 32,
+                              sg_factors + p * (8 * BP_MAX_LOG_G));
+}
+// the g_len - 1 scalars s_g[1..] of every proof, one lane each (bp_sg_entry)
+__global__ void __launch_bounds__(256)
+k_bp_sg(u32* term_sc, const u32* sg_factors, const int* proof_ok, bp_shape sh, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t p = t / (sh.g_len - 1); const u32 i = 1u + (u32)(t % (sh.g_len - 1));
+    if (p >= n || !proof_ok[p]) return;
+    bp_sg_entry(term_sc + p * sh.n_terms * 8, sg_factors + p * (8 * BP_MAX_LOG_G), sh, i);
 }
 // terms t0 .. t0 + tcount - 1 of every proof, one lane each (full double-and-add)
 __global__ void __launch_bounds__(256, 2)
@@ -1411,7 +1420,7 @@ static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, con
 }
 static size_t bpv_ws_bytes(size_t n, const bp_shape& sh) {
     const size_t T = sh.n_terms, nt = n * T;
-    return ws_need({(size_t)sh.n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n, nt * 28 * 4, nt + 64, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4});
+    return ws_need({(size_t)sh.n_gens * 18 * 4, 64, nt * 8 * 4, 4 * n, nt * 28 * 4, nt + 64, (n * (T / 1024 + 1) + 64) * 28 * 4, (n * (T / 1024 + 1) + 64) * 28 * 4, n * 8 * BP_MAX_LOG_G * 4});
 }
 // device pointers in (gens33_host: the generator set once more on the host, the fixed-base table's cache key); one launch group
 static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res, const bp_shape& sh, const unsigned char* d_pr, size_t proof_len, const unsigned char* d_tr,
@@ -1420,6 +1429,8 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
     u32* gens18 = c.take<u32>(n_gens * 18); int* gens_ok = c.take<int>(16); u32* term_sc = c.take<u32>(nt * 8); int* proof_ok = c.take<int>(n);
     u32* out28 = c.take<u32>(nt * 28); unsigned char* term_ok = c.take<unsigned char>(nt + 64);
     u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
+    u32* sg_factors = c.take<u32>(n * 8 * BP_MAX_LOG_G);
+    if (sh.log_g > BP_MAX_LOG_G) return s2k_fail_arg("secp256k1_bppp_norm_product_verify_batch", "g_len above 256");
     if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
     HIPCHK(hipMemsetAsync(d_res, 0, sizeof(int32_t) * n, st));
     HIPCHK(hipEventRecord(e->ev[0], st));
@@ -1432,7 +1443,8 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
         hipLaunchKernelGGL(k_bp_gens, dim3((unsigned)((n_gens + 63) / 64)), dim3(64), 0, st, gens18, gens_ok, d_g33, (u32)n_gens);
         if (!bp_ensure_table(e, st, gens18, gens_ok, gens33_host, n_gens, &fixed)) return 0;
     }
-    hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, n);
+    hipLaunchKernelGGL(k_bp_prologue, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, term_sc, proof_ok, sh, d_pr, proof_len, d_tr, d_rho, d_cv, sg_factors, n);
+    if (sh.g_len > 1) hipLaunchKernelGGL(k_bp_sg, dim3((unsigned)((n * (sh.g_len - 1) + 255) / 256)), dim3(256), 0, st, term_sc, sg_factors, proof_ok, sh, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
     {
         const u32 t0 = fixed ? (u32)n_gens : 0u, tcount = (u32)T - t0;

@@ -287,8 +287,13 @@ int emu_bppp_verify(const unsigned char* proof, size_t proof_len, const unsigned
     int ok = 1;
     for (size_t i = 0; i < n_gens; i++) { ge p; ok &= bp_parse33(p, gens33 + 33 * i); fe_norm_weak(p.x); fe_norm_weak(p.y);
         for (int k = 0; k < 9; k++) { gens18[18 * i + k] = p.x.n[k]; gens18[18 * i + 9 + k] = p.y.n[k]; } }
+    // both forms of the s_g vector: the serial recurrence inside bp_prologue and the per-entry products of the device path (k_bp_sg)
+    std::vector<u32> term_sc2(sh.n_terms * 8), fac(8 * BP_MAX_LOG_G);
     ok &= bp_prologue(term_sc.data(), sh, proof, transcript104, rho32, c_vec32);
     if (!ok) return 0;
+    if (!bp_prologue(term_sc2.data(), sh, proof, transcript104, rho32, c_vec32, fac.data())) return 0;
+    for (u32 i = 1; i < sh.g_len; i++) bp_sg_entry(term_sc2.data(), fac.data(), sh, i);
+    if (term_sc2 != term_sc) return 0;
     gej sum; gej_set_infinity(sum);
     for (u32 t = 0; t < sh.n_terms; t++) {
         gej o; ok &= bp_term(o, sh, t, term_sc.data(), gens18.data(), proof, commit33, 1, gtab_host(), g_lm);
