@@ -1448,9 +1448,17 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
     HIPCHK(hipEventRecord(e->ev[2], st));
     {
         const u32 t0 = fixed ? (u32)n_gens : 0u, tcount = (u32)T - t0;
-        if (fixed) hipLaunchKernelGGL(k_bp_terms_fixed, dim3((unsigned)((n * n_gens + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, e->bp_tab, n);
+        // the generator terms (fixed-base tables: throughput bound, fills the machine) run on the side stream next to the proof's own
+        // points (one full double multiplication per lane, ~13 lanes per proof: latency bound at batch sizes like 2^12)
+        if (fixed) {
+            HIPCHK(hipEventRecord(e->ev_msm_fork, st));
+            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_msm_fork, 0));
+            hipLaunchKernelGGL(k_bp_terms_fixed, dim3((unsigned)((n * n_gens + 255) / 256)), dim3(256), 0, e->stream2, out28, term_ok, sh, term_sc, proof_ok, e->bp_tab, n);
+            HIPCHK(hipEventRecord(e->ev_msm_join, e->stream2));
+        }
         hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((n * tcount + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm,
                            e->gtab, e->ptab, n, t0, tcount);
+        if (fixed) HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
     }
     HIPCHK(hipEventRecord(e->ev[3], st));
     const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);
