@@ -68,7 +68,8 @@ struct s2k_engine {
     // one chunk (side streams, latency bound) runs underneath the rings kernel of the chunk before it (caller's stream).
     unsigned char* rp_mem[2]; size_t rp_mem_bytes;
     hipStream_t stream_pre;
-    hipEvent_t ev_rp_in, ev_rp_fork[2], ev_rp_join[2], ev_rp_pre[2], ev_rp_done[2];
+    hipEvent_t ev_rp_in, ev_rp_fork[2], ev_rp_join[2], ev_rp_pre[2], ev_rp_done[2], ev_rp_draws, ev_rp_rewound;
+    int rp_rewound_valid;
     int rp_done_valid[2]; unsigned rp_seq;
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
     hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
@@ -203,6 +204,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
     e->ring_seq = 0;
     e->last_stream = nullptr; e->last_stream_valid = 0; e->ev_last = nullptr; e->ev_msm_fork = nullptr; e->ev_msm_join = nullptr;
+    e->ev_rp_draws = nullptr; e->ev_rp_rewound = nullptr; e->rp_rewound_valid = 0;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
@@ -227,6 +229,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_join, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_draws, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_rewound, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_fork[i], hipEventDisableTiming));
         S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_join[i], hipEventDisableTiming));
@@ -269,6 +273,8 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->ev_msm_fork) hipEventDestroy(e->ev_msm_fork);
     if (e->ev_msm_join) hipEventDestroy(e->ev_msm_join);
     if (e->ev_rp_in) hipEventDestroy(e->ev_rp_in);
+    if (e->ev_rp_draws) hipEventDestroy(e->ev_rp_draws);
+    if (e->ev_rp_rewound) hipEventDestroy(e->ev_rp_rewound);
     if (e->stream_pre) { hipStreamSynchronize(e->stream_pre); hipStreamDestroy(e->stream_pre); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -451,6 +457,14 @@ struct rp_rewind_args {
     u32* ev; u32* prep; u32* secs;                  // scratch, one chunk: [m][128][8], [m][128][8], [m][32][8] words
     unsigned char* blind_out; uint64_t* value_out; unsigned char* msg_out; uint64_t* outlen; size_t msg_stride; const unsigned char* nonces;
 };
+// the DRBG replay of every structurally valid proof (rp_rewind_draws): needs nothing from the ring verification, so rp_launch runs
+// it on a side stream underneath the rings kernel
+__global__ void __launch_bounds__(64)
+k_rp_rewind_draws(rp_ws ws, rp_rewind_args ra, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* gens64, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || !ws.rec[p].ok) return;
+    rp_rewind_draws(ws.rec[p], proofs + proof_off[p], ra.nonces + 32 * p, gens64 + 64 * p, ra.prep + p * 1024, ra.secs + p * 256);
+}
 __global__ void __launch_bounds__(256, 2)
 k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_value, const unsigned char* proofs, const uint64_t* proof_off,
             const unsigned char* gens64, const u32* gtab, u32* ptab, size_t n) {
@@ -463,8 +477,8 @@ k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_v
     if (ok) {
         mlen = (ra.msg_out && ra.outlen) ? ra.outlen[p] : 0;
         if (mlen > ra.msg_stride) mlen = ra.msg_stride;
-        ok = rp_rewind(blind, value, ra.msg_out ? ra.msg_out + p * ra.msg_stride : nullptr, &mlen, ws.rec[p], proof, ra.nonces + 32 * p, gens64 + 64 * p,
-                       ra.ev + p * 1024, ra.prep + p * 1024, ra.secs + p * 256);
+        ok = rp_rewind_recover(blind, value, ra.msg_out ? ra.msg_out + p * ra.msg_stride : nullptr, &mlen, ws.rec[p], proof,
+                               ra.ev + p * 1024, ra.prep + p * 1024, ra.secs + p * 256);
     }
     // the commitment must be blind*G + (value*scale + min_value)*gen  (rangeproof_impl.h:662-672)
     u64 vv = 0;
@@ -557,6 +571,15 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_join[slot], 0));
         hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, sp, w, m);
         HIPCHK(hipEventRecord(e->ev_rp_pre[slot], sp));
+        if (rewind) {
+            // rewinding: the replay of the prover's random stream (serial per proof, ~1 500 SHA-256 compressions) only needs the header
+            // and the commitment, so it goes behind the first stage on the side stream and runs underneath the rings kernel; its
+            // scratch (prep / secs) is one set per call, so it waits for the recovery pass of the chunk before
+            rp_rewind_args ra = *rewind; ra.nonces += 32 * p0;
+            if (e->rp_rewound_valid) HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_rewound, 0));
+            hipLaunchKernelGGL(k_rp_rewind_draws, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sp, w, ra, proofs, proof_off + p0, gens64 + 64 * p0, m);
+            HIPCHK(hipEventRecord(e->ev_rp_draws, sp));
+        }
         // ---- caller's stream
         HIPCHK(hipStreamWaitEvent(st, e->ev_rp_pre[slot], 0));
         const unsigned rq = e->ring_seq & 31u;
@@ -569,8 +592,10 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
             ra.blind_out += 32 * p0; ra.value_out += p0; ra.nonces += 32 * p0;
             if (ra.msg_out) ra.msg_out += ra.msg_stride * p0;
             if (ra.outlen) ra.outlen += p0;
+            HIPCHK(hipStreamWaitEvent(st, e->ev_rp_draws, 0));
             hipLaunchKernelGGL(k_rp_rewind, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, ra, results + p0, min_value + p0, proofs, proof_off + p0,
                                gens64 + 64 * p0, e->gtab, e->ptab, m);
+            HIPCHK(hipEventRecord(e->ev_rp_rewound, st)); e->rp_rewound_valid = 1;
         }
         HIPCHK(hipEventRecord(e->ev_rp_done[slot], st));
         e->rp_done_valid[slot] = 1;

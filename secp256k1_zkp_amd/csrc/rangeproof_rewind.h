@@ -87,11 +87,12 @@ S2K_HD void rp_recover_x(scalar& x, const scalar& k, const scalar& e, const scal
 }
 S2K_HD void rp_load_scalar_words(scalar& s, const u32* w8) { int ov; rp_words_to_scalar(s, ov, w8); }
 
-// One lane per proof that passed verification.  ev: [128][8] challenge words written by the rings kernel; prep / secs: this
-// proof's scratch ([128][8] and [32][8] words).  On success returns 1 with the blinding factor and the *raw* mantissa value
-// (the caller scales it and checks the commitment); msg_out receives min(*mlen, recovered) bytes and *mlen the count (:364-485).
-S2K_HD int rp_rewind(scalar& blind, u64& value, unsigned char* msg_out, u64* mlen, const rp_rec& rec, const unsigned char* proof,
-                     const unsigned char* nonce32, const unsigned char* gen64, const u32* ev, u32* prep, u32* secs) {
+// Rewinding in two parts, one lane per proof each.
+// rp_rewind_draws: the replay of the prover's RFC 6979 stream -- the ring nonces ("secs", [32][8] words) and the pad of every ring
+// position ("prep", [128][8] words).  It needs the nonce, the commitment, the generator and the proof's header only, NOT the outcome
+// of the verification, and it is a serial chain of ~1 500 SHA-256 compressions: the engine runs it on a side stream underneath the
+// rings kernel (engine.hip, rp_launch).
+S2K_HD void rp_rewind_draws(const rp_rec& rec, const unsigned char* proof, const unsigned char* nonce32, const unsigned char* gen64, u32* prep, u32* secs) {
     const u32 rings = rec.rings, last = rec.last_rsize;
     rp_drbg rng;
     {   // seed = nonce | ser(commit) | ser(gen) | proof[0 .. header)    (genrand :74-78; ser = [!is_square(y)] | x, :53-59)
@@ -110,8 +111,6 @@ S2K_HD int rp_rewind(scalar& blind, u64& value, unsigned char* msg_out, u64* mle
         drbg_init(rng, seed, 98 + hdr);
     }
     scalar acc; sc_set_zero(acc);
-    scalar s_orig_last[4];
-    for (int i = 0; i < 4; i++) sc_set_zero(s_orig_last[i]);
     u32 npub = 0;
     for (u32 i = 0; i < rings; i++) {
         scalar sec; u32 t[8]; int ov;
@@ -127,10 +126,20 @@ S2K_HD int rp_rewind(scalar& blind, u64& value, unsigned char* msg_out, u64* mle
         for (u32 j = 0; j < rsize; j++) {
             drbg_generate(t, rng);
             for (int k = 0; k < 8; k++) prep[8 * npub + k] = t[k];
-            if (i + 1 == rings) { rp_words_to_scalar(s_orig_last[j], ov, t); }
             npub++;
         }
     }
+}
+// rp_rewind_recover: for a proof that passed verification.  ev: [128][8] challenge words written by the rings kernel; prep / secs:
+// what rp_rewind_draws left.  On success returns 1 with the blinding factor and the *raw* mantissa value (the caller scales it and
+// checks the commitment); msg_out receives min(*mlen, recovered) bytes and *mlen the count (:364-485).
+S2K_HD int rp_rewind_recover(scalar& blind, u64& value, unsigned char* msg_out, u64* mlen, const rp_rec& rec, const unsigned char* proof,
+                             const u32* ev, const u32* prep, const u32* secs) {
+    const u32 rings = rec.rings, last = rec.last_rsize;
+    scalar s_orig_last[4];
+    for (int i = 0; i < 4; i++) sc_set_zero(s_orig_last[i]);
+    for (u32 j = 0; j < last && j < 4; j++) { int ov; rp_words_to_scalar(s_orig_last[j], ov, prep + 8 * (((rings - 1) << 2) + j)); }
+    u32 npub = 0;
     value = 0xFFFFFFFFFFFFFFFFull;
     sc_set_zero(blind);
     const unsigned char* sbytes = proof + rec.off_s;
@@ -193,4 +202,10 @@ S2K_HD int rp_rewind(scalar& blind, u64& value, unsigned char* msg_out, u64* mle
     }
     *mlen = offset;
     return 1;
+}
+// both parts back to back (host emulation)
+S2K_HD int rp_rewind(scalar& blind, u64& value, unsigned char* msg_out, u64* mlen, const rp_rec& rec, const unsigned char* proof,
+                     const unsigned char* nonce32, const unsigned char* gen64, const u32* ev, u32* prep, u32* secs) {
+    rp_rewind_draws(rec, proof, nonce32, gen64, prep, secs);
+    return rp_rewind_recover(blind, value, msg_out, mlen, rec, proof, ev, prep, secs);
 }
