@@ -29,6 +29,17 @@ static const u32 sha256_k[64] = {
     0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
     0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
 
+// three-way XOR as ONE instruction on the device (v_bitop3_b32 with the parity truth table: the compiler forms it for Ch and Maj
+// but leaves the sigma functions as two v_xor_b32 each: 224 instructions of a 1 709-instruction block)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define S2K_XOR3(a, b, c) ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
+#define S2K_CH(e, f, g) ((u32)__builtin_amdgcn_bitop3_b32((e), (f), (g), 0xCA))          /* e ? f : g, bitwise */
+#define S2K_MAJ(a, b, c) ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0xE8))
+#else
+#define S2K_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#define S2K_CH(e, f, g) (((e) & (f)) ^ (~(e) & (g)))
+#define S2K_MAJ(a, b, c) (((a) & (b)) ^ ((a) & (c)) ^ ((b) & (c)))
+#endif
 // s <- compress(s, w); w is consumed (used as the rolling message schedule).
 S2K_HD void sha256_compress(u32 s[8], u32 w[16]) {
     u32 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
@@ -36,15 +47,15 @@ S2K_HD void sha256_compress(u32 s[8], u32 w[16]) {
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             const u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-            const u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
-            const u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            const u32 s0 = S2K_XOR3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+            const u32 s1 = S2K_XOR3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
             w[i & 15] += s0 + w[(i + 9) & 15] + s1;
         }
-        const u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
-        const u32 ch = (e & f) ^ (~e & g);
+        const u32 S1 = S2K_XOR3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25));
+        const u32 ch = S2K_CH(e, f, g);
         const u32 t1 = h + S1 + ch + S2K_SHA_K(i) + w[i & 15];
-        const u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
-        const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+        const u32 S0 = S2K_XOR3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22));
+        const u32 mj = S2K_MAJ(a, b, c);
         const u32 t2 = S0 + mj;
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
