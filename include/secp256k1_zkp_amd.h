@@ -51,10 +51,25 @@ S2K_API void s2k_clear_status(void);
  *   Setting the option to 1 is the caller's promise that the input arrays of a `_dev` call are complete when the call is made (and
  *   stay untouched until its results are consumed); min_value/max_value may then be written before the stream reaches the call.
  *   Results are unaffected; host-buffer entry points ignore the option.
- * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results). */
+ * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results).
+ * S2K_OPT_GEN_CACHE_SLOTS (default 2, 0..8; $S2K_GEN_CACHE): how many rangeproof generators may have a fixed-base table at a time
+ *   (11.8 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.
+ * S2K_OPT_GEN_CACHE_MIN (default 65536; $S2K_GEN_CACHE_MIN): an uncached generator gets a table automatically once this many proofs
+ *   carrying it have been seen (host-buffer calls count before the launch, `_dev` calls through a device mailbox read at the next call). */
 #define S2K_OPT_RP_INPUTS_READY 1
 #define S2K_OPT_RP_SPLIT 2
+#define S2K_OPT_GEN_CACHE_SLOTS 3
+#define S2K_OPT_GEN_CACHE_MIN 4
 S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
+/* Rangeproof generator tables.  The four public keys of a Borromean ring differ by multiples of the proof's generator
+ * (secp256k1_rangeproof_pub_expand, src/modules/rangeproof/rangeproof_impl.h:19-51), so when the engine holds a fixed-base table of that
+ * generator a ring builds its odd-multiples tables once instead of four times (~20 % less work per proof).  The table of
+ * secp256k1_generator_h (include/secp256k1_generator.h:36) is built at the first rangeproof call; other generators get one through
+ * this call (gen64: the 64 bytes of a secp256k1_generator object, host memory) or automatically (S2K_OPT_GEN_CACHE_MIN); the least
+ * recently used table makes room.  Proofs whose generator has no table take the general form of the kernel: results never depend on
+ * the cache.  s2k_engine_generator_cached: 1 when gen64 has a table now. */
+S2K_API int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* gen64);
+S2K_API int s2k_engine_generator_cached(s2k_engine* e, const unsigned char* gen64);
 /* Make sure the per-batch HBM workspace can hold `n_items` rangeproofs (optional; calls grow it on demand). */
 S2K_API int s2k_engine_reserve(s2k_engine* e, size_t n_items);
 /* Block until everything queued on the engine's stream has finished. */

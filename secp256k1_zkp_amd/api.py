@@ -77,6 +77,18 @@ class Engine:
 
     OPT_RP_INPUTS_READY = 1      # include/secp256k1_zkp_amd.h: S2K_OPT_*
     OPT_RP_SPLIT = 2
+    OPT_GEN_CACHE_SLOTS = 3
+    OPT_GEN_CACHE_MIN = 4
+
+    def cache_generator(self, gen64):
+        """Build the fixed-base table of one rangeproof generator now (s2k_engine_cache_generator)."""
+        g = bytes(gen64)
+        if len(g) != 64:
+            raise ValueError("cache_generator: a generator is 64 bytes")
+        self._check(self._lib.s2k_engine_cache_generator(self._h, g), "s2k_engine_cache_generator")
+
+    def generator_cached(self, gen64):
+        return bool(self._lib.s2k_engine_generator_cached(self._h, bytes(gen64)))
 
     def set_option(self, option, value):
         self._check(self._lib.s2k_engine_set_option(self._h, int(option), int(value)), "s2k_engine_set_option")

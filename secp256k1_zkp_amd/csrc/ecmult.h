@@ -74,7 +74,8 @@ S2K_HD void ptab_store_raw(u32* e, const fe& x, const fe& y, const fe& third) {
 // its step) limbs; returns the Z all of them will share once rescaled (the Z of the last entry).  ptab_rescale: brings every entry to the Z of the last one times `zs0`
 // (secp256k1_ge_table_set_globalz, group_impl.h:289-320) and packs it as canonical words with its beta*x twin.  zs0 = 1 for a
 // single table; with two tables each is rescaled by the OTHER one's Z so that all sixteen entries share one Z (ecmult_lane_split).
-S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) {
+template <int N>
+S2K_HD void ptab_build_raw_n(fe& ziso, u32* tab, const gej& A) {
     // 2A by the usual doubling, whose intermediates also give A itself at the Z of 2A for free: Z(2A) = Y Z, so A rescaled by Y is
     // (X Y^2, Y^4) = (-T, S^2).  From then on every odd multiple is a CO-Z addition of 2A (both operands share Z: 5M + 2S instead of the
     // 8M + 3S of a mixed addition, and 2A comes out rescaled to the sum's Z for the next step); the step's Z ratio is just X(2A) - X(P).
@@ -90,7 +91,7 @@ S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) {
     fe_mul(qy, l, w); fe_add(qy, s2); fe_neg(qy, qy, 2); fe_norm_weak(qy);     // Y(2A) = -(L (X3 + T) + S^2)      (1)
     fe_neg(px, t, 1); py = s2;                             // A at the Z of 2A                      (2, 1)
     { fe one; fe_set_int(one, 1); ptab_store_raw(tab, px, py, one); }
-    for (int i = 1; i < S2K_PTAB_ENTRIES; i++) {
+    for (int i = 1; i < N; i++) {
         fe dx, dy, c, d, w1, w2, e, a1, x3, y3, tmp;
         fe_neg(dx, px, 4); fe_add(dx, qx); fe_norm_weak(dx);              // X(2A) - X(P): also Z(sum) / Z(operands)
         fe_neg(dy, py, 3); fe_add(dy, qy); fe_norm_weak(dy);
@@ -108,7 +109,12 @@ S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) {
     }
     ziso = zc;
 }
-S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
+S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) { ptab_build_raw_n<S2K_PTAB_ENTRIES>(ziso, tab, A); }
+// N parked entries at `tab` (one per S2K_PTAB_ENTRY_WORDS slot) -> N finished 64-byte sectors at fin + i * fin_stride.  fin == tab with
+// fin_stride == S2K_PTAB_ENTRY_WORDS is the in-place form (a finished sector overwrites the head of its own parked entry, which has
+// been taken over into registers by then).
+template <int N>
+S2K_HD void ptab_rescale_n(u32* tab, u32* fin, int fin_stride, const fe* zs0) {
     fe zs; if (zs0) zs = *zs0; else fe_set_int(zs, 1);
     // The parked entry of step i-1 is requested before the arithmetic of step i and taken over after it (the first use of the loaded
     // words is where the wait lands; x, y, h are a second register set, so no copy of in-flight data sits at the loop head).  Exactly
@@ -117,16 +123,17 @@ S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
     u32 nraw[27];
     fe x, y, h;
 #pragma unroll
-    for (int k = 0; k < 27; k++) nraw[k] = tab[(S2K_PTAB_ENTRIES - 1) * S2K_PTAB_ENTRY_WORDS + k];
+    for (int k = 0; k < 27; k++) nraw[k] = tab[(N - 1) * S2K_PTAB_ENTRY_WORDS + k];
 #pragma unroll
     for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
-    for (int i = S2K_PTAB_ENTRIES - 1; i >= 0; i--) {
-        u32* e = tab + i * S2K_PTAB_ENTRY_WORDS;
+    for (int i = N - 1; i >= 0; i--) {
+        const u32* er = tab + i * S2K_PTAB_ENTRY_WORDS;
+        u32* e = fin + i * fin_stride;
         if (i > 0) {
 #pragma unroll
-            for (int k = 0; k < 27; k++) nraw[k] = e[k - S2K_PTAB_ENTRY_WORDS];
+            for (int k = 0; k < 27; k++) nraw[k] = er[k - S2K_PTAB_ENTRY_WORDS];
         }
-        if (zs0 || i != S2K_PTAB_ENTRIES - 1) {
+        if (zs0 || i != N - 1) {
             fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
             fe_mul(x, x, zs2); fe_mul(y, y, zs3);
         }
@@ -153,6 +160,7 @@ S2K_HD void ptab_rescale(u32* tab, const fe* zs0) {
         }
     }
 }
+S2K_HD void ptab_rescale(u32* tab, const fe* zs0) { ptab_rescale_n<S2K_PTAB_ENTRIES>(tab, tab, S2K_PTAB_ENTRY_WORDS, zs0); }
 // Builds the table for a finite Jacobian A (magnitudes <= (5,3,1)); returns the factor that takes the accumulator's Z
 // from the table's common-Z frame back to the real curve.  ~105 field multiplications.
 S2K_HD void ptab_build(fe& ziso, u32* ptab, const gej& A) {
@@ -519,6 +527,153 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     S2K_PROF_MARK(10);
 #ifdef S2K_ON_SPLIT_DONE
     S2K_ON_SPLIT_DONE();                                                                      // host test build: count completed split runs
+#endif
+    return 1;
+}
+
+
+// ---- the ring form: several multiplications by the SAME point  R_j = e_j*C + s_j*G + f_j*H ---------------------------------------
+// A Borromean ring verifies four public keys P_j = C + j*B with B = -(4^i 10^exp)*H a known multiple of the proof's generator H
+// (secp256k1_rangeproof_pub_expand, rangeproof_impl.h:19-51), so   e_j*P_j = e_j*C + f_j*H ,  f_j = -(j 4^i 10^exp) e_j mod n :
+// the variable point is the same for all four steps of the ring, and the part that changes goes through a fixed-base table of H laid
+// out exactly like the one of G (gtable.h; the engine keeps a small cache of them keyed by the generator's 64 bytes).  What that buys:
+//   * the two odd-multiples tables (of C and of T = 2^64*C) and the 64-doubling chain are built ONCE per ring instead of once per step,
+//     so they can be twice as large: signed odd 5-bit digits, 16 entries per table, 14 additions per stream instead of 17;
+//   * no "key <- key + B", "T <- T + 2^64*B" updates between the steps;
+//   * + S2K_GTAB_WINDOWS additions from H's table on the steps with j > 0.
+// Per ring: 1 chain + 2 tables + 4 x (65 doublings + 56 additions) + 77 table additions, against 4 x (64 doublings + 68 + 11 additions
+// + 2 tables + a chain quarter + 2 key updates) for ecmult_lane_split.
+// Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches), the
+// parked entries of the construction (which is also where a fall-back to ecmult_lane keeps ITS tables: S2K_PTAB_WORDS fit), the Z factor.
+// Digit stream in LDS (S2K_RING_DIG_WORDS words per lane): words 0..8 = 5-bit digit (pos * 4 + stream), six per word; 9..16 = s; 17..24 = f.
+// Only the lock-step form exists (every lane of the wavefront works: the caller gives idle lanes a dummy point and dummy scalars);
+// ecmult_ring_step returns 0, having produced nothing, when a lane met an operand with its own x coordinate, and the caller then takes
+// that step through ecmult_lane on P_j itself.
+#define S2K_RING_W 5
+#define S2K_RING_ENTRIES 16
+#define S2K_RING_DIGITS 13                                      /* 13 x 5 bits above bit 0, + the fixed top digit: odd k < 2^66 */
+#define S2K_RING_ADDS_P (4 * (S2K_RING_DIGITS + 1))
+#define S2K_RING_DIG_WORDS 25
+#define S2K_RTAB_TABLE_WORDS (S2K_RING_ENTRIES * 16)
+#define S2K_RTAB_RAW (2 * S2K_RTAB_TABLE_WORDS)
+#define S2K_RTAB_RAW_WORDS (2 * S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS)
+#define S2K_RTAB_ZISO (S2K_RTAB_RAW + S2K_RTAB_RAW_WORDS)
+#define S2K_RTAB_WORDS (S2K_RTAB_ZISO + 32)
+
+// C, T = 2^64*C finite, magnitudes <= (5,3,1)
+S2K_HD void ecmult_ring_tables(u32* rtab, const gej& C, const gej& T) {
+    fe za, zt, ziso;
+    u32* const raw = rtab + S2K_RTAB_RAW;
+    ptab_build_raw_n<S2K_RING_ENTRIES>(za, raw, C);
+    ptab_build_raw_n<S2K_RING_ENTRIES>(zt, raw + S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS, T);
+    ptab_rescale_n<S2K_RING_ENTRIES>(raw, rtab, 16, &zt);
+    ptab_rescale_n<S2K_RING_ENTRIES>(raw + S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS, rtab + S2K_RTAB_TABLE_WORDS, 16, &za);
+    fe_mul(ziso, za, zt);
+#pragma unroll
+    for (int i = 0; i < 9; i++) rtab[S2K_RTAB_ZISO + i] = ziso.n[i];
+}
+// e != 0; has_f uniform over the wavefront.  htab: this lane's generator's table (same layout as gtab).
+S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scalar& s, const scalar& f, int has_f, const u32* gtab, const u32* htab,
+                            const s2k_lds_ptr dig) {
+    u32 sneg = 0;
+    {
+        half_scalar h0, h1; sc_split_lambda_odd(h0, h1, e);
+        piece65 pc[4]; sc_split_pieces(pc, h0, h1);
+        u32 dw[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) dw[i] = 0;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            sneg |= (u32)pc[st].neg << st;
+#pragma unroll
+            for (int pos = 0; pos < S2K_RING_DIGITS; pos++) {            // pos 0 = most significant digit below the fixed top digit
+                const int i = S2K_RING_DIGITS - 1 - pos, bit = S2K_RING_W * i + 1, word = bit >> 5, sh = bit & 31;
+                const u64 pair = (u64)pc[st].w[word] | ((u64)(word + 1 < 3 ? pc[st].w[word + 1] : 0u) << 32);
+                const u32 v = (u32)(pair >> sh) & 31u;
+                const int nib = pos * 4 + st;
+                dw[nib / 6] |= v << ((nib % 6) * 5);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { dig[(9 + i) * S2K_DIG_STRIDE] = s.d[i]; dig[(17 + i) * S2K_DIG_STRIDE] = f.d[i]; }
+    }
+    const int a_g0 = S2K_RING_ADDS_P, a_h0 = a_g0 + S2K_GTAB_WINDOWS;
+    const int a_end = has_f ? a_h0 + S2K_GTAB_WINDOWS : a_h0;
+    auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
+        addr = rtab; valid = 0; neg = 0;
+        if (idx < a_g0) {
+            const int st = idx & 3;
+            u32 v = 16u;                                                                    // the fixed top digit +1
+            if (idx >= 4) { const int nib = idx - 4; v = (dig[(nib / 6) * S2K_DIG_STRIDE] >> ((nib % 6) * 5)) & 31u; }
+            valid = 1;
+            neg = (v < 16u) ^ (int)((sneg >> st) & 1u);
+            const u32 en = (v < 16u) ? (15u - v) : (v - 16u);
+            addr = rtab + (st >> 1) * S2K_RTAB_TABLE_WORDS + en * 16;
+        } else if (idx < a_end) {
+            const int second = idx >= a_h0;
+            const int g = idx - (second ? a_h0 : a_g0), base = second ? 17 : 9;
+            const int b = g * S2K_GTAB_BITS, w = b >> 5;
+            const u64 pair = (u64)dig[(base + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(base + 1 + w) * S2K_DIG_STRIDE] : 0u) << 32);
+            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+            if (v) { addr = (second ? htab : gtab) + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+        }
+    };
+    auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
+        fe y, yn;
+        fe_from_words(o.x, raw); fe_from_words(y, raw + 8);
+        if (lam) { fe beta; fe_set_beta(beta); fe_mul(o.x, o.x, beta); }          // `lam` is a compile-time constant at every call site
+        fe_neg(yn, y, 1);
+        fe_select(o.y, yn, y, neg);
+    };
+    const u32* nxt_addr; int nxt_valid, nxt_neg;
+    u32 raw[16];
+    ge cur; int cur_valid;
+    op_locate(nxt_addr, nxt_valid, nxt_neg, 0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+    op_decode(cur, raw, nxt_neg, 0);
+    op_locate(nxt_addr, nxt_valid, nxt_neg, 1);
+    // variable part: additions 0..55 as 28 (plain stream, lambda stream) pairs, 5 doublings in front of every group of four but the first
+    int au = 0;
+    while (au < a_g0) {
+        if (au >= 4 && !(au & 3)) {
+#pragma unroll 1
+            for (int k = 0; k < S2K_RING_W; k++) gej_double_lean(R, R);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
+        if (au == 0) gej_set_ge(R, cur);
+        else { const int same_x = gej_add_ge_lean(R, R, cur); if (S2K_WAVE_ANY(same_x)) return 0; }
+        op_decode(cur, raw, nxt_neg, 1);                                    // operand of the lambda stream
+        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 2);
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+        { const int same_x = gej_add_ge_lean(R, R, cur); if (S2K_WAVE_ANY(same_x)) return 0; }
+        au += 2;
+        op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+    }
+    {   // back to the real curve
+        fe zi;
+#pragma unroll
+        for (int i = 0; i < 9; i++) zi.n[i] = rtab[S2K_RTAB_ZISO + i];
+        fe_mul(R.z, R.z, zi);
+    }
+    // table part (G, then H): a zero window adds nothing (per lane), so these additions are committed by select
+    while (au < a_end) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+        gej t; const int same_x = gej_add_ge_lean(t, R, cur);
+        if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
+        if (cur_valid) R = t;
+        au++;
+        op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
+        op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
+    }
+#ifdef S2K_ON_RING_STEP_DONE
+    S2K_ON_RING_STEP_DONE();
 #endif
     return 1;
 }

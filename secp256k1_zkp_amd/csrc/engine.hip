@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -80,6 +81,18 @@ struct s2k_engine {
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
     u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
     int bp_gens_ok;            // every generator of the cached set parsed (what k_bp_gens found when the table was built)
+    // Fixed-base tables of rangeproof generators (rangeproof.h, shared-generator form of the rings kernel): a small cache keyed by the 64
+    // generator bytes.  Slot tables have the layout of gtab (S2K_GTAB_WORDS words, allocated when a slot is first used and then reused by
+    // whatever generator takes the slot); xmul is the x-table of the ring-base multiples (RP_XMUL_WORDS).  gen_keys (device) is what
+    // k_rp_header matches a proof's generator against; gen_seen counts the proofs met per uncached generator (host-buffer calls count
+    // directly, `_dev` calls through the device mailbox gen_mbox / its pinned copy) and a generator is built once it reaches gen_min.
+    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; } gen[RP_GEN_SLOTS];
+    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty;
+    unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
+    rp_gen_mbox* gen_mbox;     // device
+    rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
+    hipEvent_t ev_mbox; int mbox_pending;
+    std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;
     std::recursive_mutex mu;
 };
 
@@ -104,6 +117,11 @@ static int engine_ptab(s2k_engine* e, size_t lanes) {
     HIPCHK(hipMalloc((void**)&e->ptab, lanes * S2K_PTAB_WORDS * sizeof(u32)));
     e->ptab_lanes = lanes;
     return 1;
+}
+// the arena for `lanes` callers of the ring form (S2K_RTAB_WORDS per lane), in units of engine_ptab
+static int engine_rtab(s2k_engine* e, size_t lanes) {
+    lanes = (lanes + 255) & ~size_t(255);
+    return engine_ptab(e, (lanes * S2K_RTAB_WORDS + S2K_PTAB_WORDS - 1) / S2K_PTAB_WORDS);
 }
 // Upper bound on lanes per launch: keeps the per-lane table arena at 1.2 GB however large the batch is; bigger
 // batches run as several launches over sub-ranges (same stream, so the order of results is unaffected).
@@ -153,6 +171,34 @@ k_gtab_entries(u32* gtab) {
     if (w < S2K_GTAB_WINDOWS && v >= 2 && (w + 1 < S2K_GTAB_WINDOWS || v < (1u << top_bits))) gtab_build_entry(gtab, w, v);
 }
 
+// fixed-base table of another point than G (a rangeproof generator): window bases from the 64 generator bytes, then k_gtab_entries
+__global__ void k_gen_base(u32* tab, const unsigned char* gen64) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= S2K_GTAB_WINDOWS) return;
+    ge g; rp_load_generator(g, gen64);
+    gtab_build_base(tab, w, &g);
+}
+// x of j * 4^ring * 10^exp * H for j = 1..3 (rp_ring_suspect): one multiplication per lane
+__global__ void __launch_bounds__(256, 2)
+k_gen_xmul(u32* __restrict__ xmul, const unsigned char* __restrict__ gen64, const u32* __restrict__ gtab, u32* __restrict__ ptab) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 total = RP_XMUL_EXPS * RP_MAX_RINGS * 3;
+    const int live = t < total;
+    const u32 tt = live ? t : 0;
+    const u32 j = tt % 3 + 1, ring = (tt / 3) % RP_MAX_RINGS; const int ex = (int)(tt / (3 * RP_MAX_RINGS));
+    ge g; rp_load_generator(g, gen64);
+    gej A; gej_set_ge(A, g); A.inf = !live;
+    scalar c, k, z; rp_ring_const(c, ex, ring); k = c;
+    for (u32 i = 1; i < j; i++) sc_add(k, k, c);
+    sc_set_zero(z);
+    if (!live) sc_set_zero(k);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + (size_t)t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    gej R; ecmult_lane(R, A, k, z, 0, gtab, lm);
+    ge a; ge_set_gej(a, R);
+    if (live) { u32 w[8]; fe_to_words(w, a.x); for (int i = 0; i < 8; i++) xmul[8 * tt + i] = w[i]; }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // batch double multiplication  r = na*A + ng*G    (secp256k1_ecmult, src/ecmult.h:47)
 // one multiplication per lane; inputs are gathered with byte loads (160 B per lane against ~1.5 M cycles of
@@ -191,6 +237,89 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// generator-table cache (rangeproof.h, shared-generator form): host side
+// ------------------------------------------------------------------------------------------------------------
+// secp256k1_generator_h (src/modules/generator/main_impl.h:30-35): the generator of bench_rangeproof and of every non-asset caller
+static const unsigned char k_generator_h[64] = {
+    0x50, 0x92, 0x9b, 0x74, 0xc1, 0xa0, 0x49, 0x54, 0xb7, 0x8b, 0x4b, 0x60, 0x35, 0xe9, 0x7a, 0x5e, 0x07, 0x8a, 0x5a, 0x0f, 0x28, 0xec, 0x96, 0xd5, 0x47, 0xbf, 0xee, 0x9a, 0xce, 0x80, 0x3a, 0xc0,
+    0x31, 0xd3, 0xc6, 0x86, 0x39, 0x73, 0x92, 0x6e, 0x04, 0x9e, 0x63, 0x7c, 0xb1, 0xb5, 0xf4, 0x0a, 0x36, 0xda, 0xc2, 0x8a, 0xf1, 0x76, 0x69, 0x68, 0xc3, 0x0c, 0x23, 0x13, 0xf3, 0xa3, 0x89, 0x04};
+static rp_gen_dev gen_dev_view(const s2k_engine* e) {
+    rp_gen_dev gc; gc.keys = e->gen_keys; gc.valid = 0; gc.any = 0;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) {
+        const int v = i < e->gen_slots && e->gen[i].valid;
+        gc.tab[i] = v ? e->gen[i].tab : nullptr; gc.xmul[i] = v ? e->gen[i].xmul : nullptr;
+        if (v) { gc.valid |= 1u << i; gc.any = (u32)i; }
+    }
+    return gc;
+}
+static int gen_cache_find(s2k_engine* e, const unsigned char* key) {
+    for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, key, 64)) { e->gen[i].stamp = ++e->gen_clock; return i; }
+    return -1;
+}
+// Builds (stream-ordered on `st`) the tables of `key` into a free slot or the least recently used one; -1 when there is no memory for a
+// table (the proofs then simply keep the general form).  Everything that may still read the slot's old content was queued on `st`
+// before (stream_guard) or waits for gen_dirty (rp_launch).
+static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key) {
+    int slot = gen_cache_find(e, key);
+    if (slot >= 0) return slot;
+    if (e->gen_slots <= 0) return -1;
+    slot = 0;
+    for (int i = 0; i < e->gen_slots; i++) { if (!e->gen[i].valid) { slot = i; break; } if (e->gen[i].stamp < e->gen[slot].stamp) slot = i; }
+    s2k_engine::gen_slot& g = e->gen[slot];
+    if (!g.tab) {
+        if (hipMalloc((void**)&g.tab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }
+        if (hipMalloc((void**)&g.xmul, sizeof(u32) * RP_XMUL_WORDS) != hipSuccess) { (void)hipGetLastError(); hipFree(g.tab); g.tab = nullptr; g.xmul = nullptr; return -1; }
+    }
+    if (!engine_ptab(e, 2048)) return -1;
+    g.valid = 0;
+    memcpy(g.key, key, 64);
+    if (hipMemcpyAsync(e->gen_keys + 64 * slot, g.key, 64, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, e->gen_keys + 64 * slot);
+    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, g.tab);
+    hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, e->gen_keys + 64 * slot, e->gtab, e->ptab);
+    if (hipGetLastError() != hipSuccess) return -1;
+    g.valid = 1; g.stamp = ++e->gen_clock;
+    e->gen_dirty = 1;
+    return slot;
+}
+// `count` more proofs were seen with this (uncached) generator; returns 1 when it has now been seen often enough to deserve a table
+static int gen_note_seen(s2k_engine* e, const unsigned char* key, size_t count) {
+    for (auto& it : e->gen_seen) if (!memcmp(it.first.data(), key, 64)) { it.second += count; return it.second >= e->gen_min; }
+    if (e->gen_seen.size() >= 64) {                         // bounded: forget the least seen
+        size_t lo = 0; for (size_t i = 1; i < e->gen_seen.size(); i++) if (e->gen_seen[i].second < e->gen_seen[lo].second) lo = i;
+        e->gen_seen.erase(e->gen_seen.begin() + lo);
+    }
+    std::array<unsigned char, 64> k; memcpy(k.data(), key, 64);
+    e->gen_seen.emplace_back(k, count);
+    return count >= e->gen_min;
+}
+static void gen_forget_seen(s2k_engine* e, const unsigned char* key) {
+    for (size_t i = 0; i < e->gen_seen.size(); i++) if (!memcmp(e->gen_seen[i].first.data(), key, 64)) { e->gen_seen.erase(e->gen_seen.begin() + i); return; }
+}
+// Start of a rangeproof call: (1) secp256k1_generator_h gets its table once, (2) what the header kernels of the call before reported
+// through the mailbox is counted (its pinned copy is only read once the copy has completed) and generators that are due are built.
+static void gen_cache_service(s2k_engine* e, hipStream_t st) {
+    if (e->gen_slots <= 0) return;
+    if (e->gen_h == 1) { e->gen_h = 2; (void)gen_cache_build(e, st, k_generator_h); }
+    if (e->mbox_pending && hipEventQuery(e->ev_mbox) == hipSuccess) {
+        e->mbox_pending = 0;
+        for (int m = 0; m < RP_GEN_MBOX; m++) {
+            if (e->gen_mbox_host->state[m] != 2u || !e->gen_mbox_host->count[m]) continue;
+            const unsigned char* key = e->gen_mbox_host->key[m];
+            if (gen_cache_find(e, key) >= 0) continue;
+            if (gen_note_seen(e, key, e->gen_mbox_host->count[m]) && gen_cache_build(e, st, key) >= 0) gen_forget_seen(e, key);
+        }
+    } else if (e->mbox_pending) (void)hipGetLastError();
+}
+// End of a rangeproof call: copy the mailbox out and clear it (both on `st`, behind the call's kernels)
+static void gen_cache_collect(s2k_engine* e, hipStream_t st) {
+    if (e->gen_slots <= 0 || e->mbox_pending) return;
+    if (hipMemcpyAsync(e->gen_mbox_host, e->gen_mbox, sizeof(rp_gen_mbox), hipMemcpyDeviceToHost, st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMemsetAsync(e->gen_mbox, 0, sizeof(rp_gen_mbox), st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(e->ev_mbox, st) == hipSuccess) e->mbox_pending = 1; else (void)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // C ABI: engine lifecycle
 // ------------------------------------------------------------------------------------------------------------
 extern "C" s2k_engine* s2k_engine_create(int device) {
@@ -208,6 +337,12 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; }
+    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0;
+    e->gen_keys = nullptr; e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
+    if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); e->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
+    if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) e->gen_min = (size_t)strtoull(gm, nullptr, 10);
+    if (const char* gh = getenv("S2K_GEN_CACHE_H")) e->gen_h = atoi(gh) != 0;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
@@ -241,6 +376,12 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
     S2K_CREATE_CHK(hipMalloc((void**)&e->dev_flags, 64));
     S2K_CREATE_CHK(hipMemset(e->dev_flags, 0, 64));
+    S2K_CREATE_CHK(hipMalloc((void**)&e->gen_keys, 64 * RP_GEN_SLOTS));
+    S2K_CREATE_CHK(hipMemset(e->gen_keys, 0, 64 * RP_GEN_SLOTS));
+    S2K_CREATE_CHK(hipMalloc((void**)&e->gen_mbox, sizeof(rp_gen_mbox)));
+    S2K_CREATE_CHK(hipMemset(e->gen_mbox, 0, sizeof(rp_gen_mbox)));
+    S2K_CREATE_CHK(hipHostMalloc((void**)&e->gen_mbox_host, sizeof(rp_gen_mbox), hipHostMallocDefault));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_mbox, hipEventDisableTiming));
     S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
     S2K_CREATE_CHK(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
     hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
@@ -260,6 +401,11 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
     if (e->dev_flags) hipFree(e->dev_flags);
+    for (int i = 0; i < RP_GEN_SLOTS; i++) { if (e->gen[i].tab) hipFree(e->gen[i].tab); if (e->gen[i].xmul) hipFree(e->gen[i].xmul); }
+    if (e->gen_keys) hipFree(e->gen_keys);
+    if (e->gen_mbox) hipFree(e->gen_mbox);
+    if (e->gen_mbox_host) hipHostFree(e->gen_mbox_host);
+    if (e->ev_mbox) hipEventDestroy(e->ev_mbox);
     for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     for (int i = 0; i < 2; i++) {
         if (e->rp_mem[i]) hipFree(e->rp_mem[i]);
@@ -386,12 +532,17 @@ extern "C" int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
 // Borromean rangeproof batch verification (rangeproof.h): five kernels on one stream
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
+k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* gens64,
+            rp_gen_dev gc, rp_gen_mbox* mbox, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint64_t mn, mx;
     rp_header(ws.rec[p], &mn, &mx, proofs + proof_off[p], proof_off[p + 1] - proof_off[p]);
     min_value[p] = mn; max_value[p] = mx;
+    // which cached generator table (if any) serves this proof; a generator without one is reported for the host's build decision
+    const u32 slot = rp_gen_lookup(gc, gens64 + 64 * p);
+    ws.rec[p].gslot = slot;
+    if (slot == RP_GSLOT_NONE && mbox && (ws.rec[p].hdr & 1u)) rp_gen_report_miss(mbox, gens64 + 64 * p);
 }
 // three waves per 64 proofs: wave 0 commitment + min_value*H, wave 1 generator flag + message hash, wave 2 ring bases
 __global__ void __launch_bounds__(192)
@@ -432,15 +583,29 @@ k_rp_sum(rp_ws ws, size_t n) {
 #define S2K_RINGS_WAVES 2
 #endif
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split) {
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split,
+           rp_gen_dev gc) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     int live = p < n;
     if (!live) p = 0;
     const rp_rec& rec = ws.rec[p];
     live &= (ring < rec.rings);
-    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
-    const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
+    __shared__ u32 s_dig[S2K_RING_DIG_WORDS * 256];
+    u32* const lane_tab = ptab + t * S2K_RTAB_WORDS;
+    // Shared-generator form when every working lane of the wavefront has a cached table for its proof's generator (lanes may name
+    // different slots); otherwise -- or when that form hands the wavefront back (a suspect ring) -- the general form below.
+    if (gc.valid) {
+        const int idle = !(live && rec.ok);
+        const u32 slot = idle ? gc.any : rec.gslot;
+        if (S2K_WAVE_ALL(slot < RP_GEN_SLOTS) && S2K_WAVE_ANY(!idle)) {
+            const u32 sl = slot < RP_GEN_SLOTS ? slot : gc.any;
+            if (rp_ring_shared(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
+                               ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab,
+                               gc.tab[sl], gc.xmul[sl], lane_tab, S2K_LANE_DIG(s_dig), ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr)) return;
+        }
+    }
+    const lane_mem lm{lane_tab, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
             ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr,
             split ? ws.dbases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (const u32*)nullptr, split ? ws.tcur + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (u32*)nullptr);
@@ -549,11 +714,14 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
                      const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr, int inputs_on_stream = 0) {
     const size_t nw = std::min(n, RP_CHUNK);
     if (!engine_rp_slots(e, nw)) return 0;
-    if (!engine_ptab(e, ((nw * RP_MAX_RINGS + 255) / 256) * 256)) return 0;
+    if (!engine_rtab(e, nw * RP_MAX_RINGS)) return 0;
+    gen_cache_service(e, st);
+    const rp_gen_dev gc = gen_dev_view(e);
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
     const hipStream_t sp = e->stream_pre;
-    if (inputs_on_stream || !e->rp_inputs_ready) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); }
+    // (a table built or replaced since the last call was queued on `st`: the side stream must see it, too)
+    if (inputs_on_stream || !e->rp_inputs_ready || e->gen_dirty) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); e->gen_dirty = 0; }
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
         const size_t m = std::min(n - p0, RP_CHUNK);
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
@@ -561,7 +729,8 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         ws_carver c{e->rp_mem[slot], 0}; rp_ws w; rp_ws_carve(w, c, nw);
         // ---- side streams
         if (e->rp_done_valid[slot]) HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_done[slot], 0));
-        hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, sp, w, min_value + p0, max_value + p0, proofs, proof_off + p0, m);
+        hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, sp, w, min_value + p0, max_value + p0, proofs, proof_off + p0, gens64 + 64 * p0,
+                           gc, e->gen_slots > 0 ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
         HIPCHK(hipEventRecord(e->ev_rp_fork[slot], sp));
         HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_rp_fork[slot], 0));
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
@@ -584,7 +753,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         HIPCHK(hipStreamWaitEvent(st, e->ev_rp_pre[slot], 0));
         const unsigned rq = e->ring_seq & 31u;
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[2], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][0], st)); }
-        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split, gc);
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
         if (rewind) {
@@ -601,8 +770,43 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         e->rp_done_valid[slot] = 1;
     }
     HIPCHK(hipGetLastError());
+    gen_cache_collect(e, st);
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
+}
+// Host-side view of a batch's generators (host-buffer entry points): every generator that appears often enough gets its table before
+// the launch, so such a batch takes the shared-generator form from its first call.
+static void gen_cache_scan_host(s2k_engine* e, hipStream_t st, const unsigned char* gens64, size_t n) {
+    if (e->gen_slots <= 0) return;
+    std::vector<std::pair<const unsigned char*, size_t>> distinct;
+    for (size_t i = 0; i < n; i++) {
+        const unsigned char* g = gens64 + 64 * i;
+        size_t k = 0;
+        for (; k < distinct.size(); k++) if (!memcmp(distinct[k].first, g, 64)) { distinct[k].second++; break; }
+        if (k == distinct.size()) { if (distinct.size() >= 32) return; distinct.emplace_back(g, 1); }      // many different generators: nothing to share
+    }
+    for (auto& d : distinct) {
+        if (gen_cache_find(e, d.first) >= 0) continue;
+        if (gen_note_seen(e, d.first, d.second) && gen_cache_build(e, st, d.first) >= 0) gen_forget_seen(e, d.first);
+    }
+}
+// Builds the tables of one generator now (host bytes: the 64-byte secp256k1_generator object, include/secp256k1_generator.h:22-24).
+// Returns 1 when the generator has a table afterwards.
+extern "C" int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* gen64) {
+    if (!e || !gen64) return s2k_fail_arg("s2k_engine_cache_generator", "illegal argument");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    stream_guard sg(e, e->stream);
+    if (e->gen_h == 1 && !memcmp(gen64, k_generator_h, 64)) e->gen_h = 2;
+    if (gen_cache_build(e, e->stream, gen64) < 0) return s2k_fail("s2k_engine_cache_generator", "no slot or no memory for a generator table (S2K_GEN_CACHE)");
+    return 1;
+}
+// 1 when `gen64` currently has a table
+extern "C" int s2k_engine_generator_cached(s2k_engine* e, const unsigned char* gen64) {
+    if (!e || !gen64) return 0;
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, gen64, 64)) return 1;
+    return 0;
 }
 extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
@@ -642,6 +846,7 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     if (ebytes) { HIPCHK(hipMemcpyAsync(d_ex, extra, ebytes, hipMemcpyHostToDevice, st)); }
     if (extra && extra_off) HIPCHK(hipMemcpyAsync(d_eoff, extra_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_gen, gens64, 64 * n, hipMemcpyHostToDevice, st));
+    gen_cache_scan_host(e, st, gens64, n);
     if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, nullptr, 1)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
@@ -685,6 +890,7 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipMemcpyAsync((void*)ra.nonces, nonces, 32 * n, hipMemcpyHostToDevice, st));
     if (message_out) { HIPCHK(hipMemcpyAsync(ra.outlen, outlen, 8 * n, hipMemcpyHostToDevice, st)); HIPCHK(hipMemsetAsync(ra.msg_out, 0, mbytes, st)); }
     else HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
+    gen_cache_scan_host(e, st, gens64, n);
     if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, &ra, 1)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
@@ -716,7 +922,9 @@ extern "C" int secp256k1_rangeproof_rewind_batch_dev(s2k_engine* e, void* stream
     ra.outlen = message_out ? outlen : c.take<uint64_t>(n);
     ra.ev = c.take<u32>(nw * 1024); ra.prep = c.take<u32>(nw * 1024); ra.secs = c.take<u32>(nw * 256);
     if (!message_out) HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
-    return rp_launch(e, st, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n, &ra);
+    // inputs_on_stream = 1 whatever S2K_OPT_RP_INPUTS_READY says: the replay kernel writes ra.prep / ra.secs -- carved from the SHARED workspace
+    // -- on the side stream, so that stream has to wait for whatever an earlier call queued on `st` may still be doing with the workspace
+    return rp_launch(e, st, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n, &ra, 1);
 }
 // single-item forms with the reference's argument lists.  A 0 from these means "invalid" only while s2k_last_status() is
 // S2K_STATUS_OK; an engine-level failure also returns 0 (never 1) and leaves S2K_STATUS_ENGINE_FAILURE for the caller's
@@ -1953,6 +2161,20 @@ extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
     switch (option) {
     case S2K_OPT_RP_INPUTS_READY: e->rp_inputs_ready = value != 0; return 1;
     case S2K_OPT_RP_SPLIT: e->rp_split = value != 0; return 1;
+    case S2K_OPT_GEN_CACHE_SLOTS: {
+        const int v = value < 0 ? 0 : (value > RP_GEN_SLOTS ? RP_GEN_SLOTS : (int)value);
+        if (v < e->gen_slots) {                            // slots that go away give their tables back once nothing can still read them
+            if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return s2k_fail("s2k_engine_set_option", "device synchronisation failed");
+            for (int i = v; i < e->gen_slots; i++) {
+                if (e->gen[i].valid && !memcmp(e->gen[i].key, k_generator_h, 64) && e->gen_h == 2) e->gen_h = 1;
+                if (e->gen[i].tab) hipFree(e->gen[i].tab);
+                if (e->gen[i].xmul) hipFree(e->gen[i].xmul);
+                e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0;
+            }
+        }
+        e->gen_slots = v; return 1;
+    }
+    case S2K_OPT_GEN_CACHE_MIN: e->gen_min = value < 1 ? 1 : (size_t)value; return 1;
     default: return s2k_fail_arg("s2k_engine_set_option", "unknown option");
     }
 }

@@ -22,9 +22,10 @@ S2K_HD void gtab_store(u32* gtab, u32 w, u32 v, const ge& a) {
     fe_to_words(wx, a.x); fe_to_words(wy, a.y);                     // `a` is normalised (ge_set_gej)
     for (int i = 0; i < 8; i++) { p[i] = wx[i]; p[8 + i] = wy[i]; }
 }
-// step 1 (one thread per window w): base[w] = 2^(B w) * G, affine, stored as entry (w, 1).
-S2K_HD void gtab_build_base(u32* gtab, u32 w) {
-    ge g; ge_set_generator(g);
+// step 1 (one thread per window w): base[w] = 2^(B w) * G, affine, stored as entry (w, 1).  `base`: any other point than G (the
+// fixed-base tables of the rangeproof generators, rangeproof.h "shared-generator form", have exactly this layout).
+S2K_HD void gtab_build_base(u32* gtab, u32 w, const ge* base = nullptr) {
+    ge g; if (base) g = *base; else ge_set_generator(g);
     gej j; gej_set_ge(j, g);
     for (u32 i = 0; i < S2K_GTAB_BITS * w; i++) { gej t; gej_double(t, j); j = t; }
     ge a; ge_set_gej(a, j);

@@ -16,12 +16,13 @@
 // two orders of magnitude cheaper, so their low parallelism does not matter.  Stages communicate through a
 // per-proof scratch record in HBM (layout below); nothing is read back by the host between stages.
 #pragma once
-#include "ecmult.h"
+#include "gtable.h"
 #include "sha256.h"
 
 #define RP_MAX_RINGS 32
 #define RP_GEJ_WORDS 28
 #define RP_RING_OUT_BYTES (RP_MAX_RINGS * 33 + 32)      /* 1088 = 17 SHA-256 blocks for a full-size proof */
+#define RP_GSLOT_NONE 0xFFFFFFFFu
 
 struct rp_rec {
     u32 ok;            // structural checks passed (K0); cleared by later stages on failure
@@ -32,6 +33,7 @@ struct rp_rec {
     u32 off_e0;
     u32 off_s;
     u32 hdr;           // bit 0: header and structure parsed (K0a); bits 8..15: exp + 1
+    u32 gslot;         // slot of the proof's generator in the engine's table cache, RP_GSLOT_NONE when it has none (shared-generator form of K3)
     u32 m[8];          // message hash, big-endian words
     u32 commit[18];    // commitment, affine limbs (x, y)
     u32 accj[RP_GEJ_WORDS];   // min_value * H (infinity when min_value == 0)
@@ -99,7 +101,7 @@ S2K_HD int rp_getheader(u32& offset, int& exp, int& mantissa, u64& scale, u64* m
 // K0a: header and structure (rangeproof_impl.h:541-608 up to the point where curve arithmetic starts).  Cheap; K1 (lift) only
 // needs this part, so the expensive part below (K0b) can run next to K1.
 S2K_HD void rp_header(rp_rec& rec, u64* min_value, u64* max_value, const unsigned char* proof, u64 plen) {
-    rec.ok = 0; rec.rings = 0; rec.last_rsize = 0; rec.hdr = 0;
+    rec.ok = 0; rec.rings = 0; rec.last_rsize = 0; rec.hdr = 0; rec.gslot = RP_GSLOT_NONE;
     rec.off_signs = 0; rec.off_pts = 0; rec.off_e0 = 0; rec.off_s = 0;
     *min_value = 0; *max_value = 0;
     u32 offset; int exp, mantissa; u64 scale;
@@ -257,6 +259,7 @@ S2K_HD void rp_sum(rp_rec& rec, u32* pub0 /*[32][28]*/, const unsigned char* lif
     gej last; const int f = gej_add_ge(last, acc, cm);
     if (f == GEJ_ADD_NEEDS_DOUBLE) { gej t; gej_double(t, last); last = t; }
     if (last.inf) ok = 0;
+    else { ge a; ge_set_gej(a, last); gej_set_ge(last, a); }          // every ring key leaves this stage with Z = 1 (rp_ring_shared relies on it)
     gej_store28_h(pub0 + RP_GEJ_WORDS * (rec.rings - 1), last);
     if (!ok) rec.ok = 0;
 }
@@ -391,6 +394,190 @@ S2K_HD void rp_ring(const rp_rec& rec, const u32* base28, u32* pub28, unsigned c
         for (int i = 0; i < 8; i++) s2k_store_be32(ring_out33 + 1 + 4 * i, outx[i]);
         *ring_ok = (unsigned char)ok;
     }
+}
+
+// ---- the generator-table cache as the kernels see it ---------------------------------------------------------------------------
+#define RP_GEN_SLOTS 8
+#define RP_GEN_MBOX 4
+struct rp_gen_dev {                       // by value to the kernels: the cache at the time of the launch
+    const u32* tab[RP_GEN_SLOTS];         // fixed-base table (layout of gtab), nullptr for an empty slot
+    const u32* xmul[RP_GEN_SLOTS];        // RP_XMUL_WORDS
+    const unsigned char* keys;            // [RP_GEN_SLOTS][64] generator bytes
+    u32 valid;                            // bit i: slot i holds a table
+    u32 any;                              // index of some valid slot (idle lanes read its x-table)
+};
+// generators that had no table: the first few distinct ones of a call with the number of proofs that carried them
+struct rp_gen_mbox { u32 state[RP_GEN_MBOX]; u32 count[RP_GEN_MBOX]; unsigned char key[RP_GEN_MBOX][64]; };
+S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
+    u32 slot = RP_GSLOT_NONE;
+    for (u32 i = 0; i < RP_GEN_SLOTS; i++) {
+        if (!((gc.valid >> i) & 1u)) continue;
+        int same = 1;
+        for (int k = 0; k < 64; k++) same &= (gc.keys[64 * i + k] == gen64[k]);
+        if (same) slot = i;
+    }
+    return slot;
+}
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64) {
+    for (int m = 0; m < RP_GEN_MBOX; m++) {
+        u32 st = atomicAdd(&mb->state[m], 0u);
+        if (st == 0u && atomicCAS(&mb->state[m], 0u, 1u) == 0u) {
+            for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k];
+            mb->count[m] = 1u;
+            __threadfence();
+            atomicExch(&mb->state[m], 2u);
+            return;
+        }
+        if (st == 1u) continue;                       // being written by another lane: this proof goes uncounted
+        st = atomicAdd(&mb->state[m], 0u);
+        if (st == 2u) {
+            int same = 1;
+            for (int k = 0; k < 64; k++) same &= (mb->key[m][k] == gen64[k]);
+            if (same) { atomicAdd(&mb->count[m], 1u); return; }
+        }
+    }
+}
+#endif
+
+// ---- K3, shared-generator form --------------------------------------------------------------------------------------
+// The four keys of a ring are P_j = C + j*B with B = -(4^ring 10^exp)*H (pub_expand :19-51), so every step is
+//     e_j*P_j + s_j*G = e_j*C + s_j*G + f_j*H ,   f_j = -(j 4^ring 10^exp) e_j mod n ,
+// one variable point for the whole ring: its tables and the 2^64 chain are built once (ecmult.h, "the ring form") and f_j*H comes from a
+// fixed-base table of the proof's generator (`htab`, same layout as the table of G; the engine caches one per generator).
+// Bit-exactness of the accept/reject decision needs two things the reference does with the keys themselves:
+//   * it rejects a key that is the point at infinity (borromean_impl.h:78): P_j = inf <=> C = -j*B, impossible for an honest prover but
+//     a choice an adversarial one has.  `xmul` holds the affine x of j*(4^ring 10^exp)*H for j = 1..3 (a per-generator table, see
+//     RP_XMUL_*): a ring whose C has one of these x coordinates is `suspect` and the caller takes the whole wavefront through rp_ring;
+//   * exceptional additions inside a step (an operand with the accumulator's own x): that step is redone through ecmult_lane on P_j.
+// Idle lanes (a proof that failed earlier, a ring beyond the proof's count, a step beyond the ring's size, a zero or overflowing
+// scalar) ride along on a dummy point / dummy scalars so that the wavefront stays in lock step; their results are discarded.
+#define RP_XMUL_EXPS 19
+#define RP_XMUL_WORDS (RP_XMUL_EXPS * RP_MAX_RINGS * 3 * 8)       /* [exp][ring][j-1][8 canonical words, least significant first] */
+S2K_HD void rp_ring_const(scalar& c, int exp, u32 ring) {         // 4^ring * 10^exp  (< 2^124)
+    u64 scale = 1;
+    for (int i = 0; i < exp; i++) scale *= 10;
+    const u32 sh = 2 * ring;
+    const u64 lo = scale << sh, hi = sh ? (scale >> (64 - sh)) : 0;
+    sc_set_zero(c);
+    c.d[0] = (u32)lo; c.d[1] = (u32)(lo >> 32); c.d[2] = (u32)hi; c.d[3] = (u32)(hi >> 32);
+}
+// 1 when C (affine, Z = 1 record) shares its x with one of B, 2B, 3B
+S2K_HD int rp_ring_suspect(const gej& C, const u32* xmul /* this (exp, ring)'s 3 x 8 words */) {
+    int hit = 0;
+    for (int j = 0; j < 3; j++) {
+        u32 w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = xmul[8 * j + i];
+        fe x; fe_from_words(x, w);
+        hit |= fe_equal(x, C.x);
+    }
+    return hit;
+}
+// Returns 0 without having written anything when the wavefront has to take rp_ring instead (a suspect ring).
+// pub28: C with Z = 1 (rp_lift; rp_sum brings the last key to affine when asked to).  rtab: this lane's S2K_RTAB_WORDS of HBM.
+S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* base28, const u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
+                          const unsigned char* proof, u32 ring, int live, const u32* gtab, const u32* htab, const u32* xmul, u32* rtab,
+                          const s2k_lds_ptr dig, u32* ev_out = nullptr) {
+    const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
+    int ok = live & (int)rec.ok;
+    const int exp = ok ? (int)((rec.hdr >> 8) & 0xFFu) - 1 : 0;
+    gej C;
+    {
+        gej_load28_h(C, pub28);
+        if (C.inf) ok = 0;
+        ge g; ge_set_generator(g);
+        if (!ok) gej_set_ge(C, g);                                       // idle lane: dummy point
+    }
+    {
+        const int e_idx = exp < 0 ? 0 : exp;
+        const int suspect = ok & rp_ring_suspect(C, xmul + ((size_t)e_idx * RP_MAX_RINGS + ring) * 24);
+        if (S2K_WAVE_ANY(suspect)) return 0;
+    }
+    u32 e[8];
+    {
+        u32 m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+        u32 e0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {                                   // never touch proof bytes of a proof that failed its structural checks
+            const unsigned char* pe0 = proof + rec.off_e0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) e0[i] = s2k_load_be32(pe0 + 4 * i);
+        }
+        rp_hash_e0(e, e0, m, ring);
+    }
+    S2K_PROF_DECL;
+    {
+        gej T = C;
+#pragma unroll 1
+        for (int k = 0; k < 64; k++) gej_double_lean(T, T);
+        fe_norm_weak(T.y);
+        S2K_PROF_MARK(11);
+        ecmult_ring_tables(rtab, C, T);
+        S2K_PROF_MARK(8);
+    }
+    scalar cring; rp_ring_const(cring, exp < 0 ? 0 : exp, ring);
+    // dummy scalars of idle lanes / idle steps (any fixed nonzero values)
+    const scalar dummy_e = {{0x9E3779B9u, 0x7F4A7C15u, 0xF39CC060u, 0x5CEDC834u, 0x1082276Bu, 0xF3A27251u, 0xF86C6A11u, 0x0D5A2B4Fu}};
+    const scalar dummy_s = {{0x2545F491u, 0x4F6CDD1Du, 0x6C078965u, 0x5851F42Du, 0x14057B7Eu, 0xF767814Fu, 0x9FB21C65u, 0x1E35A7BDu}};
+    u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
+#pragma unroll 1
+    for (u32 j = 0; j < 4; j++) {
+        const int step_live = ok & (j < rsize);
+        scalar ens, s; int ov_e, ov_s = 0;
+        if (ev_out && live) { for (int i = 0; i < 8; i++) ev_out[8 * j + i] = e[i]; }
+        rp_words_to_scalar(ens, ov_e, e);
+        sc_set_zero(s);
+        if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);
+        int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens);
+        if (!good) { ens = dummy_e; s = dummy_s; }
+        scalar f; sc_set_zero(f);
+        if (j > 0) {
+            scalar k = cring;
+            for (u32 t = 1; t < j; t++) sc_add(k, k, cring);
+            sc_mul(f, ens, k); sc_negate(f, f);
+        }
+        gej R;
+        S2K_PROF_MARK(0);
+        const int done = ecmult_ring_step(R, rtab, ens, s, f, j > 0, gtab, htab, dig);
+        if (!S2K_WAVE_ALL(done)) {
+            // an exceptional addition somewhere in the wavefront: this step through the general multiplication, on the key itself
+            gej P = C, B; gej_load28_h(B, base28);
+            for (u32 t = 0; t < j; t++) { gej n2; gej_add_var(n2, P, B); P = n2; }
+            scalar e2 = ens, s2 = s;
+            if (!good | P.inf) { sc_set_zero(e2); sc_set_zero(s2); good = 0; }
+            const lane_mem lm{rtab + S2K_RTAB_RAW, dig};
+            ecmult_lane(R, P, e2, s2, 1, gtab, lm);
+        }
+        S2K_PROF_RESET;
+        good &= !R.inf;
+        ge a; ge_set_gej(a, R);
+        S2K_PROF_MARK(4);
+        u32 xw[8]; fe_to_words(xw, a.x);
+        u32 xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xb[i] = xw[7 - i];
+        const u32 prefix = 2u | (u32)fe_is_odd(a.y);
+        if (step_live) ok &= good;
+        if (j + 1 < rsize) {
+            u32 m[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+            rp_hash_step(e, prefix, xb, m, ring, j + 1);
+        } else if (j + 1 == rsize) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) outx[i] = xb[i];
+            outp = prefix;
+        }
+        S2K_PROF_MARK(5);
+    }
+    if (live) {
+        ring_out33[0] = (unsigned char)outp;
+        for (int i = 0; i < 8; i++) s2k_store_be32(ring_out33 + 1 + 4 * i, outx[i]);
+        *ring_ok = (unsigned char)ok;
+    }
+    return 1;
 }
 
 // ---- K4: close the loop (borromean_impl.h:100-103) ---------------------------------------------------------------------

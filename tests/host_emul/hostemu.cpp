@@ -6,6 +6,8 @@
 #define S2K_VERIFY 1
 static unsigned long long g_split_done = 0;
 #define S2K_ON_SPLIT_DONE() (g_split_done++)
+static unsigned long long g_ring_steps_done = 0;
+#define S2K_ON_RING_STEP_DONE() (g_ring_steps_done++)
 #include "../../secp256k1_zkp_amd/csrc/gtable.h"
 #include "../../secp256k1_zkp_amd/csrc/sha256.h"
 #include "../../secp256k1_zkp_amd/csrc/rangeproof.h"
@@ -88,12 +90,12 @@ static u32 g_dig[S2K_DIG_WORDS];
 static const lane_mem g_lm{g_ptab, g_dig};
 // Host-only construction of the window table (this library is compiled with -DS2K_GTAB_BITS=12 to keep it small): same entries as gtable.h's device kernels, but built by running
 // sums + Montgomery batch inversion so that a CPU test does not spend a minute on a million inversions.
-static const u32* gtab_host() {
-    if (g_gtab.empty()) {
+static void table_host(std::vector<u32>& g_gtab, const ge* point) {
+    {
         g_gtab.assign(S2K_GTAB_WORDS, 0);
         const u32 NV = 1u << S2K_GTAB_BITS; std::vector<gej> acc(NV); std::vector<fe> pre(NV);
         for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
-            gtab_build_base(g_gtab.data(), w);
+            gtab_build_base(g_gtab.data(), w, point);
             ge base; gtab_load(base, g_gtab.data(), w, 1);
             gej_set_ge(acc[1], base);
             for (u32 v = 2; v < NV; v++) {
@@ -112,6 +114,9 @@ static const u32* gtab_host() {
             }
         }
     }
+}
+static const u32* gtab_host() {
+    if (g_gtab.empty()) table_host(g_gtab, nullptr);
     return g_gtab.data();
 }
 // spot-check entry (w, v) of the host table against the device construction path
@@ -165,6 +170,51 @@ int emu_rangeproof_verify(unsigned long long* min_value, unsigned long long* max
                                          dbases.data() + 28 * i, tcur.data() + 28 * i);
     return rp_final(rec, ring_out, ring_ok, proof);
 }
+
+// the same with stage K3 in its shared-generator form (rp_ring_shared): a fixed-base table and the j*B x-table of the proof's generator
+// are built here the way the engine's cache builds them; *fast_rings counts the rings that completed in that form
+static std::vector<u32> g_htab, g_xmul; static unsigned char g_hkey[64]; static int g_hkey_valid = 0;
+static void htab_host(const unsigned char* gen64) {
+    if (g_hkey_valid && !memcmp(g_hkey, gen64, 64)) return;
+    ge g; rp_load_generator(g, gen64);
+    table_host(g_htab, &g);
+    g_xmul.assign(RP_XMUL_WORDS, 0);
+    gej A; gej_set_ge(A, g);
+    for (int e = 0; e < RP_XMUL_EXPS; e++) for (u32 ring = 0; ring < RP_MAX_RINGS; ring++) for (u32 j = 1; j <= 3; j++) {
+        scalar c, k, z; rp_ring_const(c, e, ring); k = c; for (u32 t = 1; t < j; t++) sc_add(k, k, c);
+        sc_set_zero(z);
+        gej R; u32 dig[S2K_DIG_WORDS]; const lane_mem lm{g_ptab, dig};
+        ecmult_lane(R, A, k, z, 0, gtab_host(), lm);
+        ge a; ge_set_gej(a, R);
+        fe_to_words(g_xmul.data() + (((size_t)e * RP_MAX_RINGS + ring) * 3 + (j - 1)) * 8, a.x);
+    }
+    memcpy(g_hkey, gen64, 64); g_hkey_valid = 1;
+}
+int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
+                                 const unsigned char* extra, size_t extra_len, const unsigned char* gen64, int* fast_rings) {
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0), rtab(S2K_RTAB_WORDS, 0);
+    unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
+    u64 mn, mx;
+    htab_host(gen64);
+    rp_prologue(rec, bases.data(), &mn, &mx, commit33, proof, plen, extra_len ? extra : nullptr, extra_len, gen64, dbases.data());
+    *min_value = mn; *max_value = mx;
+    if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
+    rp_sum(rec, pub0.data(), lift_ok);
+    int fast = 0;
+    u32 dig[S2K_RING_DIG_WORDS];
+    for (u32 i = 0; i < 32; i++) {
+        const int live = i < rec.rings;
+        int did = 0;
+        if (live && rec.ok) did = rp_ring_shared(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_htab.data(),
+                                                 g_xmul.data(), rtab.data(), dig);
+        if (did) fast++;
+        else rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_lm, nullptr,
+                     dbases.data() + 28 * i, tcur.data() + 28 * i);
+    }
+    if (fast_rings) *fast_rings = fast;
+    return rp_final(rec, ring_out, ring_ok, proof);
+}
+unsigned long long emu_ring_step_count(void) { return g_ring_steps_done; }
 
 // verification with the challenges kept, then rangeproof_rewind.h and the commitment check of k_rp_rewind (engine.hip)
 int emu_rangeproof_rewind(unsigned char* blind_out, unsigned long long* value_out, unsigned char* msg_out, unsigned long long* outlen, const unsigned char* nonce32,

@@ -173,6 +173,57 @@ def test_emu_rangeproof(emu, ref):
             assert _emu_rp(emu, commits[0], p, gens[0]) == (rr[0], rmn[0], rmx[0])
 
 
+def _emu_rp_shared(emu, c, p, g, extra=b""):
+    mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0); fast = ctypes.c_int(0)
+    r = emu.emu_rangeproof_verify_shared(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)),
+                                         g.tobytes(), ctypes.byref(fast))
+    return (r, mn.value, mx.value), fast.value
+
+
+def test_emu_rangeproof_shared_generator_form(emu, ref):
+    """K3 in its shared-generator form (rp_ring_shared: tables of the ring's point built once, f_j*H from a fixed-base table of the
+    generator): same accept/reject, min and max as the reference on its fixed vectors, on reference-signed proofs of several shapes
+    (other generators included) and on mutated proofs; rings whose point collides with a multiple of the ring base (a key at
+    infinity, which the reference rejects) must leave the fast form and still agree."""
+    rng = np.random.default_rng(31)
+    vecs = _golden("rangeproof_vectors.json")["vectors"]
+    gh = np.frombuffer(GENERATOR_H, np.uint8)
+    emu.emu_ring_step_count.restype = ctypes.c_ulonglong
+    steps0 = emu.emu_ring_step_count()
+    for v in vecs:
+        r, fast = _emu_rp_shared(emu, np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8), bytes.fromhex(v["proof"]), gh)
+        assert r == (v["result"], int(v["min_value"]), int(v["max_value"])), v["name"]
+    assert emu.emu_ring_step_count() > steps0
+    for (mb, exp, minv) in ((64, 0, 0), (5, 2, 17), (1, 0, 0), (13, 3, 1000), (52, 0, 0)):
+        commits, plist, gens, _ = ref.make_rangeproofs(1, rng, min_bits=mb, exp=exp, min_value=minv)
+        res, mn, mx = ref.rangeproof_verify_many(commits, plist, gens)
+        r, fast = _emu_rp_shared(emu, commits[0], plist[0], gens[0])
+        assert r == (res[0], mn[0], mx[0]) and res[0] == 1 and fast >= 1
+        for k in range(3):
+            p = bytearray(plist[0]); p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8)); p = bytes(p)
+            rr, rmn, rmx = ref.rangeproof_verify_many(commits[:1], [p], gens[:1])
+            assert _emu_rp_shared(emu, commits[0], p, gens[0])[0] == (rr[0], rmn[0], rmx[0])
+    # another generator than H
+    g2 = np.frombuffer(ref.rand_point(rng), np.uint8).reshape(1, 64).copy()
+    commits, plist, gens, _ = ref.make_rangeproofs(1, rng, min_bits=12, gens64=g2)
+    res, mn, mx = ref.rangeproof_verify_many(commits, plist, gens)
+    r, fast = _emu_rp_shared(emu, commits[0], plist[0], gens[0])
+    assert r == (res[0], mn[0], mx[0]) and res[0] == 1 and fast >= 1
+    # a ring commitment equal to +-j * 4^i * H: the key P_j = C + j*B is infinity (or 2jB): those rings must not be served by the fast form
+    commits, plist, gens, _ = ref.make_rangeproofs(1, rng, min_bits=8)
+    p = bytearray(plist[0])
+    # header: byte 0 (exp | flags), byte 1 (mantissa - 1); 4 rings -> 1 sign byte, then 3 ring commitments x
+    for (ring, j) in ((0, 1), (1, 2), (2, 3)):
+        k = (j * 4**ring) % N
+        pt = ref.ecmult_batch(gh.reshape(1, 64), np.frombuffer(_b(k), np.uint8).reshape(1, 32))[0][0]
+        for sign in (0, 1):          # one of the two lifts is C = -j*B (key at infinity), the other C = +j*B
+            q = bytearray(p); q[3 + 32 * ring:3 + 32 * ring + 32] = pt[:32].tobytes()
+            q[2] = (q[2] & ~(1 << ring)) | (sign << ring)
+            rr, rmn, rmx = ref.rangeproof_verify_many(commits[:1], [bytes(q)], gens[:1])
+            r, fast = _emu_rp_shared(emu, commits[0], bytes(q), gens[0])
+            assert r == (rr[0], rmn[0], rmx[0]) and fast <= 3, (ring, j, sign)
+
+
 def test_emu_schnorr(emu, ref):
     for v in _golden("bip340_vectors.json")["vectors"]:
         msg = bytes.fromhex(v["msg"])

@@ -1,0 +1,143 @@
+"""GPU parity of the shared-generator form of the rings kernel (rangeproof.h: rp_ring_shared, the engine's generator-table cache):
+whatever the cache holds, accept/reject, min and max equal the reference's secp256k1_rangeproof_verify -- with one shared generator,
+with a different generator per proof, with mixes that cross the cache's capacity, across evictions, and for generators that get their
+table automatically (host-buffer calls: counted before the launch; `_dev` calls: through the device mailbox)."""
+import numpy as np
+import pytest
+
+from tests.refapi import GENERATOR_H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    """an engine of its own: these tests change cache options"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu needs a GPU")
+    from secp256k1_zkp_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _gen(ref, rng):
+    return np.frombuffer(ref.rand_point(rng), np.uint8).copy()
+
+
+def _batch(ref, rng, gens_list, per=3, min_bits=(64, 12, 52, 1)):
+    """`per` proofs for every (generator, shape) pair, plus mutated copies"""
+    C, P, G = [], [], []
+    for g in gens_list:
+        for mb in min_bits:
+            gg = np.tile(g, (per, 1))
+            c, p, g2, _ = ref.make_rangeproofs(per, rng, min_bits=mb, gens64=gg)
+            C.append(c); P += p; G.append(g2)
+    C = np.concatenate(C); G = np.concatenate(G)
+    n = len(P)
+    mc, mp, mg = [C], list(P), [G]
+    for i in range(0, n, 2):
+        q = bytearray(P[i]); q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8))
+        mp.append(bytes(q)); mc.append(C[i:i + 1]); mg.append(G[i:i + 1])
+        mp.append(P[i]); mc.append(C[i:i + 1]); mg.append(G[(i + per * len(min_bits)) % n][None])      # right proof, another generator
+    return np.concatenate(mc), mp, np.concatenate(mg)
+
+
+def _same(engine, ref, C, P, G):
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(C, P, G, threads=8)
+    res, mn, mx = engine.rangeproof_verify_batch(C, P, G)
+    assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
+    return e_res
+
+
+def test_cache_on_off_and_capacity(eng2, ref):
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(901)
+    H = np.frombuffer(GENERATOR_H, np.uint8)
+    g1, g2, g3 = _gen(ref, rng), _gen(ref, rng), _gen(ref, rng)
+    C, P, G = _batch(ref, rng, [H, g1, g2, g3])
+    # per-item random generators on top (the Elements case: every output its own blinded asset generator)
+    gd = np.stack([_gen(ref, rng) for _ in range(8)])
+    c, p, gd, _ = ref.make_rangeproofs(8, rng, min_bits=64, gens64=gd)
+    C = np.concatenate([C, c]); P = P + p; G = np.concatenate([G, gd])
+    eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 30)           # nothing gets a table unless asked for
+    eng2.set_option(Engine.OPT_GEN_CACHE_SLOTS, 0)
+    e_res = _same(eng2, ref, C, P, G)                              # general form only
+    assert 0 < e_res.sum() < len(P) and not eng2.generator_cached(GENERATOR_H)
+    eng2.set_option(Engine.OPT_GEN_CACHE_SLOTS, 2)
+    _same(eng2, ref, C, P, G)                                      # H only (built at this call)
+    assert eng2.generator_cached(GENERATOR_H)
+    eng2.cache_generator(g1)
+    _same(eng2, ref, C, P, G)                                      # H + g1
+    eng2.cache_generator(g2)                                       # capacity 2: the least recently used table (H or g1) makes room
+    assert eng2.generator_cached(g2) and (eng2.generator_cached(GENERATOR_H) + eng2.generator_cached(g1)) == 1
+    _same(eng2, ref, C, P, G)
+    eng2.cache_generator(g3); eng2.cache_generator(g1)
+    assert eng2.generator_cached(g3) and eng2.generator_cached(g1) and not eng2.generator_cached(g2)
+    _same(eng2, ref, C, P, G)
+    # back and forth between two batches that each want "their" generator
+    for gx in (g2, g3, g2):
+        eng2.cache_generator(gx)
+        sel = [i for i in range(len(P)) if G[i].tobytes() == gx.tobytes()]
+        _same(eng2, ref, C[sel], [P[i] for i in sel], G[sel])
+
+
+def test_automatic_tables(eng2, ref):
+    """a generator that keeps coming gets a table by itself: host-buffer calls decide before the launch, `_dev` calls one call later"""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(902)
+    eng2.set_option(Engine.OPT_GEN_CACHE_SLOTS, 3)
+    eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 10)
+    ga, gb = _gen(ref, rng), _gen(ref, rng)
+    c, p, g, _ = ref.make_rangeproofs(6, rng, min_bits=20, gens64=np.tile(ga, (6, 1)))
+    _same(eng2, ref, c, p, g)
+    assert not eng2.generator_cached(ga)                           # 6 < 10
+    _same(eng2, ref, c, p, g)
+    assert eng2.generator_cached(ga)                               # 12 seen: built before the second launch
+    # `_dev`: the header kernel reports generators without a table; the host reads that report at the next call
+    c, p, g, _ = ref.make_rangeproofs(12, rng, min_bits=20, gens64=np.tile(gb, (12, 1)))
+    q = bytearray(p[3]); q[40] ^= 4; p[3] = bytes(q)
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(c, p, g)
+    dev = torch.device("cuda", 0)
+    pdata, poff = Engine.pack(p)
+    d_c = torch.tensor(c).to(dev); d_g = torch.tensor(np.ascontiguousarray(g)).to(dev)
+    d_p = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
+    d_res = torch.zeros(12, dtype=torch.int32, device=dev); d_mn = torch.zeros(12, dtype=torch.int64, device=dev); d_mx = torch.zeros(12, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for k in range(3):
+        eng2.rangeproof_verify_batch_dev(d_res, d_mn, d_mx, d_c, d_p, d_off, d_g, 12)
+        eng2.sync()
+        assert np.array_equal(d_res.cpu().numpy(), e_res) and np.array_equal(d_mx.cpu().numpy().view(np.uint64), e_mx)
+        assert eng2.generator_cached(gb) == (k >= 1)               # reported by call 0, built at the start of call 1
+    eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 16)
+
+
+@pytest.mark.parametrize("kind", ["shared", "distinct", "mixed"])
+def test_full_size_by_generator_kind(engine, ref, kind):
+    """2^14 proofs: (shared) one generator for all, (distinct) every proof its own, (mixed) five generators for most proofs -- more
+    than the cache holds -- and own generators for the rest; 52-bit proofs (26 rings) and an extra_commit among them"""
+    rng = np.random.default_rng({"shared": 11, "distinct": 12, "mixed": 13}[kind])
+    n = 1 << 14
+    if kind == "shared":
+        gens = np.tile(_gen(ref, rng), (n, 1))
+        engine.cache_generator(gens[0])
+    elif kind == "distinct":
+        gens = np.stack([_gen(ref, rng) for _ in range(n)])
+    else:
+        pool = np.stack([_gen(ref, rng) for _ in range(5)] + [np.frombuffer(GENERATOR_H, np.uint8)])
+        gens = pool[rng.integers(0, 6, n)]
+        own = rng.random(n) < 0.2
+        gens[own] = np.stack([_gen(ref, rng) for _ in range(int(own.sum()))])
+        engine.cache_generator(pool[0]); engine.cache_generator(pool[1])
+    h = n // 2
+    c1, p1, _, _ = ref.make_rangeproofs(h, rng, min_bits=64, gens64=gens[:h], threads=16)
+    c2, p2, _, _ = ref.make_rangeproofs(n - h, rng, min_bits=52, gens64=gens[h:], threads=16)
+    commits = np.concatenate([c1, c2]); proofs = p1 + p2
+    for i in range(0, n, 41):
+        q = bytearray(proofs[i]); q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8)); proofs[i] = bytes(q)
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(commits, proofs, gens, threads=16)
+    res, mn, mx = engine.rangeproof_verify_batch(commits, proofs, gens)
+    assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
+    assert e_res.sum() == n - len(range(0, n, 41))

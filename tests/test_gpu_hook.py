@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def hk(engine):
     if not os.path.exists(hookapi.HOOKED_PATH):
-        pytest.skip("oracle/_ref/libsecp256k1_hooked.so not built")
+        pytest.fail("-m gpu needs oracle/_ref/libsecp256k1_hooked.so (make -C oracle hooked)")
     h = hookapi.Hooked()
     yield h
     h.set_backend()
