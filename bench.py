@@ -35,14 +35,19 @@ MAD32_PEAK_ARCH = 3.93e13
 HBM_PEAK_GBS = 8000.0
 
 
-def make_inputs(n, seed):
-    """n 64-bit proofs (exp 0, min_value 0, generator H), signed with the reference when oracle/_ref is available
-    (as src/bench_rangeproof.c:26-36 does), otherwise tiled from the committed golden 64-bit vector."""
+def make_inputs(n, seed, distinct_generators=False):
+    """n 64-bit proofs (exp 0, min_value 0), signed with the reference when oracle/_ref is available (as src/bench_rangeproof.c:26-36
+    does), otherwise tiled from the committed golden 64-bit vector.  Generator: secp256k1_generator_h for every proof (what
+    bench_rangeproof uses), or -- distinct_generators -- a different random curve point per proof (the Elements case: every
+    confidential output carries its own blinded asset generator)."""
     rng = np.random.default_rng(seed)
     try:
         from tests.refapi import Ref
         ref = Ref()
-        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=min(usable_cores() * 2, 64))
+        gens_in = None
+        if distinct_generators:
+            gens_in = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(n)])
+        commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, gens64=gens_in, threads=min(usable_cores() * 2, 64))
         return commits, proofs, gens, "synthetic (secp256k1_rangeproof_sign via oracle/_ref, %d unique 64-bit proofs)" % n, ref
     except OSError:
         from tests.refapi import GENERATOR_H
@@ -90,6 +95,74 @@ def cpu_baseline_port(commits, proofs, gens):
     return {"value": kn / dt, "unit": "verifies/s", "cores": cores, "kind": "port", "sample": "%d 64-bit proofs on %d threads (%.2f s), oracle/zkp_oracle.c" % (kn, cores, dt)}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _usable_cpu_list():
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    return cpus[:usable_cores()]
+
+
+def _run_ref_bench(binary, args, iters, cpu=None, timeout=300):
+    """one run of a reference bench program (oracle/_ref/, built by `make -C oracle benches` from the reference's src/bench_*.c) ->
+    {name: (min, avg, max)} in microseconds per iteration as src/bench.h:78-111 prints them"""
+    import subprocess
+    cmd = [binary] + list(args)
+    if cpu is not None:
+        cmd = ["taskset", "-c", str(cpu)] + cmd
+    env = dict(os.environ, SECP256K1_BENCH_ITERS=str(iters))
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout).stdout
+    res = {}
+    for line in out.splitlines():
+        parts = [x.strip() for x in line.split(",")]
+        if len(parts) == 4:
+            try:
+                res[parts[0]] = tuple(float(x) for x in parts[1:])
+            except ValueError:
+                pass
+    return res
+
+
+def cpu_baseline_ref_benches():
+    """The CPU column from the reference's OWN benchmark programs on this box's host cores:
+    bench_rangeproof (as shipped: min_bits = 32, and the min_bits = 64 variant BASELINE's metric names), one process and one
+    taskset-pinned process per usable core; bench_ecmult pippenger_wnaf, one process.  None when the binaries did not travel."""
+    import concurrent.futures
+    d = os.path.join(ROOT, "oracle", "_ref")
+    b64, b32, bec = (os.path.join(d, x) for x in ("bench_rangeproof_64", "bench_rangeproof", "bench_ecmult"))
+    if not all(os.path.exists(x) and os.access(x, os.X_OK) for x in (b64, b32, bec)):
+        return None
+    out = {"cpu_model": cpu_model(), "cores": usable_cores(), "hardware_threads": os.cpu_count()}
+    iters = 12                                  # verifications per repetition (x 10 repetitions, src/bench.h): ~0.6 s per process
+    r32 = _run_ref_bench(b32, [], iters).get("rangeproof_verify_bit")
+    r64 = _run_ref_bench(b64, [], iters).get("rangeproof_verify_bit")
+    if not r32 or not r64:
+        return None
+    out["bench_rangeproof"] = {"min_bits": 32, "us_per_bit_min_avg_max": r32, "verifies_per_s_one_process": 1e6 / (32 * r32[1])}
+    out["bench_rangeproof_64"] = {"min_bits": 64, "us_per_bit_min_avg_max": r64, "verifies_per_s_one_process": 1e6 / (64 * r64[1])}
+    cpus = _usable_cpu_list()
+    t = time.time()
+    with concurrent.futures.ThreadPoolExecutor(len(cpus)) as ex:
+        rs = list(ex.map(lambda c: _run_ref_bench(b64, [], 3 * iters, cpu=c).get("rangeproof_verify_bit"), cpus))
+    wall = time.time() - t
+    rs = [r for r in rs if r]
+    out["bench_rangeproof_64_all_cores"] = {"processes": len(rs), "pinned_to": cpus, "wall_s": wall,
+                                            "verifies_per_s": sum(1e6 / (64 * r[1]) for r in rs),
+                                            "us_per_bit_avg_min_max_over_processes": (min(r[1] for r in rs), max(r[1] for r in rs))}
+    ec = _run_ref_bench(bec, ["pippenger_wnaf"], 400)
+    big = ec.get("ecmult_multi_32767p_g")
+    if big:
+        out["bench_ecmult_pippenger_32767p_g"] = {"us_per_point_min_avg_max": big, "mpoint_scalar_per_s": 1.0 / big[1]}
+    return out
+
+
 def cpu_baseline(ref, commits, proofs, gens):
     """the reference's secp256k1_rangeproof_verify on host cores, bounded sample (~10-20 s of CPU work)."""
     if ref is None:
@@ -115,6 +188,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--no-distinct", action="store_true", help="skip the second timed loop (every proof its own generator)")
     args = ap.parse_args()
 
     import torch
@@ -190,6 +264,33 @@ def main():
     assert all_ok, "a valid proof was rejected"
     assert int(d_max.min().item()) == -1          # max_value == 2^64-1 for every 64-bit proof
 
+    # The same batch size with a DIFFERENT generator for every proof (the Elements case: one blinded asset generator per confidential
+    # output).  No fixed-base generator table applies there (secp256k1_zkp_amd.h, s2k_engine_cache_generator), so every ring takes the
+    # general form of the rings kernel: reported next to the headline so that the shared-generator figure cannot be misread.
+    distinct = None
+    if not args.no_distinct and ref is not None:
+        c2, p2, g2, _, _ = make_inputs(n, seed=4321 + rank, distinct_generators=True)
+        pd2, po2 = Engine.pack(p2)
+        d_c2 = torch.tensor(c2).to(dev); d_g2 = torch.tensor(np.ascontiguousarray(g2)).to(dev)
+        d_p2 = torch.tensor(np.concatenate([pd2, np.zeros(64, np.uint8)])).to(dev); d_o2 = torch.tensor(po2.astype(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        for _ in range(max(1, args.warmup)):
+            eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_c2, d_p2, d_o2, d_g2, n, stream=stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0d = time.perf_counter()
+        for _ in range(args.steps):
+            eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_c2, d_p2, d_o2, d_g2, n, stream=stream)
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t0d
+        if world > 1:
+            tmax = torch.tensor([dtd], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dtd = float(tmax.item())
+        assert bool(d_res.all().item()), "a valid proof (own generator) was rejected"
+        distinct = {"value": world * n * args.steps / dtd, "ms_per_step": dtd / args.steps * 1e3}
+        del d_c2, d_g2, d_p2, d_o2
+
     # secondary figure of the BASELINE metric: one 2^20-term MSM (config 5), terms sharded over the ranks, partial
     # Jacobian sums all-gathered as raw limbs (RCCL) and summed locally -- strong scaling, reported next to the headline.
     msm = None
@@ -260,40 +361,60 @@ def main():
         value = world * n * args.steps / dt
         kms = float(np.mean(kern_ms))
         achieved = PROOF_BYTES_ALGO * n / (kms * 1e-3) / 1e9
-        # memory-side traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the
-        # committed rocprofv3 measurement of this same command (profiles/, tools/profile_round.sh), scaled to this batch
-        traffic, traffic_src = None, None
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_rp_rings.json")))
-        if pmc:
-            pj = json.load(open(pmc[-1]))
+        # memory-side traffic and issued-instruction counters of the dominant kernel: PMC counters cannot be read from inside this process,
+        # so the figures are committed rocprofv3 passes of this same command (profiles/, tools/profile_round.sh) -- used ONLY when the file
+        # carries the sha256 of the library this process has loaded (the counters then belong to this binary); otherwise null + the reason
+        import hashlib
+        from secp256k1_zkp_amd import _native
+        lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()
+        traffic, traffic_src, issued = None, None, None
+        def _stamped(pattern):
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+                try:
+                    j = json.load(open(f))
+                except Exception:
+                    continue
+                if j.get("so_sha256") == lib_sha:
+                    return f, j
+            return None, None
+        f_pmc, pj = _stamped("*pmc_rp_rings.json")
+        if pj:
             traffic = pj["hbm_bytes_per_launch_raw"] * n / 16384.0
-            traffic_src = os.path.relpath(pmc[-1], ROOT)
-        # issued (not algorithmic) integer-MAC rate: SQ counter passes of this same command (tools/profile_counters.sh);
-        # SQ_INSTS_VALU_INT64 counts wave-level 64-bit integer instructions (v_mad_u64_u32 and the 64-bit shifts)
-        issued = None
-        sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json")))
-        if sq:
-            cj = json.load(open(sq[-1])).get("k_rp_rings", {})
+            traffic_src = os.path.relpath(f_pmc, ROOT)
+        else:
+            traffic_src = "no profiles/*pmc_rp_rings.json stamped with this library's sha256 (%s...): run tools/profile_round.sh on this build" % lib_sha[:12]
+        # issued (not algorithmic) integer-MAC rate: SQ counter passes of this same command; SQ_INSTS_VALU_INT64 counts wave-level 64-bit
+        # integer instructions (v_mad_u64_u32 and the 64-bit shifts)
+        f_sq, sj = _stamped("*sq_counters.json")
+        if sj:
+            kname = "k_rp_rings_shared" if "k_rp_rings_shared" in sj else "k_rp_rings"
+            cj = sj.get(kname, {})
             if "SQ_INSTS_VALU_INT64" in cj:
                 int64 = cj["SQ_INSTS_VALU_INT64"]["mean_per_launch"] * n / 16384.0; valu = cj["SQ_INSTS_VALU"]["mean_per_launch"] * n / 16384.0
-                issued = {"source": os.path.relpath(sq[-1], ROOT), "int64_wave_instructions_per_launch": int64, "valu_wave_instructions_per_launch": valu,
+                issued = {"source": os.path.relpath(f_sq, ROOT), "kernel": kname, "int64_wave_instructions_per_launch": int64, "valu_wave_instructions_per_launch": valu,
                           "int64_lane_ops_per_s": int64 * 64 / (kms * 1e-3), "frac_of_peak": int64 * 64 / (kms * 1e-3) / MAD32_PEAK,
-                          "note": "counter-backed issue rate of 64-bit integer VALU instructions (v_mad_u64_u32 + 64-bit shifts) in k_rp_rings, this run's kernel time"}
+                          "note": "counter-backed issue rate of 64-bit integer VALU instructions (v_mad_u64_u32 + 64-bit shifts) in the rings kernel, this run's kernel time"}
         mad_rate = 4 * MAC64_PER_PROOF * n / (kms * 1e-3)
         out = {
             "metric": "64-bit Borromean rangeproof verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit), 32x32->64 integer MAC", "data": data_desc,
+            # verified: every timed proof was signed by the reference (oracle/_ref) and accepted; false when the run fell back to a tiled golden proof
+            "verified": ref is not None,
+            "value_distinct_generators": distinct["value"] if distinct else None,
+            "ms_per_step_distinct_generators": distinct["ms_per_step"] if distinct else None,
+            "generators": "value: secp256k1_generator_h for every proof (src/bench_rangeproof.c), fixed-base table of that generator cached by the engine; "
+                          "value_distinct_generators: the same batch size, every proof its own random generator (no table applies: general form of the rings kernel)",
             "config": {"workload": "secp256k1_rangeproof_verify, batch of %d 64-bit proofs per GPU (exp=0, min_value=0, 32 rings x 4)" % n,
                        "batch_per_gpu": n, "sharding": "replicas (independent proofs, no collective)",
                        "calls_in_flight": ("K steps queued back to back, first stage of step k+1 on side streams under step k's ring kernel "
                                            "(S2K_OPT_RP_INPUTS_READY: inputs resident and untouched)") if os.environ.get("S2K_BENCH_PIPELINE", "0") != "0"
                                           else "same queueing, engine default: the first stage of a call waits for the call before it"},
             # the binding roofline of this path is the integer VALU: exact 256-bit modular arithmetic, no MFMA, ~0.05 % of HBM
-            "roofline": {"bound": "valu", "kernel": "k_rp_rings", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK / 1e12,
+            "roofline": {"bound": "valu", "kernel": "k_rp_rings_shared (+ k_rp_rings for wavefronts without a generator table)", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK / 1e12,
                          "unit": "T lane-MAC/s (v_mad_u64_u32, 32x32+64)", "frac": mad_rate / MAD32_PEAK, "frac_of_architectural_peak": mad_rate / MAD32_PEAK_ARCH,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, incl. Infinity-Cache hits)", "traffic_source": traffic_src,
-                         "kernel_ms": kms, "issued": issued,
+                         "kernel_ms": kms, "issued": issued, "library_sha256": lib_sha,
                          "note": "achieved = algorithmic 6.6e6 MAC64/proof (reference schedule, SURVEY 8d) x 4 v_mad_u64_u32 x proofs / kernel time (HIP events on the launch stream); "
                                  "peak measured with >= 10 ms launches (tools/ubench/issue_model.hip, profiles/r02a_issue_model.txt)"},
             "hbm_roofline": {"bound": "hbm", "kernel": "k_rp_rings", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -302,9 +423,28 @@ def main():
         if msm:
             out["msm"] = msm
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(ref, commits, proofs, gens)
-            if cb:
-                out["cpu_baseline"] = cb
+            # (1) the reference's own bench programs (src/bench_rangeproof.c with min_bits = 64, src/bench_ecmult.c; timer of src/bench.h),
+            #     one process and one taskset-pinned process per usable core; (2) the same functions through the oracle/_ref shim with
+            #     OpenMP, on THIS run's proofs, as a cross-check of (1)
+            shim = cpu_baseline(ref, commits, proofs, gens)
+            rb = cpu_baseline_ref_benches()
+            if rb:
+                ac = rb["bench_rangeproof_64_all_cores"]
+                out["cpu_baseline"] = {"value": ac["verifies_per_s"], "unit": "verifies/s", "cores": ac["processes"], "kind": "reference",
+                                       "cpu_model": rb["cpu_model"], "hardware_threads": rb["hardware_threads"],
+                                       "per_core": rb["bench_rangeproof_64"]["verifies_per_s_one_process"],
+                                       "sample": "the reference's bench_rangeproof (src/bench_rangeproof.c, min_bits = 64, SECP256K1_BENCH_ITERS=36 x 10 repetitions), "
+                                                 "%d processes pinned with taskset to the usable cores, avg column of src/bench.h: %.0f verifies/s in all; one process: %.1f /s "
+                                                 "(%.1f us per bit); as shipped (min_bits = 32): %.1f us per bit"
+                                                 % (ac["processes"], ac["verifies_per_s"], rb["bench_rangeproof_64"]["verifies_per_s_one_process"],
+                                                    rb["bench_rangeproof_64"]["us_per_bit_min_avg_max"][1], rb["bench_rangeproof"]["us_per_bit_min_avg_max"][1]),
+                                       "bench_programs": rb, "shim_cross_check": shim}
+                if msm and "bench_ecmult_pippenger_32767p_g" in rb:
+                    msm.setdefault("cpu_baseline", {})["bench_ecmult"] = rb["bench_ecmult_pippenger_32767p_g"]
+            elif shim:
+                if ref is None:
+                    shim["kind"] = "port"
+                out["cpu_baseline"] = shim
         print(json.dumps(out))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -66,15 +66,19 @@ S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
 #define S2K_PTAB_NG (S2K_PTAB_ZISO + 9)
 #define S2K_PTAB_WORDS (2 * S2K_PTAB_TABLE_WORDS + 32)    // two tables (the second one only in the split form below) + parked factors
 
+// A parked entry is 27 words (x, y, third); WS = distance between its consecutive words: 1 for an entry that lies in one piece in the
+// lane's own slice, 64 for the wave-interleaved parking area of the ring form (word k of the 64 lanes of a wavefront side by side, so
+// that one store / load instruction moves 256 contiguous bytes instead of touching 64 different lines).
+template <int WS = 1>
 S2K_HD void ptab_store_raw(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) { e[i] = x.n[i]; e[9 + i] = y.n[i]; e[18 + i] = third.n[i]; }
+    for (int i = 0; i < 9; i++) { e[i * WS] = x.n[i]; e[(9 + i) * WS] = y.n[i]; e[(18 + i) * WS] = third.n[i]; }
 }
 // Table construction in two passes.  ptab_build_raw: the odd multiples by co-Z additions of 2A, each entry parked as (x, y, z-ratio of
 // its step) limbs; returns the Z all of them will share once rescaled (the Z of the last entry).  ptab_rescale: brings every entry to the Z of the last one times `zs0`
 // (secp256k1_ge_table_set_globalz, group_impl.h:289-320) and packs it as canonical words with its beta*x twin.  zs0 = 1 for a
 // single table; with two tables each is rescaled by the OTHER one's Z so that all sixteen entries share one Z (ecmult_lane_split).
-template <int N>
+template <int N, int WS = 1, int ES = S2K_PTAB_ENTRY_WORDS>
 S2K_HD void ptab_build_raw_n(fe& ziso, u32* tab, const gej& A) {
     // 2A by the usual doubling, whose intermediates also give A itself at the Z of 2A for free: Z(2A) = Y Z, so A rescaled by Y is
     // (X Y^2, Y^4) = (-T, S^2).  From then on every odd multiple is a CO-Z addition of 2A (both operands share Z: 5M + 2S instead of the
@@ -90,7 +94,7 @@ S2K_HD void ptab_build_raw_n(fe& ziso, u32* tab, const gej& A) {
     fe_add2(w, qx, t);
     fe_mul(qy, l, w); fe_add(qy, s2); fe_neg(qy, qy, 2); fe_norm_weak(qy);     // Y(2A) = -(L (X3 + T) + S^2)      (1)
     fe_neg(px, t, 1); py = s2;                             // A at the Z of 2A                      (2, 1)
-    { fe one; fe_set_int(one, 1); ptab_store_raw(tab, px, py, one); }
+    { fe one; fe_set_int(one, 1); ptab_store_raw<WS>(tab, px, py, one); }
     for (int i = 1; i < N; i++) {
         fe dx, dy, c, d, w1, w2, e, a1, x3, y3, tmp;
         fe_neg(dx, px, 4); fe_add(dx, qx); fe_norm_weak(dx);              // X(2A) - X(P): also Z(sum) / Z(operands)
@@ -104,7 +108,7 @@ S2K_HD void ptab_build_raw_n(fe& ziso, u32* tab, const gej& A) {
         fe_mul2(a1, qy, e, y3, dy, tmp);                                  // (1*3, 1*6)
         fe_neg(tmp, a1, 1); fe_add(y3, tmp);                              // Y(P + 2A)                   (3)
         fe_mul(zc, zc, dx);
-        ptab_store_raw(tab + i * S2K_PTAB_ENTRY_WORDS, x3, y3, dx);       // third slot: z ratio of this step
+        ptab_store_raw<WS>(tab + i * ES, x3, y3, dx);                      // third slot: z ratio of this step
         px = x3; py = y3; qx = w1; qy = a1;                               // 2A rescaled to the new Z
     }
     ziso = zc;
@@ -113,7 +117,7 @@ S2K_HD void ptab_build_raw(fe& ziso, u32* tab, const gej& A) { ptab_build_raw_n<
 // N parked entries at `tab` (one per S2K_PTAB_ENTRY_WORDS slot) -> N finished 64-byte sectors at fin + i * fin_stride.  fin == tab with
 // fin_stride == S2K_PTAB_ENTRY_WORDS is the in-place form (a finished sector overwrites the head of its own parked entry, which has
 // been taken over into registers by then).
-template <int N>
+template <int N, int WS = 1, int ES = S2K_PTAB_ENTRY_WORDS>
 S2K_HD void ptab_rescale_n(u32* tab, u32* fin, int fin_stride, const fe* zs0) {
     fe zs; if (zs0) zs = *zs0; else fe_set_int(zs, 1);
     // The parked entry of step i-1 is requested before the arithmetic of step i and taken over after it (the first use of the loaded
@@ -123,15 +127,15 @@ S2K_HD void ptab_rescale_n(u32* tab, u32* fin, int fin_stride, const fe* zs0) {
     u32 nraw[27];
     fe x, y, h;
 #pragma unroll
-    for (int k = 0; k < 27; k++) nraw[k] = tab[(N - 1) * S2K_PTAB_ENTRY_WORDS + k];
+    for (int k = 0; k < 27; k++) nraw[k] = tab[(N - 1) * ES + k * WS];
 #pragma unroll
     for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
     for (int i = N - 1; i >= 0; i--) {
-        const u32* er = tab + i * S2K_PTAB_ENTRY_WORDS;
+        const u32* er = tab + i * ES;
         u32* e = fin + i * fin_stride;
         if (i > 0) {
 #pragma unroll
-            for (int k = 0; k < 27; k++) nraw[k] = er[k - S2K_PTAB_ENTRY_WORDS];
+            for (int k = 0; k < 27; k++) nraw[k] = er[k * WS - ES];
         }
         if (zs0 || i != N - 1) {
             fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
@@ -543,8 +547,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 //   * + S2K_GTAB_WINDOWS additions from H's table on the steps with j > 0.
 // Per ring: 1 chain + 2 tables + 4 x (65 doublings + 56 additions) + 77 table additions, against 4 x (64 doublings + 68 + 11 additions
 // + 2 tables + a chain quarter + 2 key updates) for ecmult_lane_split.
-// Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches), the
-// parked entries of the construction (which is also where a fall-back to ecmult_lane keeps ITS tables: S2K_PTAB_WORDS fit), the Z factor.
+// Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches) and the Z
+// factor; the parked entries of the construction live in a per-wavefront, lane-interleaved area (S2K_RRAW_WAVE_WORDS).
 // Digit stream in LDS (S2K_RING_DIG_WORDS words per lane): words 0..8 = 5-bit digit (pos * 4 + stream), six per word; 9..16 = s; 17..24 = f.
 // Only the lock-step form exists (every lane of the wavefront works: the caller gives idle lanes a dummy point and dummy scalars);
 // ecmult_ring_step returns 0, having produced nothing, when a lane met an operand with its own x coordinate, and the caller then takes
@@ -555,19 +559,25 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #define S2K_RING_ADDS_P (4 * (S2K_RING_DIGITS + 1))
 #define S2K_RING_DIG_WORDS 25
 #define S2K_RTAB_TABLE_WORDS (S2K_RING_ENTRIES * 16)
-#define S2K_RTAB_RAW (2 * S2K_RTAB_TABLE_WORDS)
-#define S2K_RTAB_RAW_WORDS (2 * S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS)
-#define S2K_RTAB_ZISO (S2K_RTAB_RAW + S2K_RTAB_RAW_WORDS)
-#define S2K_RTAB_WORDS (S2K_RTAB_ZISO + 32)
+#define S2K_RTAB_ZISO (2 * S2K_RTAB_TABLE_WORDS)
+#define S2K_RTAB_WORDS (S2K_RTAB_ZISO + 16)                     /* per lane: 32 finished sectors + the Z factor */
+// parking area of the construction: per WAVEFRONT, word k of parked entry e of the 64 lanes at ((e * 27 + k) * 64 + lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define S2K_RAW_WS 64
+#else
+#define S2K_RAW_WS 1
+#endif
+#define S2K_RAW_ES (27 * S2K_RAW_WS)
+#define S2K_RRAW_WAVE_WORDS (2 * S2K_RING_ENTRIES * 27 * 64)
 
-// C, T = 2^64*C finite, magnitudes <= (5,3,1)
-S2K_HD void ecmult_ring_tables(u32* rtab, const gej& C, const gej& T) {
+// C, T = 2^64*C finite, magnitudes <= (5,3,1).  rtab: this lane's S2K_RTAB_WORDS; raw: this lane's column of its wavefront's parking area
+S2K_HD void ecmult_ring_tables(u32* rtab, u32* raw, const gej& C, const gej& T) {
     fe za, zt, ziso;
-    u32* const raw = rtab + S2K_RTAB_RAW;
-    ptab_build_raw_n<S2K_RING_ENTRIES>(za, raw, C);
-    ptab_build_raw_n<S2K_RING_ENTRIES>(zt, raw + S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS, T);
-    ptab_rescale_n<S2K_RING_ENTRIES>(raw, rtab, 16, &zt);
-    ptab_rescale_n<S2K_RING_ENTRIES>(raw + S2K_RING_ENTRIES * S2K_PTAB_ENTRY_WORDS, rtab + S2K_RTAB_TABLE_WORDS, 16, &za);
+    u32* const raw_t = raw + S2K_RING_ENTRIES * S2K_RAW_ES;
+    ptab_build_raw_n<S2K_RING_ENTRIES, S2K_RAW_WS, S2K_RAW_ES>(za, raw, C);
+    ptab_build_raw_n<S2K_RING_ENTRIES, S2K_RAW_WS, S2K_RAW_ES>(zt, raw_t, T);
+    ptab_rescale_n<S2K_RING_ENTRIES, S2K_RAW_WS, S2K_RAW_ES>(raw, rtab, 16, &zt);
+    ptab_rescale_n<S2K_RING_ENTRIES, S2K_RAW_WS, S2K_RAW_ES>(raw_t, rtab + S2K_RTAB_TABLE_WORDS, 16, &za);
     fe_mul(ziso, za, zt);
 #pragma unroll
     for (int i = 0; i < 9; i++) rtab[S2K_RTAB_ZISO + i] = ziso.n[i];
@@ -576,6 +586,7 @@ S2K_HD void ecmult_ring_tables(u32* rtab, const gej& C, const gej& T) {
 S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scalar& s, const scalar& f, int has_f, const u32* gtab, const u32* htab,
                             const s2k_lds_ptr dig) {
     u32 sneg = 0;
+    S2K_PROF_DECL;
     {
         half_scalar h0, h1; sc_split_lambda_odd(h0, h1, e);
         piece65 pc[4]; sc_split_pieces(pc, h0, h1);
@@ -599,6 +610,7 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
 #pragma unroll
         for (int i = 0; i < 8; i++) { dig[(9 + i) * S2K_DIG_STRIDE] = s.d[i]; dig[(17 + i) * S2K_DIG_STRIDE] = f.d[i]; }
     }
+    S2K_PROF_MARK(1);
     const int a_g0 = S2K_RING_ADDS_P, a_h0 = a_g0 + S2K_GTAB_WINDOWS;
     const int a_end = has_f ? a_h0 + S2K_GTAB_WINDOWS : a_h0;
     auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
@@ -639,8 +651,10 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
     int au = 0;
     while (au < a_g0) {
         if (au >= 4 && !(au & 3)) {
+            S2K_PROF_MARK(7);
 #pragma unroll 1
             for (int k = 0; k < S2K_RING_W; k++) gej_double_lean(R, R);
+            S2K_PROF_MARK(6);
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];                  // request the next record before the arithmetic
@@ -655,6 +669,7 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
         op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
     }
+    S2K_PROF_MARK(7);
     {   // back to the real curve
         fe zi;
 #pragma unroll
@@ -672,6 +687,7 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
         op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
     }
+    S2K_PROF_MARK(10);
 #ifdef S2K_ON_RING_STEP_DONE
     S2K_ON_RING_STEP_DONE();
 #endif

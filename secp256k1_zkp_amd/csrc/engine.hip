@@ -75,6 +75,7 @@ struct s2k_engine {
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
     hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
     hipEvent_t ev_msm_fork, ev_msm_join;   // the MSM's gated exact path runs on the side stream, next to the bucket pipeline
+    int rp_stagger;            // diagnostic ($S2K_RP_STAGGER): workgroups of the shared-form rings kernel start out of phase
     int rp_inputs_ready;       // S2K_OPT_RP_INPUTS_READY: the side-stream stage need not wait for earlier work of the caller's stream
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
@@ -87,7 +88,7 @@ struct s2k_engine {
     // k_rp_header matches a proof's generator against; gen_seen counts the proofs met per uncached generator (host-buffer calls count
     // directly, `_dev` calls through the device mailbox gen_mbox / its pinned copy) and a generator is built once it reaches gen_min.
     struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; } gen[RP_GEN_SLOTS];
-    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty;
+    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty; int gen_scanned;
     unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
     rp_gen_mbox* gen_mbox;     // device
     rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
@@ -118,10 +119,11 @@ static int engine_ptab(s2k_engine* e, size_t lanes) {
     e->ptab_lanes = lanes;
     return 1;
 }
-// the arena for `lanes` callers of the ring form (S2K_RTAB_WORDS per lane), in units of engine_ptab
+// the arena for `lanes` callers of the ring form (S2K_RTAB_WORDS per lane, then S2K_RRAW_WAVE_WORDS per wavefront), in units of engine_ptab
 static int engine_rtab(s2k_engine* e, size_t lanes) {
     lanes = (lanes + 255) & ~size_t(255);
-    return engine_ptab(e, (lanes * S2K_RTAB_WORDS + S2K_PTAB_WORDS - 1) / S2K_PTAB_WORDS);
+    const size_t words = lanes * S2K_RTAB_WORDS + (lanes / 64) * S2K_RRAW_WAVE_WORDS;
+    return engine_ptab(e, std::max(lanes, (words + S2K_PTAB_WORDS - 1) / S2K_PTAB_WORDS));
 }
 // Upper bound on lanes per launch: keeps the per-lane table arena at 1.2 GB however large the batch is; bigger
 // batches run as several launches over sub-ranges (same stream, so the order of results is unaffected).
@@ -304,7 +306,7 @@ static void gen_cache_service(s2k_engine* e, hipStream_t st) {
     if (e->mbox_pending && hipEventQuery(e->ev_mbox) == hipSuccess) {
         e->mbox_pending = 0;
         for (int m = 0; m < RP_GEN_MBOX; m++) {
-            if (e->gen_mbox_host->state[m] != 2u || !e->gen_mbox_host->count[m]) continue;
+            if (!e->gen_mbox_host->tag[m] || !e->gen_mbox_host->count[m]) continue;
             const unsigned char* key = e->gen_mbox_host->key[m];
             if (gen_cache_find(e, key) >= 0) continue;
             if (gen_note_seen(e, key, e->gen_mbox_host->count[m]) && gen_cache_build(e, st, key) >= 0) gen_forget_seen(e, key);
@@ -337,8 +339,11 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
+    e->rp_stagger = 0;
+    if (const char* sg = getenv("S2K_RP_STAGGER")) e->rp_stagger = atoi(sg) & 255;
+    if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_stagger |= atoi(sg) << 8;       // diagnostic launches (rp_ring_shared's dbg bits): results are meaningless
     for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; }
-    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0;
+    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0; e->gen_scanned = 0;
     e->gen_keys = nullptr; e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
     if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); e->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
     if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) e->gen_min = (size_t)strtoull(gm, nullptr, 10);
@@ -582,9 +587,20 @@ k_rp_sum(rp_ws ws, size_t n) {
 #ifndef S2K_RINGS_WAVES
 #define S2K_RINGS_WAVES 2
 #endif
+// K3 comes as two kernels over the same grid (1 lane / ring, lane t = proof t >> 5, ring t & 31):
+//   k_rp_rings_shared  the shared-generator form (rangeproof.h: rp_ring_shared) for every wavefront all of whose working lanes have a cached
+//                      table for their proof's generator (lanes may name different slots); a wavefront it does not serve -- no table, or
+//                      a suspect ring -- raises its word of `todo`;
+//   k_rp_rings         the general form; with `todo` it only works on the wavefronts flagged there (the others leave at once).
+// Two kernels rather than one with both bodies: each gets its own register allocation (the combined kernel spilled 325 VGPRs) and the
+// hot loops of one form do not share the instruction cache with the other's.
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split,
-           rp_gen_dev gc) {
+k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev,
+                  rp_gen_dev gc, u32* __restrict__ todo, u32 stagger) {
+    if (stagger & 255u) {                                                    // diagnostic: start the workgroups out of phase
+        const u32 d = ((blockIdx.x * 2654435761u) >> 26) * (stagger & 255u);
+        for (u32 i = 0; i < d; i++) __builtin_amdgcn_s_sleep(127);
+    }
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t p = t >> 5; const u32 ring = (u32)(t & 31);
     int live = p < n;
@@ -592,20 +608,31 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
     const rp_rec& rec = ws.rec[p];
     live &= (ring < rec.rings);
     __shared__ u32 s_dig[S2K_RING_DIG_WORDS * 256];
-    u32* const lane_tab = ptab + t * S2K_RTAB_WORDS;
-    // Shared-generator form when every working lane of the wavefront has a cached table for its proof's generator (lanes may name
-    // different slots); otherwise -- or when that form hands the wavefront back (a suspect ring) -- the general form below.
-    if (gc.valid) {
-        const int idle = !(live && rec.ok);
-        const u32 slot = idle ? gc.any : rec.gslot;
-        if (S2K_WAVE_ALL(slot < RP_GEN_SLOTS) && S2K_WAVE_ANY(!idle)) {
-            const u32 sl = slot < RP_GEN_SLOTS ? slot : gc.any;
-            if (rp_ring_shared(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-                               ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab,
-                               gc.tab[sl], gc.xmul[sl], lane_tab, S2K_LANE_DIG(s_dig), ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr)) return;
-        }
+    const int idle = !(live && rec.ok);
+    const u32 slot = idle ? gc.any : rec.gslot;
+    int served = 0;
+    if (!S2K_WAVE_ANY(!idle)) served = 1;                                  // nothing to do for this wavefront in either form
+    else if (S2K_WAVE_ALL(slot < RP_GEN_SLOTS)) {
+        const u32 sl = slot < RP_GEN_SLOTS ? slot : gc.any;
+        served = rp_ring_shared(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
+                                ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab,
+                                gc.tab[sl], gc.xmul[sl], ptab + t * S2K_RTAB_WORDS,
+                                ptab + (size_t)gridDim.x * 256 * S2K_RTAB_WORDS + (t >> 6) * S2K_RRAW_WAVE_WORDS + (t & 63), S2K_LANE_DIG(s_dig), ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr, stagger >> 8);
     }
-    const lane_mem lm{lane_tab, S2K_LANE_DIG(s_dig)};
+    if ((threadIdx.x & 63) == 0) todo[t >> 6] = served ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split,
+           const u32* __restrict__ todo) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (todo && !S2K_UNIFORM(todo[t >> 6])) return;
+    size_t p = t >> 5; const u32 ring = (u32)(t & 31);
+    int live = p < n;
+    if (!live) p = 0;
+    const rp_rec& rec = ws.rec[p];
+    live &= (ring < rec.rings);
+    __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
+    const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
             ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab, lm, ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr,
             split ? ws.dbases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (const u32*)nullptr, split ? ws.tcur + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (u32*)nullptr);
@@ -677,10 +704,11 @@ k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_v
 }
 
 static size_t rp_ws_bytes(size_t n) {
-    return ws_need({n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4,
+    return ws_need({(n * RP_MAX_RINGS / 64 + 8) * 4, n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4,
                     n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_RING_OUT_BYTES, n * RP_MAX_RINGS});
 }
 static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
+    w.todo = c.take<u32>(n * RP_MAX_RINGS / 64 + 8);
     w.rec = c.take<rp_rec>(n);
     w.bases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.pub0 = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
@@ -717,6 +745,8 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     if (!engine_rtab(e, nw * RP_MAX_RINGS)) return 0;
     gen_cache_service(e, st);
     const rp_gen_dev gc = gen_dev_view(e);
+    const int count_misses = e->gen_slots > 0 && !e->gen_scanned;      // (a host-buffer call has counted its generators already)
+    e->gen_scanned = 0;
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
     const hipStream_t sp = e->stream_pre;
@@ -730,7 +760,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         // ---- side streams
         if (e->rp_done_valid[slot]) HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_done[slot], 0));
         hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, sp, w, min_value + p0, max_value + p0, proofs, proof_off + p0, gens64 + 64 * p0,
-                           gc, e->gen_slots > 0 ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
+                           gc, count_misses ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
         HIPCHK(hipEventRecord(e->ev_rp_fork[slot], sp));
         HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_rp_fork[slot], 0));
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
@@ -753,7 +783,9 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         HIPCHK(hipStreamWaitEvent(st, e->ev_rp_pre[slot], 0));
         const unsigned rq = e->ring_seq & 31u;
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[2], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][0], st)); }
-        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split, gc);
+        if (gc.valid) hipLaunchKernelGGL(k_rp_rings_shared, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, gc, w.todo, (u32)e->rp_stagger);
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split,
+                           gc.valid ? (const u32*)w.todo : (const u32*)nullptr);
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
         if (rewind) {
@@ -778,6 +810,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
 // the launch, so such a batch takes the shared-generator form from its first call.
 static void gen_cache_scan_host(s2k_engine* e, hipStream_t st, const unsigned char* gens64, size_t n) {
     if (e->gen_slots <= 0) return;
+    e->gen_scanned = 1;
     std::vector<std::pair<const unsigned char*, size_t>> distinct;
     for (size_t i = 0; i < n; i++) {
         const unsigned char* g = gens64 + 64 * i;

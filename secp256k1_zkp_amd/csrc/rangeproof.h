@@ -48,6 +48,7 @@ struct rp_ws {           // device pointers into the engine workspace
     unsigned char* lift_ok;   // [n][32]
     unsigned char* ring_out;  // [n][RP_RING_OUT_BYTES]: the rings' 33-byte outputs back to back, then room for m
     unsigned char* ring_ok;   // [n][32]
+    u32* todo;                // [n * 32 / 64] one word per wavefront of the rings launch: 1 = the general form still has to do it
 };
 
 S2K_HD void gej_store28_h(u32* p, const gej& a) {
@@ -406,8 +407,11 @@ struct rp_gen_dev {                       // by value to the kernels: the cache 
     u32 valid;                            // bit i: slot i holds a table
     u32 any;                              // index of some valid slot (idle lanes read its x-table)
 };
-// generators that had no table: the first few distinct ones of a call with the number of proofs that carried them
-struct rp_gen_mbox { u32 state[RP_GEN_MBOX]; u32 count[RP_GEN_MBOX]; unsigned char key[RP_GEN_MBOX][64]; };
+// generators that had no table: the first few distinct ones of a call with the number of proofs that carried them.  A slot is claimed
+// by a 64-bit tag of the generator bytes (one compare-and-swap; lanes with the same generator then only count), so nothing on the
+// device ever waits for another lane's key bytes -- the host reads those after the kernel.  Two generators with the same tag would
+// share a count: harmless, the count only decides whether a table is worth building.
+struct rp_gen_mbox { unsigned long long tag[RP_GEN_MBOX]; u32 count[RP_GEN_MBOX]; unsigned char key[RP_GEN_MBOX][64]; };
 S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
     u32 slot = RP_GSLOT_NONE;
     for (u32 i = 0; i < RP_GEN_SLOTS; i++) {
@@ -420,22 +424,13 @@ S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
 }
 #if defined(__HIPCC__) || defined(__HIP__)
 __device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64) {
+    unsigned long long h = 0xCBF29CE484222325ull;
+    for (int k = 0; k < 64; k++) { h ^= gen64[k]; h *= 0x100000001B3ull; }
+    if (!h) h = 1;
     for (int m = 0; m < RP_GEN_MBOX; m++) {
-        u32 st = atomicAdd(&mb->state[m], 0u);
-        if (st == 0u && atomicCAS(&mb->state[m], 0u, 1u) == 0u) {
-            for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k];
-            mb->count[m] = 1u;
-            __threadfence();
-            atomicExch(&mb->state[m], 2u);
-            return;
-        }
-        if (st == 1u) continue;                       // being written by another lane: this proof goes uncounted
-        st = atomicAdd(&mb->state[m], 0u);
-        if (st == 2u) {
-            int same = 1;
-            for (int k = 0; k < 64; k++) same &= (mb->key[m][k] == gen64[k]);
-            if (same) { atomicAdd(&mb->count[m], 1u); return; }
-        }
+        const unsigned long long old = atomicCAS(&mb->tag[m], 0ull, h);
+        if (old == 0ull) { for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k]; }
+        if (old == 0ull || old == h) { atomicAdd(&mb->count[m], 1u); return; }
     }
 }
 #endif
@@ -449,7 +444,7 @@ __device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsign
 //   * it rejects a key that is the point at infinity (borromean_impl.h:78): P_j = inf <=> C = -j*B, impossible for an honest prover but
 //     a choice an adversarial one has.  `xmul` holds the affine x of j*(4^ring 10^exp)*H for j = 1..3 (a per-generator table, see
 //     RP_XMUL_*): a ring whose C has one of these x coordinates is `suspect` and the caller takes the whole wavefront through rp_ring;
-//   * exceptional additions inside a step (an operand with the accumulator's own x): that step is redone through ecmult_lane on P_j.
+//   * exceptional additions inside a step (an operand with the accumulator's own x): the ring is handed back as well.
 // Idle lanes (a proof that failed earlier, a ring beyond the proof's count, a step beyond the ring's size, a zero or overflowing
 // scalar) ride along on a dummy point / dummy scalars so that the wavefront stays in lock step; their results are discarded.
 #define RP_XMUL_EXPS 19
@@ -474,11 +469,12 @@ S2K_HD int rp_ring_suspect(const gej& C, const u32* xmul /* this (exp, ring)'s 3
     }
     return hit;
 }
-// Returns 0 without having written anything when the wavefront has to take rp_ring instead (a suspect ring).
-// pub28: C with Z = 1 (rp_lift; rp_sum brings the last key to affine when asked to).  rtab: this lane's S2K_RTAB_WORDS of HBM.
-S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* base28, const u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
-                          const unsigned char* proof, u32 ring, int live, const u32* gtab, const u32* htab, const u32* xmul, u32* rtab,
-                          const s2k_lds_ptr dig, u32* ev_out = nullptr) {
+// Returns 0 without having written any result when the wavefront has to take rp_ring instead (a suspect ring, an exceptional addition).
+// pub28: C with Z = 1 (rp_lift; rp_sum brings the last key to affine).  rtab: this lane's S2K_RTAB_WORDS of HBM; raw: its column of the
+// wavefront's parking area (ecmult.h, S2K_RRAW_WAVE_WORDS).
+S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
+                          const unsigned char* proof, u32 ring, int live, const u32* gtab, const u32* htab, const u32* xmul, u32* rtab, u32* raw,
+                          const s2k_lds_ptr dig, u32* ev_out = nullptr, u32 dbg = 0) {
     const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
     int ok = live & (int)rec.ok;
     const int exp = ok ? (int)((rec.hdr >> 8) & 0xFFu) - 1 : 0;
@@ -510,12 +506,14 @@ S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* base28, const u32* pub28
     S2K_PROF_DECL;
     {
         gej T = C;
+        // dbg (diagnostic launches only, $S2K_RP_DEBUG; results are then meaningless): bit 0 = no chain, bit 1 = no tables, bit 2 = no steps
 #pragma unroll 1
-        for (int k = 0; k < 64; k++) gej_double_lean(T, T);
+        for (int k = 0; k < ((dbg & 1u) ? 0 : 64); k++) gej_double_lean(T, T);
         fe_norm_weak(T.y);
         S2K_PROF_MARK(11);
-        ecmult_ring_tables(rtab, C, T);
+        if (!(dbg & 2u)) ecmult_ring_tables(rtab, raw, C, T);
         S2K_PROF_MARK(8);
+        if (dbg & 4u) { if (live) *ring_ok = (unsigned char)(T.x.n[0] & 1u); return 1; }
     }
     scalar cring; rp_ring_const(cring, exp < 0 ? 0 : exp, ring);
     // dummy scalars of idle lanes / idle steps (any fixed nonzero values)
@@ -540,16 +538,9 @@ S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* base28, const u32* pub28
         }
         gej R;
         S2K_PROF_MARK(0);
-        const int done = ecmult_ring_step(R, rtab, ens, s, f, j > 0, gtab, htab, dig);
-        if (!S2K_WAVE_ALL(done)) {
-            // an exceptional addition somewhere in the wavefront: this step through the general multiplication, on the key itself
-            gej P = C, B; gej_load28_h(B, base28);
-            for (u32 t = 0; t < j; t++) { gej n2; gej_add_var(n2, P, B); P = n2; }
-            scalar e2 = ens, s2 = s;
-            if (!good | P.inf) { sc_set_zero(e2); sc_set_zero(s2); good = 0; }
-            const lane_mem lm{rtab + S2K_RTAB_RAW, dig};
-            ecmult_lane(R, P, e2, s2, 1, gtab, lm);
-        }
+        // an exceptional addition somewhere in the wavefront (an operand with the accumulator's own x: adversarial inputs only): the whole
+        // ring goes back to the caller, i.e. to the general form, which starts it over on the keys themselves
+        if (!S2K_WAVE_ALL(ecmult_ring_step(R, rtab, ens, s, f, j > 0, gtab, htab, dig))) return 0;
         S2K_PROF_RESET;
         good &= !R.inf;
         ge a; ge_set_gej(a, R);

@@ -192,7 +192,7 @@ static void htab_host(const unsigned char* gen64) {
 }
 int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
                                  const unsigned char* extra, size_t extra_len, const unsigned char* gen64, int* fast_rings) {
-    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0), rtab(S2K_RTAB_WORDS, 0);
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0), rtab(S2K_RTAB_WORDS, 0), rraw(2 * S2K_RING_ENTRIES * 27, 0);
     unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
     u64 mn, mx;
     htab_host(gen64);
@@ -205,8 +205,8 @@ int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long lo
     for (u32 i = 0; i < 32; i++) {
         const int live = i < rec.rings;
         int did = 0;
-        if (live && rec.ok) did = rp_ring_shared(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_htab.data(),
-                                                 g_xmul.data(), rtab.data(), dig);
+        if (live && rec.ok) did = rp_ring_shared(rec, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_htab.data(),
+                                                 g_xmul.data(), rtab.data(), rraw.data(), dig);
         if (did) fast++;
         else rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_lm, nullptr,
                      dbases.data() + 28 * i, tcur.data() + 28 * i);

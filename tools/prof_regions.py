@@ -31,8 +31,12 @@ v = np.array(list(buf), dtype=np.float64)
 names = ["step prologue (key load, next key, T update)", "ecmult: split + digits", "ecmult_lane only: table build", "ecmult_lane only: main loop rest", "to-affine (inversion)",
          "hash + bookkeeping", "main loop: 4 lean doublings", "main loop: lean addition + operand decode/locate", "split: 2 x co-Z table construction",
          "split: 2 x table rescale", "split: generator additions + leaving the isomorphic curve", "ring: 2^64 * key chain (64 doublings)"]
+if os.environ.get("S2K_GEN_CACHE", "") != "0":        # the shared-generator form of the kernel (rp_ring_shared / ecmult_ring_step) uses the slots like this
+    names = ["step prologue (scalars, f_j)", "ring step: split + digits", "-", "-", "to-affine (inversion)", "hash + bookkeeping", "ring step: 5 lean doublings",
+             "ring step: lean additions + operand decode/locate (variable point)", "ring: two 16-entry tables (construction + rescale)", "-",
+             "ring step: G and H table additions + leaving the isomorphic curve", "ring: 2^64 * C chain (64 doublings)"]
 tot = v[:12].sum()
 steps = n * 32 * 4 / 64
-out = {names[i]: {"wave_cycles": v[i], "share": round(v[i] / tot, 4), "cycles_per_wave_step": round(v[i] / steps)} for i in range(12)}
+out = {("%d: " % i) + names[i]: {"wave_cycles": v[i], "share": round(v[i] / tot, 4), "cycles_per_wave_step": round(v[i] / steps)} for i in range(12)}
 out["steps"] = steps
 print(json.dumps(out, indent=1))

@@ -1,6 +1,6 @@
 # One round's evidence on the GPU box: rocprofv3 kernel stats, HBM-side traffic (separate --pmc passes), SQ issue counters
 # (separate --pmc passes), the plain default bench line, secondary throughputs and the MSM size sweep.
-#   usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...   (copy the summaries to profiles/<tag>_*)
+#   usage: S2K_GIT_HEAD=<commit> bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...   (copy the summaries to profiles/<tag>_*)
 set -x
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
@@ -19,8 +19,14 @@ done
 cd $R
 cp $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats.csv
 python - "$TAG" <<'PY'
-import csv, glob, json, collections, sys
+import csv, glob, json, collections, sys, hashlib, subprocess
 tag = sys.argv[1]
+# every file written below is stamped with the commit and the sha256 of the library that produced the counters; bench.py quotes
+# traffic / issued figures only from a file whose stamp matches the library it has loaded
+so_sha = hashlib.sha256(open("secp256k1_zkp_amd/libsecp256k1_zkp_amd.so", "rb").read()).hexdigest()
+import os
+head = os.environ.get("S2K_GIT_HEAD", "unknown")      # the GPU box has no .git: pass it in,  S2K_GIT_HEAD=$(git rev-parse HEAD) bash tools/profile_round.sh <tag>
+stamp = {"so_sha256": so_sha, "git_head": head}
 def collect(pattern, prefix="k_"):
     out = {}
     for f in glob.glob(pattern, recursive=True):
@@ -35,16 +41,17 @@ def collect(pattern, prefix="k_"):
             if k.startswith(prefix) and k in out: out[k]["kernel_ns_under_profiler"] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
     return out
 mem = collect("gpurun_out/%s/pmc_*/**/*counter_collection.csv" % tag)
-rr = mem.get("k_rp_rings", {})
-if "FETCH_SIZE" in rr and "WRITE_SIZE" in rr:
-    f, w = rr["FETCH_SIZE"]["mean_per_launch"], rr["WRITE_SIZE"]["mean_per_launch"]
-    json.dump({"kernel": "k_rp_rings", "FETCH_SIZE_kb_per_launch": f, "WRITE_SIZE_kb_per_launch": w, "hbm_bytes_per_launch_raw": (f + w) * 1024,
+rings = [k for k in ("k_rp_rings_shared", "k_rp_rings") if k in mem and "FETCH_SIZE" in mem[k] and "WRITE_SIZE" in mem[k]]
+if rings:
+    # both rings kernels run per launch group (the general one only exits where the shared-generator form served the wavefront): their sum
+    f = sum(mem[k]["FETCH_SIZE"]["mean_per_launch"] for k in rings); w = sum(mem[k]["WRITE_SIZE"]["mean_per_launch"] for k in rings)
+    json.dump({**stamp, "kernel": " + ".join(rings), "FETCH_SIZE_kb_per_launch": f, "WRITE_SIZE_kb_per_launch": w, "hbm_bytes_per_launch_raw": (f + w) * 1024,
                "hbm_bytes_per_launch_fetch_x2": (2 * f + w) * 1024,
                "note": "separate --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE can read half of a wide stream on gfx950 -> the x2 figure is the upper bound); counters include Infinity-Cache hits; batch of 16384 proofs"},
               open("gpurun_out/%s/pmc_rp_rings.json" % tag, "w"), indent=1)
 sq = collect("gpurun_out/%s/sq*/**/*counter_collection.csv" % tag)
-json.dump(sq, open("gpurun_out/%s/sq_counters.json" % tag, "w"), indent=1)
-r = sq.get("k_rp_rings", {})
+json.dump({**stamp, **sq}, open("gpurun_out/%s/sq_counters.json" % tag, "w"), indent=1)
+r = sq.get("k_rp_rings_shared", sq.get("k_rp_rings", {}))
 if "GRBM_GUI_ACTIVE" in r and "kernel_ns_under_profiler" in r:
     print("effective clock GHz:", r["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 / r["kernel_ns_under_profiler"]["mean_per_launch"])
 print(json.dumps(r, indent=1)[:2500])
