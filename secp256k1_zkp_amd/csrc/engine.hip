@@ -611,8 +611,9 @@ k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint
     const int idle = !(live && rec.ok);
     const u32 slot = idle ? gc.any : rec.gslot;
     int served = 0;
+    const int part = S2K_WAVE_ANY(!idle) && S2K_WAVE_ALL(slot < RP_GEN_SLOTS);
     if (!S2K_WAVE_ANY(!idle)) served = 1;                                  // nothing to do for this wavefront in either form
-    else if (S2K_WAVE_ALL(slot < RP_GEN_SLOTS)) {
+    else if (part) {
         const u32 sl = slot < RP_GEN_SLOTS ? slot : gc.any;
         served = rp_ring_shared(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
                                 ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab,

@@ -542,8 +542,7 @@ S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* pub28, unsigned char* ri
         // ring goes back to the caller, i.e. to the general form, which starts it over on the keys themselves
         if (!S2K_WAVE_ALL(ecmult_ring_step(R, rtab, ens, s, f, j > 0, gtab, htab, dig))) return 0;
         S2K_PROF_RESET;
-        good &= !R.inf;
-        ge a; ge_set_gej(a, R);
+        ge a; ge_set_gej(a, R);                   // (R is finite here: every addition of the step had operands with different x)
         S2K_PROF_MARK(4);
         u32 xw[8]; fe_to_words(xw, a.x);
         u32 xb[8];
