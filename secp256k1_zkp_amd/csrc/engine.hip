@@ -75,7 +75,7 @@ struct s2k_engine {
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
     hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
     hipEvent_t ev_msm_fork, ev_msm_join;   // the MSM's gated exact path runs on the side stream, next to the bucket pipeline
-    int rp_stagger;            // diagnostic ($S2K_RP_STAGGER): workgroups of the shared-form rings kernel start out of phase
+    int rp_debug;              // diagnostic launches ($S2K_RP_DEBUG: rp_rings_shared's dbg bits; results are meaningless then)
     int rp_inputs_ready;       // S2K_OPT_RP_INPUTS_READY: the side-stream stage need not wait for earlier work of the caller's stream
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
@@ -119,11 +119,13 @@ static int engine_ptab(s2k_engine* e, size_t lanes) {
     e->ptab_lanes = lanes;
     return 1;
 }
-// the arena for `lanes` callers of the ring form (S2K_RTAB_WORDS per lane, then S2K_RRAW_WAVE_WORDS per wavefront), in units of engine_ptab
-static int engine_rtab(s2k_engine* e, size_t lanes) {
-    lanes = (lanes + 255) & ~size_t(255);
-    const size_t words = lanes * S2K_RTAB_WORDS + (lanes / 64) * S2K_RRAW_WAVE_WORDS;
-    return engine_ptab(e, std::max(lanes, (words + S2K_PTAB_WORDS - 1) / S2K_PTAB_WORDS));
+// the arena of the rings kernels for `rings` rings: the general form wants S2K_PTAB_WORDS per ring; the shared form, with S2K_RP_K rings per
+// lane, S2K_RTAB_WORDS per ring plus per wavefront of 64 lanes the construction's parking area and the lanes' point / challenge parking
+static int engine_rtab(s2k_engine* e, size_t rings) {
+    rings = (rings + 255) & ~size_t(255);
+    const size_t lanes = ((rings + S2K_RP_K - 1) / S2K_RP_K + 255) & ~size_t(255);
+    const size_t words = lanes * S2K_RP_K * S2K_RTAB_WORDS + (lanes / 64) * (S2K_RRAW_WAVE_WORDS + (size_t)S2K_RP_K * RP_PARK_WORDS * 64);
+    return engine_ptab(e, std::max(rings, (words + S2K_PTAB_WORDS - 1) / S2K_PTAB_WORDS));
 }
 // Upper bound on lanes per launch: keeps the per-lane table arena at 1.2 GB however large the batch is; bigger
 // batches run as several launches over sub-ranges (same stream, so the order of results is unaffected).
@@ -339,9 +341,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
-    e->rp_stagger = 0;
-    if (const char* sg = getenv("S2K_RP_STAGGER")) e->rp_stagger = atoi(sg) & 255;
-    if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_stagger |= atoi(sg) << 8;       // diagnostic launches (rp_ring_shared's dbg bits): results are meaningless
+    e->rp_debug = 0;
+    if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
     for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; }
     e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0; e->gen_scanned = 0;
     e->gen_keys = nullptr; e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
@@ -541,13 +542,14 @@ k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned c
             rp_gen_dev gc, rp_gen_mbox* mbox, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (p == 0) { ws.plan[0] = 0; ws.plan[1] = 0; }           // the work lists of K3 (k_rp_sum fills them)
     uint64_t mn, mx;
     rp_header(ws.rec[p], &mn, &mx, proofs + proof_off[p], proof_off[p + 1] - proof_off[p]);
     min_value[p] = mn; max_value[p] = mx;
     // which cached generator table (if any) serves this proof; a generator without one is reported for the host's build decision
     const u32 slot = rp_gen_lookup(gc, gens64 + 64 * p);
     ws.rec[p].gslot = slot;
-    if (slot == RP_GSLOT_NONE && mbox && (ws.rec[p].hdr & 1u)) rp_gen_report_miss(mbox, gens64 + 64 * p);
+    if (slot == RP_GSLOT_NONE && mbox && (ws.rec[p].hdr & 1u)) rp_gen_report_miss(mbox, gens64 + 64 * p, p, n);
 }
 // three waves per 64 proofs: wave 0 commitment + min_value*H, wave 1 generator flag + message hash, wave 2 ring bases
 __global__ void __launch_bounds__(192)
@@ -578,60 +580,80 @@ k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size
     if (!(rec.hdr & 1u) || ring + 1 >= rec.rings) return;          // needs the header only: runs next to k_rp_prologue
     rp_lift(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring);
 }
+// K2 also writes the work lists of stage K3 (the rings kernels never look at a proof that needs no ring work, and no lane idles on a ring
+// beyond a proof's count -- a 52-bit proof has 26 rings, a 32-bit one 16):
+//   mapF[i] = proof | group << 20   groups of S2K_RP_K consecutive rings of the proofs whose generator has a cached table (shared form)
+//   mapG[i] = proof | ring << 20    the single rings of all other proofs that passed the earlier stages (general form)
+//   plan[0], plan[1] = the two list lengths (zeroed by k_rp_header).  One atomic per wavefront reserves its proofs' entries; the order of
+//   the lists is irrelevant.  The shared-form kernel appends to mapG what it hands back.
 __global__ void __launch_bounds__(64)
-k_rp_sum(rp_ws ws, size_t n) {
+k_rp_sum(rp_ws ws, u32 gen_valid, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    rp_sum(ws.rec[p], ws.pub0 + p * RP_MAX_RINGS * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS);
+    u32 cF = 0, cG = 0, rings = 0;
+    if (p < n) {
+        rp_sum(ws.rec[p], ws.pub0 + p * RP_MAX_RINGS * RP_GEJ_WORDS, ws.lift_ok + p * RP_MAX_RINGS);
+        const rp_rec& rec = ws.rec[p];
+        if (rec.ok) {
+            rings = rec.rings;
+            const int fast = gen_valid && rec.gslot < RP_GEN_SLOTS && ((gen_valid >> rec.gslot) & 1u);
+            if (fast) cF = (rings + S2K_RP_K - 1) / S2K_RP_K; else cG = rings;
+        }
+    }
+    u32 pf = cF, pg = cG;                                    // inclusive prefix sums over the wavefront (the workgroup is one wavefront)
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 a = __shfl_up(pf, d), b = __shfl_up(pg, d);
+        if ((int)threadIdx.x >= d) { pf += a; pg += b; }
+    }
+    u32 baseF = 0, baseG = 0;
+    if (threadIdx.x == 63) { baseF = pf ? atomicAdd(&ws.plan[0], pf) : 0u; baseG = pg ? atomicAdd(&ws.plan[1], pg) : 0u; }
+    baseF = __shfl(baseF, 63); baseG = __shfl(baseG, 63);
+    u32 oF = baseF + pf - cF, oG = baseG + pg - cG;
+    for (u32 g = 0; g < cF; g++) ws.mapF[oF + g] = (u32)p | (g << 20);
+    for (u32 r = 0; r < cG; r++) ws.mapG[oG + r] = (u32)p | (r << 20);
 }
 #ifndef S2K_RINGS_WAVES
 #define S2K_RINGS_WAVES 2
 #endif
-// K3 comes as two kernels over the same grid (1 lane / ring, lane t = proof t >> 5, ring t & 31):
-//   k_rp_rings_shared  the shared-generator form (rangeproof.h: rp_ring_shared) for every wavefront all of whose working lanes have a cached
-//                      table for their proof's generator (lanes may name different slots); a wavefront it does not serve -- no table, or
-//                      a suspect ring -- raises its word of `todo`;
-//   k_rp_rings         the general form; with `todo` it only works on the wavefronts flagged there (the others leave at once).
+// K3 comes as two kernels:
+//   k_rp_rings_shared  the shared-generator form (rangeproof.h: rp_rings_shared): lane t takes group mapF[t] -- S2K_RP_K consecutive rings of a
+//                      proof whose generator has a cached fixed-base table; a wavefront that meets a suspect ring or an exceptional
+//                      addition (adversarial inputs only) appends its rings to mapG instead;
+//   k_rp_rings         the general form: lane t takes ring mapG[t].
 // Two kernels rather than one with both bodies: each gets its own register allocation (the combined kernel spilled 325 VGPRs) and the
 // hot loops of one form do not share the instruction cache with the other's.
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev,
-                  rp_gen_dev gc, u32* __restrict__ todo, u32 stagger) {
-    if (stagger & 255u) {                                                    // diagnostic: start the workgroups out of phase
-        const u32 d = ((blockIdx.x * 2654435761u) >> 26) * (stagger & 255u);
-        for (u32 i = 0; i < d; i++) __builtin_amdgcn_s_sleep(127);
-    }
+k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, u32* ev,
+                  rp_gen_dev gc, u32 dbg) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t p = t >> 5; const u32 ring = (u32)(t & 31);
-    int live = p < n;
-    if (!live) p = 0;
+    const u32 nF = ws.plan[0];
+    if ((t & ~size_t(63)) >= nF) return;
+    const int live = t < nF;
+    const u32 item = ws.mapF[live ? t : 0];
+    const size_t p = item & 0xFFFFFu; const u32 g = item >> 20;
     const rp_rec& rec = ws.rec[p];
-    live &= (ring < rec.rings);
     __shared__ u32 s_dig[S2K_RING_DIG_WORDS * 256];
-    const int idle = !(live && rec.ok);
-    const u32 slot = idle ? gc.any : rec.gslot;
-    int served = 0;
-    const int part = S2K_WAVE_ANY(!idle) && S2K_WAVE_ALL(slot < RP_GEN_SLOTS);
-    if (!S2K_WAVE_ANY(!idle)) served = 1;                                  // nothing to do for this wavefront in either form
-    else if (part) {
-        const u32 sl = slot < RP_GEN_SLOTS ? slot : gc.any;
-        served = rp_ring_shared(rec, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
-                                ws.ring_out + p * RP_RING_OUT_BYTES + ring * 33, ws.ring_ok + p * RP_MAX_RINGS + ring, proofs + proof_off[p], ring, live, gtab,
-                                gc.tab[sl], gc.xmul[sl], ptab + t * S2K_RTAB_WORDS,
-                                ptab + (size_t)gridDim.x * 256 * S2K_RTAB_WORDS + (t >> 6) * S2K_RRAW_WAVE_WORDS + (t & 63), S2K_LANE_DIG(s_dig), ev ? ev + (p * RP_MAX_RINGS + ring) * 32 : nullptr, stagger >> 8);
+    const u32 sl = rec.gslot < RP_GEN_SLOTS ? rec.gslot : gc.any;
+    const size_t lanes = (size_t)gridDim.x * 256, wave = t >> 6, lane = t & 63;
+    u32* const raw0 = ptab + lanes * S2K_RP_K * S2K_RTAB_WORDS;
+    const rp_shared_mem M{ptab + t * S2K_RP_K * S2K_RTAB_WORDS, raw0 + wave * S2K_RRAW_WAVE_WORDS + lane,
+                          raw0 + (lanes >> 6) * S2K_RRAW_WAVE_WORDS + wave * (S2K_RP_K * RP_PARK_WORDS * 64) + lane, S2K_LANE_DIG(s_dig)};
+    const int served = rp_rings_shared<S2K_RP_K>(rec, ws.pub0 + (p * RP_MAX_RINGS + g * S2K_RP_K) * RP_GEJ_WORDS, ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS,
+                                                 proofs + proof_off[p], g * S2K_RP_K, live, gtab, gc.tab[sl], gc.xmul[sl], M, ev ? ev + p * (RP_MAX_RINGS * 32) : nullptr, dbg);
+    if (!served && live) {                          // (wavefront-uniform verdict) hand this lane's rings to the general form
+        const u32 r0 = g * S2K_RP_K, cnt = rec.rings - r0 < S2K_RP_K ? rec.rings - r0 : S2K_RP_K;
+        const u32 base = atomicAdd(&ws.plan[1], cnt);
+        for (u32 i = 0; i < cnt; i++) ws.mapG[base + i] = (u32)p | ((r0 + i) << 20);
     }
-    if ((threadIdx.x & 63) == 0) todo[t >> 6] = served ? 0u : 1u;
 }
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
-k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, size_t n, u32* ev, int split,
-           const u32* __restrict__ todo) {
+k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* __restrict__ proof_off, const u32* __restrict__ gtab, u32* __restrict__ ptab, u32* ev, int split) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (todo && !S2K_UNIFORM(todo[t >> 6])) return;
-    size_t p = t >> 5; const u32 ring = (u32)(t & 31);
-    int live = p < n;
-    if (!live) p = 0;
+    const u32 nG = ws.plan[1];
+    if ((t & ~size_t(63)) >= nG) return;
+    const int live = t < nG;
+    const u32 item = ws.mapG[live ? t : 0];
+    const size_t p = item & 0xFFFFFu; const u32 ring = item >> 20;
     const rp_rec& rec = ws.rec[p];
-    live &= (ring < rec.rings);
     __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
     const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
     rp_ring(rec, ws.bases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS, ws.pub0 + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS,
@@ -705,11 +727,11 @@ k_rp_rewind(rp_ws ws, rp_rewind_args ra, int32_t* results, const uint64_t* min_v
 }
 
 static size_t rp_ws_bytes(size_t n) {
-    return ws_need({(n * RP_MAX_RINGS / 64 + 8) * 4, n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4,
+    return ws_need({64, (n * RP_MAX_RINGS / S2K_RP_K + 64) * 4, (n * RP_MAX_RINGS + 64) * 4, n * sizeof(rp_rec), n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS * RP_GEJ_WORDS * 4,
                     n * RP_MAX_RINGS * RP_GEJ_WORDS * 4, n * RP_MAX_RINGS, n * RP_RING_OUT_BYTES, n * RP_MAX_RINGS});
 }
 static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
-    w.todo = c.take<u32>(n * RP_MAX_RINGS / 64 + 8);
+    w.plan = c.take<u32>(16); w.mapF = c.take<u32>(n * RP_MAX_RINGS / S2K_RP_K + 64); w.mapG = c.take<u32>(n * RP_MAX_RINGS + 64);
     w.rec = c.take<rp_rec>(n);
     w.bases = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
     w.pub0 = c.take<u32>(n * RP_MAX_RINGS * RP_GEJ_WORDS);
@@ -769,7 +791,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         hipLaunchKernelGGL(k_rp_prologue, dim3(b64), dim3(192), 0, sp, w, min_value + p0, commits33 + 33 * p0, proofs, proof_off + p0, extra,
                            extra_off ? extra_off + p0 : nullptr, gens64 + 64 * p0, m);
         HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_join[slot], 0));
-        hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, sp, w, m);
+        hipLaunchKernelGGL(k_rp_sum, dim3(b64), dim3(64), 0, sp, w, gc.valid, m);
         HIPCHK(hipEventRecord(e->ev_rp_pre[slot], sp));
         if (rewind) {
             // rewinding: the replay of the prover's random stream (serial per proof, ~1 500 SHA-256 compressions) only needs the header
@@ -784,9 +806,9 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         HIPCHK(hipStreamWaitEvent(st, e->ev_rp_pre[slot], 0));
         const unsigned rq = e->ring_seq & 31u;
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[2], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][0], st)); }
-        if (gc.valid) hipLaunchKernelGGL(k_rp_rings_shared, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, gc, w.todo, (u32)e->rp_stagger);
-        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, m, rewind ? rewind->ev : (u32*)nullptr, e->rp_split,
-                           gc.valid ? (const u32*)w.todo : (const u32*)nullptr);
+        if (gc.valid) hipLaunchKernelGGL(k_rp_rings_shared, dim3((unsigned)((m * (RP_MAX_RINGS / S2K_RP_K) + 255) / 256)), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab,
+                                         rewind ? rewind->ev : (u32*)nullptr, gc, (u32)e->rp_debug);
+        hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
         if (rewind) {

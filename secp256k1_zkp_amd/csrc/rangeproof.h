@@ -48,7 +48,9 @@ struct rp_ws {           // device pointers into the engine workspace
     unsigned char* lift_ok;   // [n][32]
     unsigned char* ring_out;  // [n][RP_RING_OUT_BYTES]: the rings' 33-byte outputs back to back, then room for m
     unsigned char* ring_ok;   // [n][32]
-    u32* todo;                // [n * 32 / 64] one word per wavefront of the rings launch: 1 = the general form still has to do it
+    u32* plan;                // work lists of K3 (k_rp_plan): [0] groups in mapF, [1] rings in mapG
+    u32* mapF;                // [n * 32 / K] proof | ring group << 20   (shared-generator form)
+    u32* mapG;                // [n * 32]     proof | ring << 20         (general form)
 };
 
 S2K_HD void gej_store28_h(u32* p, const gej& a) {
@@ -423,14 +425,22 @@ S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
     return slot;
 }
 #if defined(__HIPCC__) || defined(__HIP__)
-__device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64) {
+__device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64, size_t p, size_t n) {
+    // a batch in which every proof has its own generator makes every lane come here: a slot that is taken by another tag is skipped
+    // on a plain load (no atomic), and only every 16th proof counts, for the 16 proofs from itself on -- the count is a heuristic
     unsigned long long h = 0xCBF29CE484222325ull;
     for (int k = 0; k < 64; k++) { h ^= gen64[k]; h *= 0x100000001B3ull; }
     if (!h) h = 1;
     for (int m = 0; m < RP_GEN_MBOX; m++) {
-        const unsigned long long old = atomicCAS(&mb->tag[m], 0ull, h);
-        if (old == 0ull) { for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k]; }
-        if (old == 0ull || old == h) { atomicAdd(&mb->count[m], 1u); return; }
+        unsigned long long old = *(volatile unsigned long long*)&mb->tag[m];
+        if (old != 0ull && old != h) continue;
+        if (old == 0ull) {
+            old = atomicCAS(&mb->tag[m], 0ull, h);
+            if (old == 0ull) { for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k]; }
+            else if (old != h) continue;
+        }
+        if ((p & 15u) == 0) atomicAdd(&mb->count[m], (u32)(n - p < 16 ? n - p : 16));
+        return;
     }
 }
 #endif
@@ -469,103 +479,179 @@ S2K_HD int rp_ring_suspect(const gej& C, const u32* xmul /* this (exp, ring)'s 3
     }
     return hit;
 }
+// K rings per lane (consecutive rings ring0 .. ring0+K-1 of one proof).  Why several: every ring position ends in a field inversion
+// (to-affine before the point is hashed), ~19 000 instructions of the wavefront whatever its lanes hold, and the K points of a lane
+// share ONE inversion (Montgomery's trick, 3 (K - 1) products).  The K rings of a lane advance position by position: for each position
+// j the K multiplications run one after the other (one copy of the code, `q` loop), each result is parked (27 words), then one
+// inversion, then K x (affine, serialise, hash).  What a ring carries from one position to the next -- the challenge e and its ok
+// flag -- is parked next to the point.
+// Memory of a lane (rp_shared_mem): rtab = K x S2K_RTAB_WORDS of its own (finished tables); raw = its column of the wavefront's
+// table-construction parking area; park = its column of the wavefront's K x RP_PARK_WORDS area (word stride S2K_RAW_WS like raw).
 // Returns 0 without having written any result when the wavefront has to take rp_ring instead (a suspect ring, an exceptional addition).
-// pub28: C with Z = 1 (rp_lift; rp_sum brings the last key to affine).  rtab: this lane's S2K_RTAB_WORDS of HBM; raw: its column of the
-// wavefront's parking area (ecmult.h, S2K_RRAW_WAVE_WORDS).
-S2K_HD int rp_ring_shared(const rp_rec& rec, const u32* pub28, unsigned char* ring_out33, unsigned char* ring_ok,
-                          const unsigned char* proof, u32 ring, int live, const u32* gtab, const u32* htab, const u32* xmul, u32* rtab, u32* raw,
-                          const s2k_lds_ptr dig, u32* ev_out = nullptr, u32 dbg = 0) {
-    const u32 rsize = (ring + 1 == rec.rings) ? rec.last_rsize : 4u;
-    int ok = live & (int)rec.ok;
-    const int exp = ok ? (int)((rec.hdr >> 8) & 0xFFu) - 1 : 0;
-    gej C;
+// pub28: the key records of the proof's rings from ring0 on (Z = 1: rp_lift; rp_sum brings the last key to affine).
+#ifndef S2K_RP_K
+#define S2K_RP_K 1                      /* rings per lane in the engine's shared-generator kernel; K > 1 shares the inversion of a ring position between K
+                                           rings but keeps K times the tables alive: measured on MI355X 15.5 (K=1) / 15.75 (2) / 15.85 ms (4) per 2^14 proofs */
+#endif
+#define RP_PARK_WORDS 40                /* 0..26 point (x, y, z or 1/z), 27..34 challenge e, 35 ok, 36 good */
+struct rp_shared_mem { u32* rtab; u32* raw; u32* park; s2k_lds_ptr dig; };
+template <int K>
+S2K_HD int rp_rings_shared(const rp_rec& rec, const u32* pub28, unsigned char* ring_out /* the proof's */, unsigned char* ring_ok /* the proof's [32] */,
+                           const unsigned char* proof, u32 ring0, int live, const u32* gtab, const u32* htab, const u32* xmul, const rp_shared_mem& M,
+                           u32* ev_out = nullptr /* the proof's [32][32] */, u32 dbg = 0) {
+    const int pok = live & (int)rec.ok;
+    const int exp = pok ? (int)((rec.hdr >> 8) & 0xFFu) - 1 : 0;
+    const int e_idx = exp < 0 ? 0 : exp;
+    const u32 nrings = pok ? rec.rings : 0u;
+    auto pk = [&](int q, int k) -> u32& { return M.park[(size_t)(q * RP_PARK_WORDS + k) * S2K_RAW_WS]; };
+    // ---- a ring whose key collides with a multiple of its base goes back to the caller (with its whole wavefront) before any work is done
     {
-        gej_load28_h(C, pub28);
-        if (C.inf) ok = 0;
-        ge g; ge_set_generator(g);
-        if (!ok) gej_set_ge(C, g);                                       // idle lane: dummy point
-    }
-    {
-        const int e_idx = exp < 0 ? 0 : exp;
-        const int suspect = ok & rp_ring_suspect(C, xmul + ((size_t)e_idx * RP_MAX_RINGS + ring) * 24);
+        int suspect = 0;
+#pragma unroll 1
+        for (int q = 0; q < K; q++) {
+            const u32 ring = ring0 + q;
+            gej C; gej_load28_h(C, pub28 + RP_GEJ_WORDS * q);
+            const int ok = (ring < nrings) & !C.inf;
+            if (ok) suspect |= rp_ring_suspect(C, xmul + ((size_t)e_idx * RP_MAX_RINGS + ring) * 24);
+        }
         if (S2K_WAVE_ANY(suspect)) return 0;
     }
-    u32 e[8];
-    {
-        u32 m[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) m[i] = rec.m[i];
-        u32 e0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) {                                   // never touch proof bytes of a proof that failed its structural checks
-            const unsigned char* pe0 = proof + rec.off_e0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) e0[i] = s2k_load_be32(pe0 + 4 * i);
-        }
-        rp_hash_e0(e, e0, m, ring);
-    }
     S2K_PROF_DECL;
-    {
+    // ---- per ring: key (a dummy for an idle ring), first challenge, 2^64 chain, both tables
+#pragma unroll 1
+    for (int q = 0; q < K; q++) {
+        const u32 ring = ring0 + q;
+        gej C; gej_load28_h(C, pub28 + RP_GEJ_WORDS * q);
+        int ok = (ring < nrings) & !C.inf;
+        if (!ok) { ge g; ge_set_generator(g); gej_set_ge(C, g); }
+        u32 e[8];
+        {
+            u32 m[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+            u32 e0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) {                                   // never touch proof bytes of a proof that failed its structural checks
+                const unsigned char* pe0 = proof + rec.off_e0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) e0[i] = s2k_load_be32(pe0 + 4 * i);
+            }
+            rp_hash_e0(e, e0, m, ring);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) pk(q, 27 + i) = e[i];
+        pk(q, 35) = (u32)ok;
+        S2K_PROF_RESET;
         gej T = C;
         // dbg (diagnostic launches only, $S2K_RP_DEBUG; results are then meaningless): bit 0 = no chain, bit 1 = no tables, bit 2 = no steps
 #pragma unroll 1
         for (int k = 0; k < ((dbg & 1u) ? 0 : 64); k++) gej_double_lean(T, T);
         fe_norm_weak(T.y);
         S2K_PROF_MARK(11);
-        if (!(dbg & 2u)) ecmult_ring_tables(rtab, raw, C, T);
+        if (!(dbg & 2u)) ecmult_ring_tables(M.rtab + (size_t)q * S2K_RTAB_WORDS, M.raw, C, T);
         S2K_PROF_MARK(8);
-        if (dbg & 4u) { if (live) *ring_ok = (unsigned char)(T.x.n[0] & 1u); return 1; }
     }
-    scalar cring; rp_ring_const(cring, exp < 0 ? 0 : exp, ring);
-    // dummy scalars of idle lanes / idle steps (any fixed nonzero values)
+    if (dbg & 4u) return 1;
+    // dummy scalars of idle rings / idle positions (any fixed nonzero values)
     const scalar dummy_e = {{0x9E3779B9u, 0x7F4A7C15u, 0xF39CC060u, 0x5CEDC834u, 0x1082276Bu, 0xF3A27251u, 0xF86C6A11u, 0x0D5A2B4Fu}};
     const scalar dummy_s = {{0x2545F491u, 0x4F6CDD1Du, 0x6C078965u, 0x5851F42Du, 0x14057B7Eu, 0xF767814Fu, 0x9FB21C65u, 0x1E35A7BDu}};
-    u32 outx[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u32 outp = 0;
 #pragma unroll 1
     for (u32 j = 0; j < 4; j++) {
-        const int step_live = ok & (j < rsize);
-        scalar ens, s; int ov_e, ov_s = 0;
-        if (ev_out && live) { for (int i = 0; i < 8; i++) ev_out[8 * j + i] = e[i]; }
-        rp_words_to_scalar(ens, ov_e, e);
-        sc_set_zero(s);
-        if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);
-        int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens);
-        if (!good) { ens = dummy_e; s = dummy_s; }
-        scalar f; sc_set_zero(f);
-        if (j > 0) {
-            scalar k = cring;
-            for (u32 t = 1; t < j; t++) sc_add(k, k, cring);
-            sc_mul(f, ens, k); sc_negate(f, f);
+        // ---- the K multiplications of this position
+#pragma unroll 1
+        for (int q = 0; q < K; q++) {
+            const u32 ring = ring0 + q;
+            const u32 rsize = (ring + 1 == nrings) ? rec.last_rsize : 4u;
+            u32 e[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) e[i] = pk(q, 27 + i);
+            const int ok = (int)pk(q, 35);
+            const int step_live = ok & (j < rsize);
+            scalar ens, s; int ov_e, ov_s = 0;
+            if (ev_out && ok) { for (int i = 0; i < 8; i++) ev_out[(size_t)ring * 32 + 8 * j + i] = e[i]; }
+            rp_words_to_scalar(ens, ov_e, e);
+            sc_set_zero(s);
+            if (step_live) sc_set_b32(s, proof + rec.off_s + 32 * (4 * ring + j), &ov_s);
+            const int good = step_live & !ov_e & !ov_s & !sc_is_zero(s) & !sc_is_zero(ens);
+            if (!good) { ens = dummy_e; s = dummy_s; }
+            scalar f; sc_set_zero(f);
+            if (j > 0) {
+                scalar cring; rp_ring_const(cring, e_idx, ring);
+                scalar k = cring;
+                for (u32 t = 1; t < j; t++) sc_add(k, k, cring);
+                sc_mul(f, ens, k); sc_negate(f, f);
+            }
+            gej R;
+            S2K_PROF_MARK(0);
+            // an exceptional addition somewhere in the wavefront (an operand with the accumulator's own x: adversarial inputs only): everything
+            // goes back to the caller, i.e. to the general form, which starts the rings over on the keys themselves
+            if (!S2K_WAVE_ALL(ecmult_ring_step(R, M.rtab + (size_t)q * S2K_RTAB_WORDS, ens, s, f, j > 0, gtab, htab, M.dig))) return 0;
+            S2K_PROF_RESET;
+            fe_norm_weak(R.x); fe_norm_weak(R.y);
+#pragma unroll
+            for (int i = 0; i < 9; i++) { pk(q, i) = R.x.n[i]; pk(q, 9 + i) = R.y.n[i]; pk(q, 18 + i) = R.z.n[i]; }
+            pk(q, 36) = (u32)good;
         }
-        gej R;
-        S2K_PROF_MARK(0);
-        // an exceptional addition somewhere in the wavefront (an operand with the accumulator's own x: adversarial inputs only): the whole
-        // ring goes back to the caller, i.e. to the general form, which starts it over on the keys themselves
-        if (!S2K_WAVE_ALL(ecmult_ring_step(R, rtab, ens, s, f, j > 0, gtab, htab, dig))) return 0;
-        S2K_PROF_RESET;
-        ge a; ge_set_gej(a, R);                   // (R is finite here: every addition of the step had operands with different x)
+        // ---- one inversion for the K points (every R is finite here: all additions of the step had operands with different x)
+        {
+            fe pre[K], z;
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) z.n[i] = pk(q, 18 + i);
+                if (q == 0) pre[0] = z; else fe_mul(pre[q], pre[q - 1], z);
+            }
+            fe inv; fe_inv(inv, pre[K - 1]);
+#pragma unroll
+            for (int q = K - 1; q >= 1; q--) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) z.n[i] = pk(q, 18 + i);
+                fe zi; fe_mul2(zi, inv, pre[q - 1], inv, inv, z);          // 1/z_q ; inv <- 1/(z_0 .. z_{q-1})
+#pragma unroll
+                for (int i = 0; i < 9; i++) pk(q, 18 + i) = zi.n[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) pk(0, 18 + i) = inv.n[i];
+        }
         S2K_PROF_MARK(4);
-        u32 xw[8]; fe_to_words(xw, a.x);
-        u32 xb[8];
+        // ---- K x (affine, serialise, next challenge / ring output)
+#pragma unroll 1
+        for (int q = 0; q < K; q++) {
+            const u32 ring = ring0 + q;
+            const u32 rsize = (ring + 1 == nrings) ? rec.last_rsize : 4u;
+            ge a;
+            {
+                fe x, y, zi, zi2, zi3;
 #pragma unroll
-        for (int i = 0; i < 8; i++) xb[i] = xw[7 - i];
-        const u32 prefix = 2u | (u32)fe_is_odd(a.y);
-        if (step_live) ok &= good;
-        if (j + 1 < rsize) {
-            u32 m[8];
+                for (int i = 0; i < 9; i++) { x.n[i] = pk(q, i); y.n[i] = pk(q, 9 + i); zi.n[i] = pk(q, 18 + i); }
+                fe_sqr(zi2, zi); fe_mul(zi3, zi2, zi);
+                fe_mul2(a.x, x, zi2, a.y, y, zi3);
+                fe_normalize(a.x); fe_normalize(a.y);
+            }
+            int ok = (int)pk(q, 35);
+            const int good = (int)pk(q, 36);
+            const int step_live = ok & (j < rsize);
+            u32 xw[8]; fe_to_words(xw, a.x);
+            u32 xb[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) m[i] = rec.m[i];
-            rp_hash_step(e, prefix, xb, m, ring, j + 1);
-        } else if (j + 1 == rsize) {
+            for (int i = 0; i < 8; i++) xb[i] = xw[7 - i];
+            const u32 prefix = 2u | (u32)fe_is_odd(a.y);
+            if (step_live) ok &= good;
+            pk(q, 35) = (u32)ok;
+            if (j + 1 < rsize) {
+                u32 m[8], e[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) outx[i] = xb[i];
-            outp = prefix;
+                for (int i = 0; i < 8; i++) m[i] = rec.m[i];
+                rp_hash_step(e, prefix, xb, m, ring, j + 1);
+#pragma unroll
+                for (int i = 0; i < 8; i++) pk(q, 27 + i) = e[i];
+            } else if (j + 1 == rsize && ring < nrings) {
+                unsigned char* o = ring_out + 33 * ring;
+                o[0] = (unsigned char)prefix;
+                for (int i = 0; i < 8; i++) s2k_store_be32(o + 1 + 4 * i, xb[i]);
+            }
+            if (j == 3 && ring < nrings) ring_ok[ring] = (unsigned char)ok;
         }
         S2K_PROF_MARK(5);
-    }
-    if (live) {
-        ring_out33[0] = (unsigned char)outp;
-        for (int i = 0; i < 8; i++) s2k_store_be32(ring_out33 + 1 + 4 * i, outx[i]);
-        *ring_ok = (unsigned char)ok;
     }
     return 1;
 }

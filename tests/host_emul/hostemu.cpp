@@ -190,9 +190,32 @@ static void htab_host(const unsigned char* gen64) {
     }
     memcpy(g_hkey, gen64, 64); g_hkey_valid = 1;
 }
+}   // extern "C"
+template <int K>
+static int emu_rp_shared_k(rp_rec& rec, std::vector<u32>& bases, std::vector<u32>& pub0, std::vector<u32>& dbases, std::vector<u32>& tcur, unsigned char* ring_out, unsigned char* ring_ok,
+                           const unsigned char* proof) {
+    std::vector<u32> rtab((size_t)K * S2K_RTAB_WORDS, 0), rraw(2 * S2K_RING_ENTRIES * 27, 0), park((size_t)K * RP_PARK_WORDS, 0);
+    u32 dig[S2K_RING_DIG_WORDS];
+    int fast = 0;
+    for (u32 g = 0; g * K < 32; g++) {
+        const u32 r0 = g * K;
+        int did = 0;
+        if (rec.ok && r0 < rec.rings) {
+            const rp_shared_mem M{rtab.data(), rraw.data(), park.data(), dig};
+            did = rp_rings_shared<K>(rec, pub0.data() + 28 * r0, ring_out, ring_ok, proof, r0, 1, gtab_host(), g_htab.data(), g_xmul.data(), M);
+        }
+        if (did) { fast += (int)((rec.rings - r0 < (u32)K) ? rec.rings - r0 : (u32)K); continue; }
+        for (u32 i = r0; i < r0 + K; i++)
+            rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, nullptr,
+                    dbases.data() + 28 * i, tcur.data() + 28 * i);
+    }
+    return fast;
+}
+extern "C" {
+// rings_per_lane: 1, 2 or 4 (the engine's S2K_RP_K); *fast_rings = rings that completed in the shared-generator form
 int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
-                                 const unsigned char* extra, size_t extra_len, const unsigned char* gen64, int* fast_rings) {
-    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0), rtab(S2K_RTAB_WORDS, 0), rraw(2 * S2K_RING_ENTRIES * 27, 0);
+                                 const unsigned char* extra, size_t extra_len, const unsigned char* gen64, int* fast_rings, int rings_per_lane) {
+    rp_rec rec; std::vector<u32> bases(32 * 28, 0), pub0(32 * 28, 0), dbases(32 * 28, 0), tcur(32 * 28, 0);
     unsigned char lift_ok[32] = {0}, ring_out[RP_RING_OUT_BYTES] = {0}, ring_ok[32] = {0};
     u64 mn, mx;
     htab_host(gen64);
@@ -201,16 +224,9 @@ int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long lo
     if (rec.ok) for (u32 i = 0; i + 1 < rec.rings; i++) rp_lift(rec, pub0.data() + 28 * i, lift_ok + i, proof, i);
     rp_sum(rec, pub0.data(), lift_ok);
     int fast = 0;
-    u32 dig[S2K_RING_DIG_WORDS];
-    for (u32 i = 0; i < 32; i++) {
-        const int live = i < rec.rings;
-        int did = 0;
-        if (live && rec.ok) did = rp_ring_shared(rec, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_htab.data(),
-                                                 g_xmul.data(), rtab.data(), rraw.data(), dig);
-        if (did) fast++;
-        else rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, live, gtab_host(), g_lm, nullptr,
-                     dbases.data() + 28 * i, tcur.data() + 28 * i);
-    }
+    if (rings_per_lane == 4) fast = emu_rp_shared_k<4>(rec, bases, pub0, dbases, tcur, ring_out, ring_ok, proof);
+    else if (rings_per_lane == 2) fast = emu_rp_shared_k<2>(rec, bases, pub0, dbases, tcur, ring_out, ring_ok, proof);
+    else fast = emu_rp_shared_k<1>(rec, bases, pub0, dbases, tcur, ring_out, ring_ok, proof);
     if (fast_rings) *fast_rings = fast;
     return rp_final(rec, ring_out, ring_ok, proof);
 }

@@ -173,11 +173,16 @@ def test_emu_rangeproof(emu, ref):
             assert _emu_rp(emu, commits[0], p, gens[0]) == (rr[0], rmn[0], rmx[0])
 
 
-def _emu_rp_shared(emu, c, p, g, extra=b""):
-    mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0); fast = ctypes.c_int(0)
-    r = emu.emu_rangeproof_verify_shared(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)),
-                                         g.tobytes(), ctypes.byref(fast))
-    return (r, mn.value, mx.value), fast.value
+def _emu_rp_shared(emu, c, p, g, extra=b"", k=None):
+    """K3 in the shared-generator form with k rings per lane; k = None: 1, 2 and 4 must agree"""
+    outs = []
+    for kk in ((1, 2, 4) if k is None else (k,)):
+        mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0); fast = ctypes.c_int(0)
+        r = emu.emu_rangeproof_verify_shared(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)),
+                                             g.tobytes(), ctypes.byref(fast), ctypes.c_int(kk))
+        outs.append(((r, mn.value, mx.value), fast.value))
+    assert all(o[0] == outs[0][0] for o in outs), outs
+    return outs[0][0], min(o[1] for o in outs)
 
 
 def test_emu_rangeproof_shared_generator_form(emu, ref):
