@@ -542,10 +542,14 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 // the variable point is the same for all four steps of the ring, and the part that changes goes through a fixed-base table of H laid
 // out exactly like the one of G (gtable.h; the engine keeps a small cache of them keyed by the generator's 64 bytes).  What that buys:
 //   * the two odd-multiples tables (of C and of T = 2^64*C) and the 64-doubling chain are built ONCE per ring instead of once per step,
-//     so they can be twice as large: signed odd 5-bit digits, 16 entries per table, 14 additions per stream instead of 17;
+//     so they can be twice as large: signed odd 5-bit digits, 16 entries per table, 13 additions per stream instead of 17.
+//     (13, not 14: 13 digits d_i = 2 b_i - 31 represent every odd k with |k| < 2^65 -- sum d_i 32^i = 2B - (2^65 - 1), so b is read off
+//     B = (k - 1)/2 + 2^64: bit t of B is bit t + 1 of k and bit 64 is set, i.e. the top digit is 16 | (k >> 61) -- and the four 65-bit
+//     pieces of sc_split_pieces are odd and below 2^65.  ecmult_lane_split's 4-bit digits need a fixed 17th digit because 16 of them
+//     only reach 2^64.)  So a step is 12 x 5 doublings and 52 additions, the first of which just takes its operand;
 //   * no "key <- key + B", "T <- T + 2^64*B" updates between the steps;
 //   * + S2K_GTAB_WINDOWS additions from H's table on the steps with j > 0.
-// Per ring: 1 chain + 2 tables + 4 x (65 doublings + 56 additions) + 77 table additions, against 4 x (64 doublings + 68 + 11 additions
+// Per ring: 1 chain + 2 tables + 4 x (60 doublings + 52 additions) + 77 table additions, against 4 x (64 doublings + 68 + 11 additions
 // + 2 tables + a chain quarter + 2 key updates) for ecmult_lane_split.
 // Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches) and the Z
 // factor; the parked entries of the construction live in a per-wavefront, lane-interleaved area (S2K_RRAW_WAVE_WORDS).
@@ -555,8 +559,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 // that step through ecmult_lane on P_j itself.
 #define S2K_RING_W 5
 #define S2K_RING_ENTRIES 16
-#define S2K_RING_DIGITS 13                                      /* 13 x 5 bits above bit 0, + the fixed top digit: odd k < 2^66 */
-#define S2K_RING_ADDS_P (4 * (S2K_RING_DIGITS + 1))
+#define S2K_RING_DIGITS 13                                      /* 13 signed odd 5-bit digits: every odd |k| < 2^65, no extra top digit (below) */
+#define S2K_RING_ADDS_P (4 * S2K_RING_DIGITS)
 #define S2K_RING_DIG_WORDS 25
 #define S2K_RTAB_TABLE_WORDS (S2K_RING_ENTRIES * 16)
 #define S2K_RTAB_ZISO (2 * S2K_RTAB_TABLE_WORDS)
@@ -597,10 +601,11 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         for (int st = 0; st < 4; st++) {
             sneg |= (u32)pc[st].neg << st;
 #pragma unroll
-            for (int pos = 0; pos < S2K_RING_DIGITS; pos++) {            // pos 0 = most significant digit below the fixed top digit
+            for (int pos = 0; pos < S2K_RING_DIGITS; pos++) {            // pos 0 = most significant digit
                 const int i = S2K_RING_DIGITS - 1 - pos, bit = S2K_RING_W * i + 1, word = bit >> 5, sh = bit & 31;
                 const u64 pair = (u64)pc[st].w[word] | ((u64)(word + 1 < 3 ? pc[st].w[word + 1] : 0u) << 32);
-                const u32 v = (u32)(pair >> sh) & 31u;
+                u32 v = (u32)(pair >> sh) & 31u;
+                if (pos == 0) v |= 16u;                                  // bit 64 of B (the piece is below 2^65: bits 65, 66 are clear)
                 const int nib = pos * 4 + st;
                 dw[nib / 6] |= v << ((nib % 6) * 5);
             }
@@ -617,8 +622,7 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         addr = rtab; valid = 0; neg = 0;
         if (idx < a_g0) {
             const int st = idx & 3;
-            u32 v = 16u;                                                                    // the fixed top digit +1
-            if (idx >= 4) { const int nib = idx - 4; v = (dig[(nib / 6) * S2K_DIG_STRIDE] >> ((nib % 6) * 5)) & 31u; }
+            const u32 v = (dig[(idx / 6) * S2K_DIG_STRIDE] >> ((idx % 6) * 5)) & 31u;
             valid = 1;
             neg = (v < 16u) ^ (int)((sneg >> st) & 1u);
             const u32 en = (v < 16u) ? (15u - v) : (v - 16u);
@@ -647,7 +651,7 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
     for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
     op_decode(cur, raw, nxt_neg, 0);
     op_locate(nxt_addr, nxt_valid, nxt_neg, 1);
-    // variable part: additions 0..55 as 28 (plain stream, lambda stream) pairs, 5 doublings in front of every group of four but the first
+    // variable part: additions 0..51 as 26 (plain stream, lambda stream) pairs, 5 doublings in front of every group of four but the first
     int au = 0;
     while (au < a_g0) {
         if (au >= 4 && !(au & 3)) {
