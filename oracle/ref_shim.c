@@ -311,6 +311,48 @@ REF_EXPORT int ref_rangeproof_make_many(unsigned char *commits33, unsigned char 
     secp256k1_context_destroy(ctx);
     return ok;
 }
+/* the same two loops with an extra_commit per item (extra: n records of `estride` bytes, length elens[i]; Elements commits to the output's script there) */
+REF_EXPORT void ref_rangeproof_verify_many_extra(int *results, uint64_t *min_v, uint64_t *max_v, const unsigned char *commits33, const unsigned char *proofs,
+                                                 size_t stride, const size_t *plens, const unsigned char *extra, size_t estride, const size_t *elens,
+                                                 const unsigned char *gens64, size_t n, int threads) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    long i;
+    (void)threads;
+#ifdef _OPENMP
+    #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+#endif
+    for (i = 0; i < (long)n; i++) {
+        secp256k1_pedersen_commitment c; secp256k1_generator g;
+        results[i] = 0;
+        memcpy(g.data, gens64 + 64 * i, 64);
+        if (secp256k1_pedersen_commitment_parse(ctx, &c, commits33 + 33 * i)) {
+            results[i] = secp256k1_rangeproof_verify(ctx, &min_v[i], &max_v[i], &c, proofs + stride * i, plens[i], elens[i] ? extra + estride * i : NULL, elens[i], &g);
+        }
+    }
+    secp256k1_context_destroy(ctx);
+}
+REF_EXPORT int ref_rangeproof_make_many_extra(unsigned char *commits33, unsigned char *proofs, size_t stride, size_t *plens, const unsigned char *blinds32,
+                                              const uint64_t *values, const unsigned char *gens64, const unsigned char *extra, size_t estride, const size_t *elens,
+                                              uint64_t min_value, int exp, int min_bits, size_t n, int threads) {
+    secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
+    long i; int ok = 1;
+    (void)threads;
+#ifdef _OPENMP
+    #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+#endif
+    for (i = 0; i < (long)n; i++) {
+        secp256k1_pedersen_commitment c; secp256k1_generator g; size_t len = stride; unsigned char ser[33];
+        memcpy(g.data, gens64 + 64 * i, 64);
+        if (!secp256k1_pedersen_commit(ctx, &c, blinds32 + 32 * i, values[i], &g)) { ok = 0; continue; }
+        secp256k1_pedersen_commitment_serialize(ctx, ser, &c);
+        memcpy(commits33 + 33 * i, ser, 33);
+        if (!secp256k1_rangeproof_sign(ctx, proofs + stride * i, &len, min_value, &c, blinds32 + 32 * i, ser, exp, min_bits, values[i], NULL, 0,
+                                       elens[i] ? extra + estride * i : NULL, elens[i], &g)) { ok = 0; len = 0; }
+        plens[i] = len;
+    }
+    secp256k1_context_destroy(ctx);
+    return ok;
+}
 REF_EXPORT void ref_schnorrsig_verify_many(int *results, const unsigned char *sigs64, const unsigned char *msgs, size_t msglen, const unsigned char *pks32, size_t n, int threads) {
     secp256k1_context *ctx = secp256k1_context_create(SECP256K1_CONTEXT_NONE);
     long i;

@@ -226,7 +226,27 @@ def pedersen():
     print("pedersen tally:", len(cases), "vectors", [c["result"] for c in cases])
 
 
+def split_bounds():
+    """scalars_near_split_bounds (src/tests.c:4718-4739): the 20 scalars that reach the largest outputs of secp256k1_scalar_split_lambda,
+    (a*LAMBDA + (ORDER + b)/2) % ORDER for a in -2..2, b in -3, -1, 1, 3 -- the reference feeds them to ecmult in run_ecmult_near_split_bound"""
+    text = open(os.path.join(REF, "src", "tests.c")).read()
+    body = text[text.index("scalars_near_split_bounds[20] = {"):]
+    body = body[:body.index("};")]
+    vals = []
+    for m in re.finditer(r"SECP256K1_SCALAR_CONST\(([^)]*)\)", body):
+        words = [int(x, 16) for x in m.group(1).split(",")]
+        assert len(words) == 8
+        v = 0
+        for w in words:
+            v = (v << 32) | w
+        vals.append("%064x" % v)
+    assert len(vals) == 20
+    # (the values are taken as the array holds them; they are what the reference's run_ecmult_near_split_bound feeds to ecmult)
+    json.dump(dict(source="src/tests.c:4718-4739 scalars_near_split_bounds", scalars=vals), open(os.path.join(OUT, "split_bounds.json"), "w"), indent=0)
+    print("split bounds:", len(vals), "scalars")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at " + REF)
-    rangeproof(); bppp(); bip340(); surjection(); halfagg(); pedersen()
+    rangeproof(); bppp(); bip340(); surjection(); halfagg(); pedersen(); split_bounds()

@@ -121,6 +121,25 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         flag[i] = 2 * (S2K_WAVE_ALL(done) ? 1 : 0) + (R.inf ? 1 : 0);
         fe_normalize(r.x); fe_normalize(r.y); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
     } break;
+    case 40: {   // the ring form (ecmult.h: ecmult_ring_tables + ecmult_ring_step) as the rangeproof rings use it: R = e*A + s*G + f*G (the table of G
+                 // stands in for the generator's); a = points, b = (e || s || f) 96 bytes per item; flag = 2 * completed + infinity.  One wavefront
+                 // per 64 items (64-lane workgroups); scratch behind the flags: n * S2K_RTAB_WORDS, then one parking area per wavefront.
+        __shared__ u32 s_dig[S2K_RING_DIG_WORDS * 256];
+        ge p; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_norm_weak(p.x); fe_norm_weak(p.y);
+        gej A, T, R; gej_set_ge(A, p);
+        T = A; for (int k = 0; k < 64; k++) gej_double_lean(T, T);
+        fe_norm_weak(T.y);
+        scalar e, sg, f; sc_set_b32(e, b + 96 * i, nullptr); sc_set_b32(sg, b + 96 * i + 32, nullptr); sc_set_b32(f, b + 96 * i + 64, nullptr);
+        u32* const scratch = (u32*)flag + n;
+        u32* rtab = scratch + (size_t)i * S2K_RTAB_WORDS;
+        u32* raw = scratch + (size_t)n * S2K_RTAB_WORDS + (size_t)(i >> 6) * S2K_RRAW_WAVE_WORDS + (i & 63);
+        ecmult_ring_tables(rtab, raw, A, T);
+        const int done = S2K_WAVE_ALL(ecmult_ring_step(R, rtab, e, sg, f, 1, gtab, gtab, S2K_LANE_DIG(s_dig)));
+        ge r; fe_set_zero(r.x); fe_set_zero(r.y);
+        if (done) ge_set_gej(r, R);
+        flag[i] = 2 * done;
+        fe_normalize(r.x); fe_normalize(r.y); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
+    } break;
     case 37: {   // lean point operations (group.h) against the general ones: double, then add b, from an affine start
         ge p, q; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_set_b32_mod(q.x, b + 64 * i); fe_set_b32_mod(q.y, b + 64 * i + 32);
         gej j; gej_set_ge(j, p);

@@ -77,6 +77,45 @@ class Ref:
         plist = [proofs[i, :int(plens[i])].tobytes() for i in range(n)]
         return commits, plist, gens64, values
 
+    @staticmethod
+    def _pack_extra(extra, n):
+        estride = max(max((len(e) for e in extra), default=1), 1)
+        buf = np.zeros((n, estride), np.uint8)
+        for i, e in enumerate(extra):
+            buf[i, :len(e)] = np.frombuffer(e, np.uint8)
+        return buf, estride, np.array([len(e) for e in extra], np.uint64)
+
+    def make_rangeproofs_extra(self, n, rng, extra, min_bits=64, exp=0, min_value=0, gens64=None, threads=8):
+        """like make_rangeproofs, every proof signed over its own extra_commit bytes (extra: list of n byte strings)"""
+        blinds = rng.integers(0, 256, (n, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F
+        hi = 2**63 if min_bits >= 63 else 2**max(min_bits, 1)
+        values = np.ascontiguousarray(rng.integers(0, hi, n, dtype=np.uint64) + np.uint64(min_value), np.uint64)
+        if gens64 is None:
+            gens64 = np.frombuffer(GENERATOR_H * n, np.uint8).reshape(n, 64).copy()
+        gens64 = np.ascontiguousarray(gens64, np.uint8)
+        ebuf, estride, elens = self._pack_extra(extra, n)
+        stride = 5134
+        commits = np.zeros((n, 33), np.uint8); proofs = np.zeros((n, stride), np.uint8); plens = np.zeros(n, np.uint64)
+        ok = self.lib.ref_rangeproof_make_many_extra(_p(commits), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(blinds), _p(values), _p(gens64),
+                                                     _p(ebuf), ctypes.c_size_t(estride), _p(elens), ctypes.c_uint64(min_value), ctypes.c_int(exp),
+                                                     ctypes.c_int(min_bits), ctypes.c_size_t(n), ctypes.c_int(threads))
+        assert ok == 1
+        return commits, [proofs[i, :int(plens[i])].tobytes() for i in range(n)], gens64
+
+    def rangeproof_verify_many_extra(self, commits33, plist, gens64, extra, threads=1):
+        n = len(plist)
+        stride = max(max((len(p) for p in plist), default=1), 1)
+        proofs = np.zeros((n, stride), np.uint8)
+        for i, p in enumerate(plist):
+            proofs[i, :len(p)] = np.frombuffer(p, np.uint8)
+        plens = np.array([len(p) for p in plist], np.uint64)
+        ebuf, estride, elens = self._pack_extra(extra, n)
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        commits33 = np.ascontiguousarray(commits33, np.uint8); gens64 = np.ascontiguousarray(gens64, np.uint8)
+        self.lib.ref_rangeproof_verify_many_extra(_p(res), _p(mn), _p(mx), _p(commits33), _p(proofs), ctypes.c_size_t(stride), _p(plens), _p(ebuf),
+                                                  ctypes.c_size_t(estride), _p(elens), _p(gens64), ctypes.c_size_t(n), ctypes.c_int(threads))
+        return res, mn, mx
+
     def make_rangeproofs_msg(self, n, rng, msg_len=0, min_bits=64, exp=0, min_value=0, values=None, threads=8):
         """proofs with random nonces and embedded random messages; returns (commits, proofs, gens, values, blinds, nonces, msgs)"""
         blinds = rng.integers(0, 256, (n, 32), dtype=np.uint8); blinds[:, 0] &= 0x7F

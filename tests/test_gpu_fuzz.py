@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12, 13])
 def test_bounded_differential_fuzz(engine, ref, seed):
     tool = os.path.join(ROOT, "tests", "tools", "fuzz_parity.py")
     out = ""
     for extra in ([], ["more"]):
-        r = subprocess.run([sys.executable, tool, str(seed), "320"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        r = subprocess.run([sys.executable, tool, str(seed), "768"] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         out += r.stdout
     lines = [l for l in out.splitlines() if "mismatches" in l]

@@ -132,12 +132,17 @@ def test_full_size_by_generator_kind(engine, ref, kind):
         gens[own] = np.stack([_gen(ref, rng) for _ in range(int(own.sum()))])
         engine.cache_generator(pool[0]); engine.cache_generator(pool[1])
     h = n // 2
+    # first half 64-bit proofs, second half 52-bit ones (26 rings: Elements' default) signed over an extra_commit (Elements: the output script)
     c1, p1, _, _ = ref.make_rangeproofs(h, rng, min_bits=64, gens64=gens[:h], threads=16)
-    c2, p2, _, _ = ref.make_rangeproofs(n - h, rng, min_bits=52, gens64=gens[h:], threads=16)
+    extra = [b""] * h + [bytes(rng.integers(0, 256, int(rng.integers(1, 80)), dtype=np.uint8)) for _ in range(n - h)]
+    c2, p2, _ = ref.make_rangeproofs_extra(n - h, rng, extra[h:], min_bits=52, gens64=gens[h:], threads=16)
     commits = np.concatenate([c1, c2]); proofs = p1 + p2
     for i in range(0, n, 41):
         q = bytearray(proofs[i]); q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8)); proofs[i] = bytes(q)
-    e_res, e_mn, e_mx = ref.rangeproof_verify_many(commits, proofs, gens, threads=16)
-    res, mn, mx = engine.rangeproof_verify_batch(commits, proofs, gens)
+    for i in range(h + 7, n, 97):
+        extra[i] = extra[i] + b"!"                                 # right proof, wrong extra_commit
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many_extra(commits, proofs, gens, extra, threads=16)
+    res, mn, mx = engine.rangeproof_verify_batch(commits, proofs, gens, extra=extra)
     assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
-    assert e_res.sum() == n - len(range(0, n, 41))
+    bad = set(range(0, n, 41)) | set(range(h + 7, n, 97))
+    assert e_res.sum() == n - len(bad)

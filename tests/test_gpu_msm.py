@@ -169,3 +169,17 @@ def test_window_sharded_shares_add_up(engine, ref):
     assert inf == einf and np.array_equal(xy, exp)
     xy, inf = parallel.msm_auto(be, tsc, tpt, tg)
     assert inf == einf and np.array_equal(xy, exp)
+
+
+def test_msm_on_reference_generated_points(engine, ref):
+    """12 000 terms whose points come from the REFERENCE (secp256k1_ge_set_xquad on random x, random sign: ref.rand_point), not from
+    the engine's own multiplications: with and without the G term, against secp256k1_ecmult_multi_var"""
+    rng = np.random.default_rng(4711)
+    n = 12000
+    pts = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(n)])
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for g in (None, bytes(rng.integers(0, 256, 32, dtype=np.uint8))):
+        exp, einf = ref.ecmult_multi(sc, pts, g)
+        got, ginf = engine.ecmult_multi(sc, pts, g)
+        assert ginf == einf and np.array_equal(got, exp)
+    assert not engine.last_msm_fallback()
