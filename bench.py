@@ -95,6 +95,60 @@ def cpu_baseline_port(commits, proofs, gens):
     return {"value": kn / dt, "unit": "verifies/s", "cores": cores, "kind": "port", "sample": "%d 64-bit proofs on %d threads (%.2f s), oracle/zkp_oracle.c" % (kn, cores, dt)}
 
 
+def measure_dropin(eng, commits, proofs, gens, steps):
+    """host-memory entry points, wall clock per call (everything between handing over host buffers and having the verdicts)"""
+    import ctypes
+    from secp256k1_zkp_amd import Engine
+    n = len(proofs)
+    out = {"unit": "verifies/s", "batch": n, "includes": "packing into pinned staging (host threads), H2D, all kernels, D2H, result copy-out",
+           "stage_threads": int(os.environ.get("S2K_STAGE_THREADS", "0")) or "default min(8, cores / 2)"}
+    # (i) packed numpy arrays -> secp256k1_rangeproof_verify_batch
+    pdata, poff = Engine.pack(proofs)
+    c = np.ascontiguousarray(commits, np.uint8); g = np.ascontiguousarray(gens, np.uint8)
+    res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    L = eng._lib
+    def call_packed():
+        assert L.secp256k1_rangeproof_verify_batch(eng._h, vp(res), vp(mn), vp(mx), vp(c), vp(pdata), vp(poff), None, None, vp(g), n) == 1
+    call_packed()
+    t = time.perf_counter()
+    for _ in range(steps):
+        call_packed()
+    dtp = (time.perf_counter() - t) / steps
+    assert res.all()
+    out["host_buffers"] = {"entry": "secp256k1_rangeproof_verify_batch (packed arrays)", "value": n / dtp, "ms_per_call": dtp * 1e3}
+    # (ii) reference types through the hooked reference library
+    try:
+        from tests import hookapi
+        if os.path.exists(hookapi.HOOKED_PATH):
+            hk = hookapi.Hooked()
+            addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
+            hk.set_backend(engine=eng._h, rangeproof=addr("secp256k1_rangeproof_verify_batch"), rangeproof_ptrs=addr("secp256k1_rangeproof_verify_batch_ptrs"))
+            cobj = np.zeros((n, 64), np.uint8); cobj[:, :33] = c.reshape(n, 33)
+            gobj = g.reshape(n, 64).copy()
+            pbufs = [np.frombuffer(p, np.uint8).copy() for p in proofs]            # every proof its own allocation, as a caller's objects would be
+            plens = (ctypes.c_size_t * n)(*[len(p) for p in proofs])
+            cp = hookapi._ptr_array([cobj[i] for i in range(n)]); gp = hookapi._ptr_array([gobj[i] for i in range(n)]); pp = hookapi._ptr_array(pbufs)
+            r32 = (ctypes.c_int * n)(); mn2 = np.zeros(n, np.uint64); mx2 = np.zeros(n, np.uint64)
+            def call_hook():
+                assert hk.lib.secp256k1_amd_rangeproof_verify_batch(hk.ctx, r32, mn2.ctypes.data, mx2.ctypes.data, cp, pp, plens, None, None, gp, n) == 1
+            s0 = hk.stats()
+            call_hook()
+            t = time.perf_counter()
+            for _ in range(steps):
+                call_hook()
+            dth = (time.perf_counter() - t) / steps
+            s1 = hk.stats()
+            assert s1 == (s0[0] + steps + 1, s0[1]), "the hook fell back to the CPU"
+            assert all(r32[i] == 1 for i in range(0, n, 97)) and int(mx2.min()) == 2**64 - 1
+            out["hooked_reference_types"] = {"entry": "secp256k1_amd_rangeproof_verify_batch (libsecp256k1_hooked.so: the unmodified reference + integration/secp256k1_amd_hook.c)",
+                                             "value": n / dth, "ms_per_call": dth * 1e3, "served": s1[0] - s0[0], "fell_back": s1[1] - s0[1]}
+            hk.set_backend()
+    except OSError as ex:
+        out["hooked_reference_types"] = {"skipped": str(ex)}
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -189,6 +243,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--no-distinct", action="store_true", help="skip the second timed loop (every proof its own generator)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
     args = ap.parse_args()
 
     import torch
@@ -290,6 +345,15 @@ def main():
         assert bool(d_res.all().item()), "a valid proof (own generator) was rejected"
         distinct = {"value": world * n * args.steps / dtd, "ms_per_step": dtd / args.steps * 1e3}
         del d_c2, d_g2, d_p2, d_o2
+
+    # The drop-in path: the same 2^14 proofs handed over in HOST memory, timed from the call to the return (packing into pinned staging,
+    # H2D, the kernels, D2H all inside): (i) the engine's host-buffer entry point on packed numpy arrays, (ii) the reference-side adapter
+    # secp256k1_amd_rangeproof_verify_batch of libsecp256k1_hooked.so (the unmodified reference + integration/secp256k1_amd_hook.c) with the
+    # reference's own types -- arrays of pointers to secp256k1_pedersen_commitment / secp256k1_generator objects and to the proofs.
+    dropin = None
+    if rank == 0 and not args.no_dropin:
+        dropin = measure_dropin(eng, commits, proofs, gens, steps=max(3, min(args.steps, 5)))
+        dropin["resident_verifies_per_s"] = n * args.steps / dt
 
     # secondary figure of the BASELINE metric: one 2^20-term MSM (config 5), terms sharded over the ranks, partial
     # Jacobian sums all-gathered as raw limbs (RCCL) and summed locally -- strong scaling, reported next to the headline.
@@ -422,6 +486,8 @@ def main():
         }
         if msm:
             out["msm"] = msm
+        if dropin:
+            out["dropin"] = dropin
         if not args.no_cpu_baseline:
             # (1) the reference's own bench programs (src/bench_rangeproof.c with min_bits = 64, src/bench_ecmult.c; timer of src/bench.h),
             #     one process and one taskset-pinned process per usable core; (2) the same functions through the oracle/_ref shim with

@@ -151,6 +151,14 @@ S2K_API int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, c
 S2K_API int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                               const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                               const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+/* The same batch given the way the reference's own callers hold it -- arrays of pointers to the objects: commit_objs[i] -> a
+ * secp256k1_pedersen_commitment (its first 33 bytes are read: src/modules/generator/main_impl.h:266-279), proofs[i] / plens[i],
+ * extra[i] / elens[i] (extra may be NULL; extra[i] may be NULL when elens[i] == 0), gen_objs[i] -> a secp256k1_generator (64 bytes).
+ * Both host-buffer forms gather their inputs once, with a few host threads ($S2K_STAGE_THREADS, default min(8, cores / 2)), straight into
+ * pinned staging memory and copy it to HBM piece by piece underneath the packing; results come back through pinned memory. */
+S2K_API int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                   const void* const* commit_objs, const unsigned char* const* proofs, const size_t* plens,
+                                                   const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n);
 S2K_API int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                   const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                   const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);

@@ -49,7 +49,20 @@ int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *res
         ARG_CHECK(extra_commits == NULL || extra_commits[i] != NULL || extra_commit_lens[i] == 0);
     }
     if (n == 0) return 1;
-    if (secp256k1_amd_be.rangeproof_verify_batch != NULL) {
+    if (secp256k1_amd_be.rangeproof_verify_batch_ptrs != NULL) {
+        /* the engine gathers straight from the library's objects into its pinned staging memory (one pass over the data, several host
+         * threads, the copies to the device underneath): this side only converts the result type */
+        int32_t *res32 = (int32_t*)checked_malloc(&ctx->error_callback, sizeof(int32_t) * n);
+        int ok = res32 != NULL;
+        if (ok) {
+            ok = secp256k1_amd_be.rangeproof_verify_batch_ptrs(secp256k1_amd_be.engine, res32, min_value, max_value, (const void *const *)commits, proofs, plens,
+                                                               extra_commits, extra_commit_lens, (const void *const *)gens, n);
+            if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
+        }
+        free(res32);
+        if (ok) { secp256k1_amd_served++; return 1; }
+        secp256k1_amd_fell_back++;
+    } else if (secp256k1_amd_be.rangeproof_verify_batch != NULL) {
         size_t pbytes = 0, ebytes = 0, po = 0, eo = 0;
         unsigned char *c33, *pbuf, *ebuf, *g64;
         uint64_t *poff, *eoff;

@@ -39,6 +39,10 @@ extern "C" {
 typedef int (*secp256k1_amd_rangeproof_verify_batch_fn)(void *engine, int32_t *results, uint64_t *min_value, uint64_t *max_value,
         const unsigned char *commits33, const unsigned char *proofs, const uint64_t *proof_off,
         const unsigned char *extra, const uint64_t *extra_off, const unsigned char *gens64, size_t n);
+/* secp256k1_rangeproof_verify_batch_ptrs: the items as arrays of pointers to the library's own objects -- nothing is packed on this side */
+typedef int (*secp256k1_amd_rangeproof_verify_batch_ptrs_fn)(void *engine, int32_t *results, uint64_t *min_value, uint64_t *max_value,
+        const void *const *commit_objs, const unsigned char *const *proofs, const size_t *plens,
+        const unsigned char *const *extra, const size_t *elens, const void *const *gen_objs, size_t n);
 typedef int (*secp256k1_amd_ecmult_multi_fn)(void *engine, unsigned char *r_xy, int32_t *r_inf, const unsigned char *g_sc,
         const unsigned char *sc, const unsigned char *pt_xy, const unsigned char *pt_inf, size_t n);
 typedef int (*secp256k1_amd_schnorrsig_verify_batch_fn)(void *engine, int32_t *results, const unsigned char *sigs, const unsigned char *msgs,
@@ -63,6 +67,7 @@ typedef struct secp256k1_amd_backend {
     secp256k1_amd_pedersen_verify_tally_batch_fn pedersen_verify_tally_batch;
     secp256k1_amd_schnorrsig_aggverify_fn schnorrsig_aggverify;                   /* secp256k1_schnorrsig_aggverify_amd */
     secp256k1_amd_rangeproof_rewind_batch_fn rangeproof_rewind_batch;             /* secp256k1_rangeproof_rewind_batch */
+    secp256k1_amd_rangeproof_verify_batch_ptrs_fn rangeproof_verify_batch_ptrs;   /* preferred over rangeproof_verify_batch when set: no packing here */
 } secp256k1_amd_backend;
 
 /* Install (copy) a backend table; NULL restores the pure CPU library.  Not thread-safe against concurrent verification

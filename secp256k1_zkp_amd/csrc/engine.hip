@@ -21,6 +21,9 @@
 #include <array>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <chrono>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +97,11 @@ struct s2k_engine {
     rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
     hipEvent_t ev_mbox; int mbox_pending;
     std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;
+    // pinned staging of the host-buffer rangeproof entry points (rp_host_run): inputs are packed into it by a few host threads, chunk by
+    // chunk, and every finished chunk goes to HBM at once (true DMA from pinned memory: the copies overlap the packing of the next chunks)
+    unsigned char* stage; size_t stage_bytes;
+    unsigned char* stage_out; size_t stage_out_bytes;
+    int stage_threads;
     std::recursive_mutex mu;
 };
 
@@ -342,6 +350,9 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
+    e->stage = nullptr; e->stage_bytes = 0; e->stage_out = nullptr; e->stage_out_bytes = 0;
+    { unsigned hc = std::thread::hardware_concurrency(); e->stage_threads = (int)std::min(8u, std::max(1u, hc / 2)); }
+    if (const char* th = getenv("S2K_STAGE_THREADS")) { const int v = atoi(th); if (v >= 1 && v <= 64) e->stage_threads = v; }
     if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
     for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; }
     e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0; e->gen_scanned = 0;
@@ -406,6 +417,8 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->gtab) hipFree(e->gtab);
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
+    if (e->stage) hipHostFree(e->stage);
+    if (e->stage_out) hipHostFree(e->stage_out);
     if (e->dev_flags) hipFree(e->dev_flags);
     for (int i = 0; i < RP_GEN_SLOTS; i++) { if (e->gen[i].tab) hipFree(e->gen[i].tab); if (e->gen[i].xmul) hipFree(e->gen[i].xmul); }
     if (e->gen_keys) hipFree(e->gen_keys);
@@ -877,6 +890,137 @@ extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream
     stream_guard sg(e, st);
     return rp_launch(e, st, results, min_value, max_value, commits33, proofs, proof_off, extra, extra_off, gens64, n);
 }
+// ---- host-buffer form: the drop-in path ---------------------------------------------------------------------------------------------
+// What an application hands over lives in pageable host memory: either packed arrays (secp256k1_rangeproof_verify_batch) or, the way the
+// reference's own callers hold things, arrays of pointers to the objects (secp256k1_rangeproof_verify_batch_ptrs).  Both are gathered ONCE,
+// straight into pinned staging memory laid out like the device buffers, by a few host threads; the proof bytes (98 % of the volume) go in
+// RP_STAGE_CHUNKS pieces and every finished piece is queued for H2D at once, so the DMA runs underneath the packing of the next pieces.
+// Then one launch of the stage pipeline over the whole batch, results back through pinned memory.
+struct rp_host_src {
+    // packed form
+    const unsigned char* commits33; const unsigned char* proofs; const uint64_t* proof_off; const unsigned char* extra; const uint64_t* extra_off; const unsigned char* gens64;
+    // pointer form (used when commit_objs != nullptr)
+    const void* const* commit_objs; const unsigned char* const* proof_ptrs; const size_t* plens; const unsigned char* const* extra_ptrs; const size_t* elens; const void* const* gen_objs;
+};
+static int engine_stage(s2k_engine* e, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > e->stage_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        if (e->stage) HIPCHK(hipHostFree(e->stage));
+        e->stage = nullptr; e->stage_bytes = 0;
+        in_bytes = (in_bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+        HIPCHK(hipHostMalloc((void**)&e->stage, in_bytes, hipHostMallocDefault));
+        e->stage_bytes = in_bytes;
+    }
+    if (out_bytes > e->stage_out_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        if (e->stage_out) HIPCHK(hipHostFree(e->stage_out));
+        e->stage_out = nullptr; e->stage_out_bytes = 0;
+        out_bytes = (out_bytes + 65535) & ~size_t(65535);
+        HIPCHK(hipHostMalloc((void**)&e->stage_out, out_bytes, hipHostMallocDefault));
+        e->stage_out_bytes = out_bytes;
+    }
+    return 1;
+}
+#define RP_STAGE_CHUNKS 16
+static int rp_host_run(s2k_engine* e, const char* who, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n) {
+    const int ptrs = src.commit_objs != nullptr;
+    const int has_extra = ptrs ? (src.extra_ptrs != nullptr) : (src.extra != nullptr && src.extra_off != nullptr);
+    // sizes and offsets
+    std::vector<uint64_t> poff_v, eoff_v;
+    const uint64_t* poff = src.proof_off; const uint64_t* eoff = src.extra_off;
+    if (ptrs) {
+        poff_v.resize(n + 1); poff_v[0] = 0;
+        for (size_t i = 0; i < n; i++) poff_v[i + 1] = poff_v[i] + src.plens[i];
+        poff = poff_v.data();
+        if (has_extra) { eoff_v.resize(n + 1); eoff_v[0] = 0; for (size_t i = 0; i < n; i++) eoff_v[i + 1] = eoff_v[i] + (src.extra_ptrs[i] ? src.elens[i] : 0); eoff = eoff_v.data(); }
+    }
+    const size_t pbytes = (size_t)poff[n], ebytes = has_extra ? (size_t)eoff[n] : 0;
+    const bool tlog = getenv("S2K_STAGE_LOG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = now();
+    // one layout for the pinned staging area and for the device workspace
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+    const size_t o_com = take(33 * n), o_gen = take(64 * n), o_off = take(8 * (n + 1)), o_eoff = take(8 * (n + 1)), o_ex = take(ebytes + 64), o_pr = take(pbytes + 64);
+    const size_t in_bytes = off + 256;
+    const size_t o_res = 0, o_min = (4 * n + 255) & ~size_t(255), o_max = o_min + ((8 * n + 255) & ~size_t(255)), out_bytes = o_max + 8 * n + 256;
+    if (!engine_stage(e, in_bytes, out_bytes)) return 0;
+    if (!engine_workspace(e, in_bytes + out_bytes + 512)) return 0;
+    unsigned char* const hs = e->stage; unsigned char* const ds = e->ws; unsigned char* const dout = e->ws + ((in_bytes + 255) & ~size_t(255));
+    hipStream_t st = e->stream;
+    stream_guard sg(e, st);
+    // small arrays: packed by this thread, queued first
+    if (ptrs) {
+        for (size_t i = 0; i < n; i++) { memcpy(hs + o_com + 33 * i, src.commit_objs[i], 33); memcpy(hs + o_gen + 64 * i, src.gen_objs[i], 64); }
+    } else {
+        memcpy(hs + o_com, src.commits33, 33 * n); memcpy(hs + o_gen, src.gens64, 64 * n);
+    }
+    memcpy(hs + o_off, poff, 8 * (n + 1));
+    if (has_extra) {
+        memcpy(hs + o_eoff, eoff, 8 * (n + 1));
+        if (ptrs) { for (size_t i = 0; i < n; i++) if (eoff[i + 1] > eoff[i]) memcpy(hs + o_ex + eoff[i], src.extra_ptrs[i], (size_t)(eoff[i + 1] - eoff[i])); }
+        else if (ebytes) memcpy(hs + o_ex, src.extra, ebytes);
+    }
+    gen_cache_scan_host(e, st, hs + o_gen, n);
+    const auto t_small = now();
+    HIPCHK(hipMemcpyAsync(ds + o_com, hs + o_com, o_pr - o_com, hipMemcpyHostToDevice, st));          // everything in front of the proofs in one piece
+    // proofs: RP_STAGE_CHUNKS pieces of whole proofs, packed by `nt` threads (piece c by thread c % nt), queued as they complete
+    const int nchunk = (int)std::min<size_t>(RP_STAGE_CHUNKS, std::max<size_t>(1, n / 64));
+    const int nt = (pbytes >= (size_t(4) << 20)) ? std::min(e->stage_threads, nchunk) : 1;
+    std::vector<size_t> cb(nchunk + 1);
+    for (int c = 0; c <= nchunk; c++) cb[c] = (size_t)((unsigned long long)n * (unsigned)c / (unsigned)nchunk);
+    std::vector<std::atomic<int>> ready(nchunk);
+    for (auto& r : ready) r.store(0);
+    auto pack = [&](int t) {
+        for (int c = t; c < nchunk; c += nt) {
+            if (ptrs) { for (size_t i = cb[c]; i < cb[c + 1]; i++) if (src.plens[i]) memcpy(hs + o_pr + poff[i], src.proof_ptrs[i], src.plens[i]); }
+            else if (poff[cb[c + 1]] > poff[cb[c]]) memcpy(hs + o_pr + poff[cb[c]], src.proofs + poff[cb[c]], (size_t)(poff[cb[c + 1]] - poff[cb[c]]));
+            ready[c].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nt; t++) workers.emplace_back(pack, t);
+    int ok = 1;
+    if (nt == 1) pack(0);
+    else {
+        // this thread packs its own share too, and queues whatever has become ready in order
+        int next = 0;
+        for (int c = 0; c < nchunk; c += nt) {
+            if (ptrs) { for (size_t i = cb[c]; i < cb[c + 1]; i++) if (src.plens[i]) memcpy(hs + o_pr + poff[i], src.proof_ptrs[i], src.plens[i]); }
+            else if (poff[cb[c + 1]] > poff[cb[c]]) memcpy(hs + o_pr + poff[cb[c]], src.proofs + poff[cb[c]], (size_t)(poff[cb[c + 1]] - poff[cb[c]]));
+            ready[c].store(1, std::memory_order_release);
+            while (ok && next < nchunk && ready[next].load(std::memory_order_acquire)) {
+                const size_t b0 = (size_t)poff[cb[next]], b1 = (size_t)poff[cb[next + 1]];
+                if (b1 > b0 && hipMemcpyAsync(ds + o_pr + b0, hs + o_pr + b0, b1 - b0, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0;
+                next++;
+            }
+        }
+        for (auto& w : workers) w.join();
+        workers.clear();
+        while (ok && next < nchunk) {
+            const size_t b0 = (size_t)poff[cb[next]], b1 = (size_t)poff[cb[next + 1]];
+            if (b1 > b0 && hipMemcpyAsync(ds + o_pr + b0, hs + o_pr + b0, b1 - b0, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0;
+            next++;
+        }
+    }
+    if (nt == 1 && pbytes) { if (hipMemcpyAsync(ds + o_pr, hs + o_pr, pbytes, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0; }
+    if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); return s2k_fail(who, "host to device copy failed"); }
+    const auto t_packed = now();
+    if (tlog) (void)hipStreamSynchronize(st);
+    const auto t_h2d = now();
+    int32_t* d_res = (int32_t*)(dout + o_res); uint64_t* d_min = (uint64_t*)(dout + o_min); uint64_t* d_max = (uint64_t*)(dout + o_max);
+    if (!rp_launch(e, st, d_res, d_min, d_max, ds + o_com, ds + o_pr, (const uint64_t*)(ds + o_off), has_extra ? ds + o_ex : nullptr, has_extra ? (const uint64_t*)(ds + o_eoff) : nullptr,
+                   ds + o_gen, n, nullptr, 1)) return 0;
+    const auto t_launched = now();
+    HIPCHK(hipMemcpyAsync(e->stage_out, dout, out_bytes - 256, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const auto t_done = now();
+    memcpy(results, e->stage_out + o_res, 4 * n); memcpy(min_value, e->stage_out + o_min, 8 * n); memcpy(max_value, e->stage_out + o_max, 8 * n);
+    if (tlog) fprintf(stderr, "[s2k stage] n=%zu threads=%d: small arrays %.2f ms, proofs packed+queued %.2f ms, H2D drained +%.2f ms, launch %.2f ms, kernels+D2H %.2f ms, copy-out %.2f ms\n",
+                      n, nt, ms(t_begin, t_small), ms(t_small, t_packed), ms(t_packed, t_h2d), ms(t_h2d, t_launched), ms(t_launched, t_done), ms(t_done, now()));
+    return 1;
+}
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                  const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
@@ -885,30 +1029,23 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     memset(results, 0, sizeof(int32_t) * n);
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
-    const size_t pbytes = (size_t)proof_off[n], ebytes = (extra && extra_off) ? (size_t)extra_off[n] : 0;
-    const size_t io = ws_need({4 * n, 8 * n, 8 * n, 33 * n, pbytes + 64, 8 * (n + 1), ebytes + 64, 8 * (n + 1), 64 * n});
-    const size_t nw = std::min(n, RP_CHUNK);
-    if (!engine_workspace(e, io)) return 0;
-    ws_carver c{e->ws, 0}; (void)nw;
-    int32_t* d_res = c.take<int32_t>(n); uint64_t* d_min = c.take<uint64_t>(n); uint64_t* d_max = c.take<uint64_t>(n);
-    unsigned char* d_com = c.take<unsigned char>(33 * n); unsigned char* d_pr = c.take<unsigned char>(pbytes + 64);
-    uint64_t* d_off = c.take<uint64_t>(n + 1); unsigned char* d_ex = c.take<unsigned char>(ebytes + 64); uint64_t* d_eoff = c.take<uint64_t>(n + 1);
-    unsigned char* d_gen = c.take<unsigned char>(64 * n);
-    hipStream_t st = e->stream;
-    stream_guard sg(e, st);
-    HIPCHK(hipMemcpyAsync(d_com, commits33, 33 * n, hipMemcpyHostToDevice, st));
-    if (pbytes) HIPCHK(hipMemcpyAsync(d_pr, proofs, pbytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_off, proof_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
-    if (ebytes) { HIPCHK(hipMemcpyAsync(d_ex, extra, ebytes, hipMemcpyHostToDevice, st)); }
-    if (extra && extra_off) HIPCHK(hipMemcpyAsync(d_eoff, extra_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_gen, gens64, 64 * n, hipMemcpyHostToDevice, st));
-    gen_cache_scan_host(e, st, gens64, n);
-    if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, nullptr, 1)) return 0;
-    HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(max_value, d_max, 8 * n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return 1;
+    rp_host_src src{}; src.commits33 = commits33; src.proofs = proofs; src.proof_off = proof_off; src.extra = extra; src.extra_off = extra_off; src.gens64 = gens64;
+    return rp_host_run(e, "secp256k1_rangeproof_verify_batch", results, min_value, max_value, src, n);
+}
+extern "C" int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs,
+                                                      const unsigned char* const* proofs, const size_t* plens, const unsigned char* const* extra, const size_t* elens,
+                                                      const void* const* gen_objs, size_t n) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_ptrs", "null engine");
+    if (n == 0) return 1;
+    if (!results || !min_value || !max_value || !commit_objs || !proofs || !plens || !gen_objs || (extra && !elens))
+        return s2k_fail_arg("secp256k1_rangeproof_verify_batch_ptrs", "illegal argument (ARG_CHECK)");
+    for (size_t i = 0; i < n; i++) if (!commit_objs[i] || !gen_objs[i] || (!proofs[i] && plens[i]) || (extra && !extra[i] && elens[i]))
+        return s2k_fail_arg("secp256k1_rangeproof_verify_batch_ptrs", "illegal argument (ARG_CHECK): null item");
+    memset(results, 0, sizeof(int32_t) * n);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    rp_host_src src{}; src.commit_objs = commit_objs; src.proof_ptrs = proofs; src.plens = plens; src.extra_ptrs = extra; src.elens = elens; src.gen_objs = gen_objs;
+    return rp_host_run(e, "secp256k1_rangeproof_verify_batch_ptrs", results, min_value, max_value, src, n);
 }
 // rewind: verification + recovery (rangeproof_rewind.h); host buffers
 extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, unsigned char* blind_out, uint64_t* value_out, unsigned char* message_out,

@@ -21,7 +21,7 @@ REWIND_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, 
 class Backend(ctypes.Structure):
     """struct secp256k1_amd_backend (integration/secp256k1_amd_hook.h)"""
     _fields_ = [("engine", _vp), ("rangeproof_verify_batch", _vp), ("ecmult_multi", _vp), ("schnorrsig_verify_batch", _vp),
-                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp)]
+                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp), ("rangeproof_verify_batch_ptrs", _vp)]
 
 
 def fnptr(cfunc):
@@ -57,15 +57,15 @@ class Hooked:
         self.ctx = L.secp256k1_context_create(self.SECP256K1_CONTEXT_NONE)
         self._keep = None
 
-    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None):
+    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None, rangeproof_ptrs=None):
         """install function pointers (ctypes callbacks or raw addresses); all None -> CPU library"""
         def addr(f):
             return f if isinstance(f, int) or f is None else fnptr(f)
-        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind)):
+        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs)):
             self.lib.secp256k1_amd_set_backend(None); self._keep = None
             return
-        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind))
-        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind)
+        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind), addr(rangeproof_ptrs))
+        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs)
         self.lib.secp256k1_amd_set_backend(ctypes.byref(b))
 
     def stats(self):

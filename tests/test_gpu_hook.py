@@ -25,10 +25,11 @@ def hk(engine):
     h.set_backend()
 
 
-def _install(hk, engine, handle):
+def _install(hk, engine, handle, ptrs=False):
     L = engine._lib
     addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
     hk.set_backend(engine=handle, rangeproof=addr("secp256k1_rangeproof_verify_batch"), msm=addr("s2k_ecmult_multi"),
+                   rangeproof_ptrs=addr("secp256k1_rangeproof_verify_batch_ptrs") if ptrs else None,
                    schnorr=addr("secp256k1_schnorrsig_verify_batch"), surjection=addr("secp256k1_surjectionproof_verify_batch"),
                    tally=addr("secp256k1_pedersen_verify_tally_batch"), aggverify=addr("secp256k1_schnorrsig_aggverify_amd"), rewind=addr("secp256k1_rangeproof_rewind_batch"))
 
@@ -58,10 +59,27 @@ def test_rangeproofs_through_the_hook(hk, engine, ref):
     assert hk.stats() == (s0[0] + 1, s0[1])
     assert np.array_equal(res, exp[0]) and np.array_equal(mn, exp[1]) and np.array_equal(mx, exp[2])
     assert 0 < res.sum() < len(plist)
+    # the pointer-array seam (secp256k1_rangeproof_verify_batch_ptrs): the engine gathers from the library's own objects, with extra_commit
+    _install(hk, engine, engine._h, ptrs=True)
+    s0 = hk.stats()
+    res, mn, mx = hk.rangeproof_verify_batch(c, plist, g)
+    assert hk.stats() == (s0[0] + 1, s0[1])
+    assert np.array_equal(res, exp[0]) and np.array_equal(mn, exp[1]) and np.array_equal(mx, exp[2])
+    extra = [b"" if i % 3 else b"script %d" % i for i in range(len(plist))]
+    ce, pe, ge = ref.make_rangeproofs_extra(len(plist), rng, extra, min_bits=20)
+    extra[4] = extra[4] + b"x"; extra[6] = b""
+    exp_e = ref.rangeproof_verify_many_extra(ce, pe, ge, extra)
+    res, mn, mx = hk.rangeproof_verify_batch(ce, pe, ge, extra=extra)
+    assert np.array_equal(res, exp_e[0]) and np.array_equal(mx, exp_e[2]) and 0 < res.sum() < len(pe)
     # forced engine failure (NULL engine): CPU fallback, same verdicts, counted
+    _install(hk, engine, None, ptrs=True)
+    s0 = hk.stats()
+    res2, _, _ = hk.rangeproof_verify_batch(c, plist, g)
+    assert hk.stats() == (s0[0], s0[1] + 1) and np.array_equal(res2, exp[0])
     _install(hk, engine, None)
+    s0 = hk.stats()
     res2, mn2, mx2 = hk.rangeproof_verify_batch(c, plist, g)
-    assert hk.stats() == (s0[0] + 1, s0[1] + 1)
+    assert hk.stats() == (s0[0], s0[1] + 1)
     assert engine._lib.s2k_last_status() == 1
     assert np.array_equal(res2, exp[0]) and np.array_equal(mn2, exp[1]) and np.array_equal(mx2, exp[2])
 
