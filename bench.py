@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--no-msm-big", action="store_true", help="skip the 2^24-term strong-scaling MSM entry")
     ap.add_argument("--no-distinct", action="store_true", help="skip the second timed loop (every proof its own generator)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
     args = ap.parse_args()
@@ -361,52 +362,70 @@ def main():
     if not args.no_msm:
         from secp256k1_zkp_amd import parallel
         from tests.refapi import G_XY, N as ORDER
-        nm = 1 << 20
-        rng = np.random.default_rng(99)
-        ks_h = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
-        ks = torch.tensor(ks_h).to(dev)
-        gpts = torch.tensor(np.frombuffer(G_XY, np.uint8).copy()).to(dev).repeat(nm, 1)
-        pts = torch.zeros(nm, 64, dtype=torch.uint8, device=dev); pinf = torch.zeros(nm, dtype=torch.int32, device=dev)
-        zero_na = torch.zeros(nm, 32, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()          # the engine's stream is not ordered against torch's: inputs must be complete first
-        eng.ecmult_batch_dev(pts, pinf, gpts, zero_na, ks, stream=stream)   # P_i = k_i*G
-        scs_h = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
-        scs = torch.tensor(scs_h).to(dev)
-        torch.cuda.synchronize()
         be = parallel.EngineBackend(eng)
         msm_fn = parallel.msm_sharded if (world == 1 or os.environ.get("S2K_MSM_SHARDING", "terms") == "terms") else parallel.msm_window_sharded
-        msm_fn(be, scs, pts)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        tm = time.perf_counter()
-        for _ in range(args.steps):
-            xy, minf = msm_fn(be, scs, pts)
-        torch.cuda.synchronize()
-        dtm = time.perf_counter() - tm
-        if world > 1:
-            tmax = torch.tensor([dtm], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dtm = float(tmax.item())
-        # in-run check of the timed result: P_i = k_i*G, so sum s_i*P_i must be (sum s_i*k_i mod n)*G -- one generator
-        # multiplication (by the reference when oracle/_ref travelled, else by the engine's own single multiplication)
+
+        def msm_inputs(nm, seed):
+            rng = np.random.default_rng(seed)
+            ks_h = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+            ks = torch.tensor(ks_h).to(dev)
+            gpts = torch.tensor(np.frombuffer(G_XY, np.uint8).copy()).to(dev).repeat(nm, 1)
+            pts = torch.zeros(nm, 64, dtype=torch.uint8, device=dev); pinf = torch.zeros(nm, dtype=torch.int32, device=dev)
+            zero_na = torch.zeros(nm, 32, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()          # the engine's stream is not ordered against torch's: inputs must be complete first
+            eng.ecmult_batch_dev(pts, pinf, gpts, zero_na, ks, stream=stream)   # P_i = k_i*G
+            scs_h = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+            scs = torch.tensor(scs_h).to(dev)
+            eng.sync(); torch.cuda.synchronize()
+            del gpts, zero_na, ks
+            return ks_h, scs_h, scs, pts
+
+        def msm_time(scs, pts):
+            """K sharded MSMs queued back to back (partial -> all-gather -> sum is one stream-ordered chain; nothing waits for the GPU inside
+            the timed region), waited for once"""
+            msm_fn(be, scs, pts, to_host=False)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            for _ in range(args.steps):
+                xy_d, inf_d = msm_fn(be, scs, pts, to_host=False)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - tm
+            if world > 1:
+                tmax = torch.tensor([dtm], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dtm = float(tmax.item())
+            return dtm / args.steps * 1e3, bytes(xy_d.cpu().numpy()), int(inf_d.item())
+
+        def block(nm, ms, xy):
+            mad_rate = 4 * MAC64_PER_MSM_TERM * nm / (ms * 1e-3)
+            return {"terms": nm, "terms_per_rank": (nm + world - 1) // world, "ms": ms, "mpoint_scalar_per_s": nm / (ms * 1e-3) / 1e6, "scaling": "strong",
+                    "frac": mad_rate / (MAD32_PEAK * world),
+                    "roofline": {"bound": "valu", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK * world / 1e12, "unit": "T lane-MAC/s (v_mad_u64_u32)",
+                                 "frac": mad_rate / (MAD32_PEAK * world), "note": "algorithmic 6.3e3 MAC64/term (reference schedule) x 4; whole call incl. the exchange, host to host"},
+                    "hbm_roofline": {"achieved": MSM_BYTES_PER_TERM * nm / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                     "frac": MSM_BYTES_PER_TERM * nm / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_term": MSM_BYTES_PER_TERM},
+                    "result_x": xy[:8].hex()}
+
+        # ---- 2^20 terms (BASELINE config 5)
+        nm = 1 << 20
+        ks_h, scs_h, scs, pts = msm_inputs(nm, 99)
+        ms, xy, minf = msm_time(scs, pts)
+        # in-run check of the timed result: P_i = k_i*G, so sum s_i*P_i must be (sum s_i*k_i mod n)*G -- one generator multiplication
+        # by the reference (when oracle/_ref travelled; otherwise the block is marked unverified)
+        checker = None
         if rank == 0:
             to_int = lambda a: [int.from_bytes(a[i].tobytes(), "big") for i in range(a.shape[0])]
             tot = sum(x * y for x, y in zip(to_int(ks_h), to_int(scs_h))) % ORDER
             tot_b = np.frombuffer(tot.to_bytes(32, "big"), np.uint8)
             if ref is not None:
                 exp_xy, exp_inf = ref.ecmult_batch(np.frombuffer(G_XY, np.uint8), np.zeros(32, np.uint8), ng=tot_b, a_inf=np.ones(1, np.uint8)); checker = "reference secp256k1_ecmult"
-            else:
-                exp_xy, exp_inf = eng.ecmult_batch(np.frombuffer(G_XY, np.uint8), np.zeros(32, np.uint8), ng=tot_b, a_inf=np.ones(1, np.uint8)); checker = "engine single multiplication"
-            assert int(minf) == int(exp_inf[0]) and bytes(xy) == exp_xy[0].tobytes(), "MSM result differs from (sum s_i k_i)*G"
-        ms = dtm / args.steps * 1e3
-        mad_rate = 4 * MAC64_PER_MSM_TERM * nm / (ms * 1e-3)
-        msm = {"terms": nm, "ms": ms, "mpoint_scalar_per_s": nm * args.steps / dtm / 1e6, "scaling": "strong",
-               "sharding": ("terms over ranks, all-gather of %d x 112 B Jacobian partials + local sum" % world) if msm_fn is parallel.msm_sharded
-                           else ("bucket windows over ranks, all-gather of per-window Jacobian sums + local Horner, %d ranks" % world),
-               "roofline": {"bound": "valu", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK * world / 1e12, "unit": "T lane-MAC/s (v_mad_u64_u32)",
-                            "frac": mad_rate / (MAD32_PEAK * world), "note": "algorithmic 6.3e3 MAC64/term (reference schedule) x 4; whole call, host to host"},
-               "hbm_roofline": {"achieved": MSM_BYTES_PER_TERM * nm / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                                "frac": MSM_BYTES_PER_TERM * nm / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_term": MSM_BYTES_PER_TERM},
-               "result_x": bytes(xy[:8]).hex(), "result_check": "== (sum s_i*k_i mod n)*G by " + (checker if rank == 0 else "rank 0")}
+                assert minf == int(exp_inf[0]) and xy == exp_xy[0].tobytes(), "MSM result differs from (sum s_i k_i)*G"
+        msm = block(nm, ms, xy)
+        msm["sharding"] = (("terms over ranks, all-gather of %d x 112 B Jacobian partials + local sum" % world) if msm_fn is parallel.msm_sharded
+                           else ("bucket windows over ranks, all-gather of per-window Jacobian sums + local Horner, %d ranks" % world))
+        msm["verified"] = checker is not None
+        msm["result_check"] = ("== (sum s_i*k_i mod n)*G by " + checker) if checker else ("unverified (oracle/_ref not present)" if rank == 0 else "rank 0")
         # CPU baseline for this half of the metric: the reference's secp256k1_ecmult_multi_var (what bench_ecmult times,
         # src/bench_ecmult.c:278-307 -- its largest size is 32768) on one host core, same box, same inputs
         if rank == 0 and ref is not None and not args.no_cpu_baseline:
@@ -416,10 +435,32 @@ def main():
                 t = time.time(); rxy, rinf = ref.ecmult_multi(scs_h[:m], pts_h[:m]); t = time.time() - t
                 cb["2^%d" % (m.bit_length() - 1)] = {"seconds": t, "mpoint_scalar_per_s": m / t / 1e6}
                 if m == nm:
-                    assert rinf == int(minf) and rxy.tobytes() == bytes(xy), "MSM differs from the reference's ecmult_multi_var"
+                    assert rinf == minf and rxy.tobytes() == xy, "MSM differs from the reference's ecmult_multi_var"
             msm["cpu_baseline"] = {"value": cb["2^20"]["mpoint_scalar_per_s"], "unit": "Mpoint-scalar/s", "cores": 1, "kind": "reference",
                                    "sample": "secp256k1_ecmult_multi_var (Pippenger) on 1 thread: 2^15 terms %.3f s = %.3f M/s, 2^20 terms %.2f s = %.3f M/s; the 2^20 result equals the GPU's"
                                              % (cb["2^15"]["seconds"], cb["2^15"]["mpoint_scalar_per_s"], cb["2^20"]["seconds"], cb["2^20"]["mpoint_scalar_per_s"])}
+        del scs, pts
+        # ---- 2^24 terms: the strong-scaling entry whose per-rank slice stays >= 2^21 terms up to 8 ranks (where one GPU is past its latency floor)
+        if not args.no_msm_big:
+            nb = 1 << 24
+            ks_h, scs_h, scs, pts = msm_inputs(nb, 199)
+            ms, xy, minf = msm_time(scs, pts)
+            big = block(nb, ms, xy)
+            if rank == 0:
+                # the same identity, evaluated in 64 slices so that the Python integers stay short-lived
+                tot = 0
+                for a in range(0, nb, 1 << 18):
+                    kb = ks_h[a:a + (1 << 18)]; sb = scs_h[a:a + (1 << 18)]
+                    tot += sum(int.from_bytes(kb[i].tobytes(), "big") * int.from_bytes(sb[i].tobytes(), "big") for i in range(kb.shape[0]))
+                tot %= ORDER
+                if ref is not None:
+                    exp_xy, exp_inf = ref.ecmult_batch(np.frombuffer(G_XY, np.uint8), np.zeros(32, np.uint8), ng=np.frombuffer(tot.to_bytes(32, "big"), np.uint8), a_inf=np.ones(1, np.uint8))
+                    assert minf == int(exp_inf[0]) and xy == exp_xy[0].tobytes(), "2^24-term MSM differs from (sum s_i k_i)*G"
+                    big["verified"] = True; big["result_check"] = "== (sum s_i*k_i mod n)*G by reference secp256k1_ecmult"
+                else:
+                    big["verified"] = False
+            msm["strong_2p24"] = big
+            del scs, pts
 
     if rank == 0:
         value = world * n * args.steps / dt

@@ -58,6 +58,12 @@ typedef int (*secp256k1_amd_rangeproof_rewind_batch_fn)(void *engine, int32_t *r
                                                        uint64_t *outlen, size_t msg_stride, const unsigned char *nonces, uint64_t *min_value, uint64_t *max_value,
                                                        const unsigned char *commits33, const unsigned char *proofs, const uint64_t *proof_off,
                                                        const unsigned char *extra, const uint64_t *extra_off, const unsigned char *gens64, size_t n);
+/* s2k_ecmult_batch and secp256k1_bppp_norm_product_verify_batch */
+typedef int (*secp256k1_amd_ecmult_batch_fn)(void *engine, unsigned char *r_xy, int32_t *r_inf, const unsigned char *a_xy, const unsigned char *a_inf,
+        const unsigned char *na, const unsigned char *ng, size_t n);
+typedef int (*secp256k1_amd_bppp_norm_product_verify_batch_fn)(void *engine, int32_t *results, const unsigned char *proofs, size_t proof_len,
+        const unsigned char *transcripts, const unsigned char *rho, const unsigned char *gens33, size_t n_gens, size_t g_len,
+        const unsigned char *c_vec, size_t c_vec_len, const unsigned char *commits33, size_t n);
 typedef struct secp256k1_amd_backend {
     void *engine;
     secp256k1_amd_rangeproof_verify_batch_fn rangeproof_verify_batch;            /* may be NULL: that call stays on the CPU */
@@ -68,11 +74,20 @@ typedef struct secp256k1_amd_backend {
     secp256k1_amd_schnorrsig_aggverify_fn schnorrsig_aggverify;                   /* secp256k1_schnorrsig_aggverify_amd */
     secp256k1_amd_rangeproof_rewind_batch_fn rangeproof_rewind_batch;             /* secp256k1_rangeproof_rewind_batch */
     secp256k1_amd_rangeproof_verify_batch_ptrs_fn rangeproof_verify_batch_ptrs;   /* preferred over rangeproof_verify_batch when set: no packing here */
+    secp256k1_amd_ecmult_batch_fn ecmult_batch;                                   /* s2k_ecmult_batch */
+    secp256k1_amd_bppp_norm_product_verify_batch_fn bppp_norm_product_verify_batch;   /* secp256k1_bppp_norm_product_verify_batch */
 } secp256k1_amd_backend;
 
-/* Install (copy) a backend table; NULL restores the pure CPU library.  Not thread-safe against concurrent verification
- * calls -- call it once at start-up, like secp256k1_context_set_sha256_compression. */
+/* Install (copy) a backend table; NULL restores the pure CPU library.  The table is published with ONE pointer store (release order) and
+ * every adapter works on the table it read at its entry, so a verification that runs concurrently sees either the old or the new table,
+ * never a mixture (include/secp256k1.h:42-52: API calls on const contexts may run concurrently).  Meant to be called at start-up, like
+ * secp256k1_context_set_sha256_compression; two installs must be a verification's duration apart (two table slots).
+ * Thread safety of the engine behind the table: one s2k_engine serialises its callers (a mutex per engine; their launches share its stream
+ * and scratch), so concurrent verifier threads are safe and take turns; give every thread its own engine for parallel submission. */
 void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend);
+/* secp256k1_ecmult_multi_var calls with fewer terms than this stay on the CPU (default 256: an engine round trip costs ~0.65 ms whatever
+ * the size, the CPU ~3-6 us per term); 0 sends everything to the engine. */
+void secp256k1_amd_set_msm_min_terms(size_t n);
 /* Counters for tests / monitoring: batches served by the backend, batches that fell back to the CPU after a backend failure. */
 void secp256k1_amd_stats(size_t *served, size_t *fell_back);
 

@@ -9,6 +9,9 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "secp256k1_zkp_amd is written for gfx950 (MI355X) only: v_bitop3_b32, the 9x29 limb schedule and the wave-cooperative DPP code assume it; build with --offload-arch=gfx950"
+#endif
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define S2K_HD __host__ __device__ __forceinline__

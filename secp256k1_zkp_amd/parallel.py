@@ -23,29 +23,35 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
+class _NoStream:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+def _chain(backend):
+    """the stream context in which partial -> all-gather -> sum form ONE stream-ordered chain (EngineBackend: its own torch stream, which
+    the RCCL collective then also runs on; CPU test backends: nothing)"""
+    return backend.chain() if hasattr(backend, "chain") else _NoStream()
+
+
+def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=True):
     """r = g_sc*G + sum sc_i*pt_i with the terms sharded over the ranks of `group`.
 
     `backend` provides  msm_partial(sc, pt_xy, g_sc, pt_inf) -> torch uint32[28] (on its device)  and
-    gej_sum(parts uint32[world,28]) -> (xy bytes[64], inf).  On a GPU rank that is `EngineBackend(engine)`.
-    Every rank passes the full input (already resident); each computes only its slice.  Returns (xy, inf) on all ranks."""
-    import torch
+    gej_sum(parts uint32[world,28], to_host) -> (xy bytes[64], inf).  On a GPU rank that is `EngineBackend(engine)`.
+    Every rank passes the full input (already resident); each computes only its slice.  Returns (xy, inf) on all ranks; with
+    to_host=False the two are device tensors and NOTHING waits for the GPU (the caller synchronises when it needs the values)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
     lo, hi = shard_range(n, rank, world)
-    part = backend.msm_partial(sc[lo:hi], pt_xy[lo:hi], g_sc if rank == 0 else None, None if pt_inf is None else pt_inf[lo:hi])
-    if world == 1:
-        parts = part.reshape(1, 28)
-    else:
-        bufs = [torch.empty_like(part) for _ in range(world)]
-        dist.all_gather(bufs, part, group=group)
-        parts = torch.stack(bufs)
-    return backend.gej_sum(parts)
+    with _chain(backend):
+        part = backend.msm_partial(sc[lo:hi], pt_xy[lo:hi], g_sc if rank == 0 else None, None if pt_inf is None else pt_inf[lo:hi])
+        return _gather_and_sum(backend, part, group, to_host)
 
 
-def _gather_and_sum(backend, part, group):
+def _gather_and_sum(backend, part, group, to_host=True):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -55,29 +61,44 @@ def _gather_and_sum(backend, part, group):
         bufs = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(bufs, part, group=group)
         parts = torch.stack(bufs)
-    return backend.gej_sum(parts)
+    return backend.gej_sum(parts, to_host) if _takes_to_host(backend) else backend.gej_sum(parts)
 
 
-def msm_window_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
+def _takes_to_host(backend):
+    import inspect
+    try:
+        return "to_host" in inspect.signature(backend.gej_sum).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def msm_window_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=True):
     """r = g_sc*G + sum sc_i*pt_i with the Pippenger digit windows sharded over the ranks of `group`: rank r computes
     sum_{w in share r} 2^(c w) S_w over ALL terms (`backend.msm_window_partial`), the Jacobian partials are all-gathered as raw
     limb buffers and summed locally.  Every rank passes the same full input.  Returns (xy, inf) on all ranks."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    part = backend.msm_window_partial(sc, pt_xy, g_sc, pt_inf, rank, world)
-    return _gather_and_sum(backend, part, group)
+    with _chain(backend):
+        part = backend.msm_window_partial(sc, pt_xy, g_sc, pt_inf, rank, world)
+        return _gather_and_sum(backend, part, group, to_host)
 
 
-def msm_auto(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None):
-    """term sharding unless the per-rank slice would fall under the bucket method's useful size (each rank would then pay the
-    whole latency floor for a sliver of the terms) while whole windows are still available to hand out."""
+# Terms at which one bucket MSM call stops being pure latency on MI355X (the call costs ~0.65 ms up to 2^16 terms and grows from there:
+# profiles/r03*_msm_sweep.txt); a backend may carry its own measured value as `floor_terms`.
+MSM_FLOOR_TERMS = 1 << 16
+
+
+def msm_auto(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=True):
+    """term sharding unless the per-rank slice would fall under the size at which a call is pure latency (each rank would then pay the
+    whole floor for a sliver of the terms) while whole windows are still available to hand out."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
-    if world > 1 and n // world < (1 << 14) and n >= (1 << 12):
-        return msm_window_sharded(backend, sc, pt_xy, g_sc, pt_inf, group)
-    return msm_sharded(backend, sc, pt_xy, g_sc, pt_inf, group)
+    floor_terms = getattr(backend, "floor_terms", MSM_FLOOR_TERMS)
+    if world > 1 and n // world < floor_terms and n >= (1 << 12):
+        return msm_window_sharded(backend, sc, pt_xy, g_sc, pt_inf, group, to_host)
+    return msm_sharded(backend, sc, pt_xy, g_sc, pt_inf, group, to_host)
 
 
 def gather_results(local, n_total, group=None):
@@ -110,14 +131,23 @@ class EngineBackend:
         self.dev = torch.device("cuda", engine.device)
         self.stream = torch.cuda.Stream(device=self.dev)
 
+    def chain(self):
+        """context: everything inside -- engine calls and torch.distributed collectives alike -- runs on this backend's stream, in order"""
+        import torch
+        return torch.cuda.stream(self.stream)
+
     def _enter(self):
         import torch
-        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
         return self.stream.cuda_stream
 
     def _leave(self):
         import torch
-        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     def msm_partial(self, sc, pt_xy, g_sc, pt_inf):
         import torch
@@ -140,12 +170,15 @@ class EngineBackend:
         self._leave()
         return out
 
-    def gej_sum(self, parts):
+    def gej_sum(self, parts, to_host=True):
+        """sum of Jacobian partials; to_host=False returns the device tensors (xy uint8[64], inf int32[1]) without waiting for anything"""
         import torch
         r = torch.zeros(64, dtype=torch.uint8, device=self.dev); inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
         parts = parts.contiguous()
         h = self._enter()
         self.engine.gej_sum_dev(r, inf, parts, parts.shape[0], stream=h)
         self._leave()
-        torch.cuda.current_stream(self.dev).synchronize()
+        if not to_host:
+            return r, inf
+        self.stream.synchronize()
         return r.cpu().numpy(), int(inf.item())

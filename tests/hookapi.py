@@ -21,7 +21,8 @@ REWIND_FN = ctypes.CFUNCTYPE(_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, 
 class Backend(ctypes.Structure):
     """struct secp256k1_amd_backend (integration/secp256k1_amd_hook.h)"""
     _fields_ = [("engine", _vp), ("rangeproof_verify_batch", _vp), ("ecmult_multi", _vp), ("schnorrsig_verify_batch", _vp),
-                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp), ("rangeproof_verify_batch_ptrs", _vp)]
+                ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp), ("rangeproof_verify_batch_ptrs", _vp), ("ecmult_batch", _vp),
+                ("bppp_norm_product_verify_batch", _vp)]
 
 
 def fnptr(cfunc):
@@ -54,18 +55,22 @@ class Hooked:
         L.secp256k1_surjectionproof_parse.argtypes = [_vp, _vp, ctypes.c_char_p, _sz]
         L.hook_test_ecmult_multi.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, ctypes.POINTER(_sz)]
         L.ref_bppp_norm_verify.argtypes = [ctypes.c_char_p, _sz, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _sz, _sz, ctypes.c_char_p, _sz, ctypes.c_char_p]
+        L.secp256k1_amd_set_msm_min_terms.argtypes = [_sz]; L.secp256k1_amd_set_msm_min_terms.restype = None
+        L.hook_test_ecmult_batch.argtypes = [_vp] * 6 + [_sz]
+        L.hook_test_bppp_batch.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]
+        L.secp256k1_amd_set_msm_min_terms(0)       # the tests drive the MSM seam at every size; the default threshold has its own test
         self.ctx = L.secp256k1_context_create(self.SECP256K1_CONTEXT_NONE)
         self._keep = None
 
-    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None, rangeproof_ptrs=None):
+    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None, rangeproof_ptrs=None, ecmult_batch=None, bppp_batch=None):
         """install function pointers (ctypes callbacks or raw addresses); all None -> CPU library"""
         def addr(f):
             return f if isinstance(f, int) or f is None else fnptr(f)
-        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs)):
+        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch)):
             self.lib.secp256k1_amd_set_backend(None); self._keep = None
             return
-        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind), addr(rangeproof_ptrs))
-        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs)
+        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind), addr(rangeproof_ptrs), addr(ecmult_batch), addr(bppp_batch))
+        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch)
         self.lib.secp256k1_amd_set_backend(ctypes.byref(b))
 
     def stats(self):
@@ -154,6 +159,32 @@ class Hooked:
         res = (_int * n)()
         r = self.lib.secp256k1_amd_pedersen_verify_tally_batch(self.ctx, res, pos_arrs, pc, neg_arrs, nc, n)
         assert r == 1
+        return np.array(list(res), np.int32)
+
+    MSM_MIN_TERMS_DEFAULT = 256       # SECP256K1_AMD_MSM_MIN_TERMS_DEFAULT (integration/secp256k1_amd_hook.c)
+
+    def set_msm_min_terms(self, n):
+        self.lib.secp256k1_amd_set_msm_min_terms(n)
+
+    def ecmult_batch(self, a_xy, na, ng=None, a_inf=None):
+        """r[i] = na[i]*a[i] + ng[i]*G through secp256k1_ecmult_batch_amd (reference types inside the library)"""
+        a_xy = np.ascontiguousarray(a_xy, np.uint8); n = a_xy.size // 64
+        na = np.ascontiguousarray(na, np.uint8); ng = None if ng is None else np.ascontiguousarray(ng, np.uint8)
+        ai = None if a_inf is None else np.ascontiguousarray(a_inf, np.uint8)
+        r = np.zeros((n, 64), np.uint8); inf = np.zeros(n, np.int32)
+        p = lambda a: None if a is None else a.ctypes.data
+        assert self.lib.hook_test_ecmult_batch(p(r), p(inf), p(a_xy), p(ai), p(na), p(ng), n) == 1
+        return r, inf
+
+    def bppp_verify_batch(self, proofs, trs, rhos, gens, g_len, cvs, commits):
+        """n proofs through secp256k1_amd_bppp_norm_product_verify_batch; arrays as ref.make_bppp returns them"""
+        proofs = np.ascontiguousarray(proofs, np.uint8); n = proofs.shape[0]
+        trs = np.ascontiguousarray(trs, np.uint8); rhos = np.ascontiguousarray(rhos, np.uint8); gens = np.ascontiguousarray(gens, np.uint8)
+        cvs = np.ascontiguousarray(cvs, np.uint8); commits = np.ascontiguousarray(commits, np.uint8)
+        res = (_int * n)()
+        ok = self.lib.hook_test_bppp_batch(res, proofs.ctypes.data, proofs.shape[1], trs.ctypes.data, rhos.ctypes.data, gens.ctypes.data, gens.shape[0], g_len,
+                                           cvs.ctypes.data, cvs.shape[1], commits.ctypes.data, n)
+        assert ok == 1
         return np.array(list(res), np.int32)
 
     def ecmult_multi(self, sc, pt_xy, g_sc=None, pt_inf=None, fail_at=-1):

@@ -329,3 +329,82 @@ def test_rewind_adapter_cpu_paths(hk, ref):
             if cap:
                 assert all(got[3][i][:48] == msgs[i].tobytes() for i in range(5) if ok[i])
     hk.set_backend()
+
+
+def test_ecmult_batch_and_bppp_batch_adapters_cpu_paths(hk, ref):
+    """the two adapters added for the single double multiplication (src/ecmult.h:47) and for the BP++ norm-argument verifier
+    (bppp_norm_product_impl.h:425) with the reference's own types: without a backend they are the library's per-item calls; a checking
+    backend sees exactly the caller's items in the engine's byte formats; a failing backend falls back and is counted"""
+    rng = np.random.default_rng(511)
+    n = 24
+    a = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(n)])
+    na = rng.integers(0, 256, (n, 32), dtype=np.uint8); ng = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    inf = np.zeros(n, np.uint8); inf[3] = 1; na[5] = 0; ng[5] = 0
+    exp, einf = ref.ecmult_batch(a, na, ng, inf)
+    hk.set_backend()
+    r, ri = hk.ecmult_batch(a, na, ng, inf)
+    assert np.array_equal(ri, einf) and np.array_equal(r, exp)
+    e2, ei2 = ref.ecmult_batch(a, na, None, inf)
+    r, ri = hk.ecmult_batch(a, na, None, inf)
+    assert np.array_equal(ri, ei2) and np.array_equal(r, e2)
+    seen = []
+    EB_FN = ctypes.CFUNCTYPE(ctypes.c_int, *([ctypes.c_void_p] * 7 + [ctypes.c_size_t]))
+
+    def eb(engine, r_xy, r_inf, a_xy, a_inf, pna, png, m):
+        A = _arr(a_xy, 64 * m).reshape(m, 64).copy(); AI = _arr(a_inf, m).copy()
+        x, fl = ref.ecmult_batch(A, _arr(pna, 32 * m).reshape(m, 32).copy(), None if not png else _arr(png, 32 * m).reshape(m, 32).copy(), AI)
+        _arr(r_xy, 64 * m)[:] = x.reshape(-1); _arr(r_inf, 4 * m, np.int32)[:] = fl
+        seen.append(m)
+        return 1
+    cb = EB_FN(eb)
+    hk.set_backend(ecmult_batch=cb)
+    s0 = hk.stats()
+    r, ri = hk.ecmult_batch(a, na, ng, inf)
+    assert seen == [n] and hk.stats() == (s0[0] + 1, s0[1]) and np.array_equal(ri, einf) and np.array_equal(r, exp)
+    hk.set_backend(ecmult_batch=_failing(EB_FN))
+    r, ri = hk.ecmult_batch(a, na, ng, inf)
+    assert hk.stats() == (s0[0] + 1, s0[1] + 1) and np.array_equal(ri, einf) and np.array_equal(r, exp)
+    # BP++: reference-made proofs, one corrupted
+    proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(5, rng, 8, 4)
+    proofs[2, 40] ^= 1
+    want = np.array(ref.bppp_verify_many(proofs, trs, rhos, gens, gl, cvs, commits), np.int32)
+    hk.set_backend()
+    assert np.array_equal(hk.bppp_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits), want) and list(want) == [1, 1, 0, 1, 1]
+    BP_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                             ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t)
+    got_args = []
+
+    def bp(engine, results, pr, plen, tr, rh, gs, n_gens, g_len, cv, c_len, cm, m):
+        P_ = _arr(pr, plen * m).reshape(m, plen).copy()
+        res = ref.bppp_verify_many(P_, _arr(tr, 104 * m).reshape(m, 104).copy(), _arr(rh, 32 * m).reshape(m, 32).copy(), _arr(gs, 33 * n_gens).reshape(n_gens, 33).copy(), g_len,
+                                   _arr(cv, 32 * c_len * m).reshape(m, c_len, 32).copy(), _arr(cm, 33 * m).reshape(m, 33).copy())
+        _arr(results, 4 * m, np.int32)[:] = np.array(res, np.int32)
+        got_args.append((m, plen, n_gens, g_len, c_len))
+        return 1
+    cbp = BP_FN(bp)
+    hk.set_backend(bppp_batch=cbp)
+    s0 = hk.stats()
+    assert np.array_equal(hk.bppp_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits), want)
+    assert got_args == [(5, proofs.shape[1], gens.shape[0], gl, cvs.shape[1])] and hk.stats() == (s0[0] + 1, s0[1])
+    hk.set_backend(bppp_batch=_failing(BP_FN))
+    assert np.array_equal(hk.bppp_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits), want) and hk.stats() == (s0[0] + 1, s0[1] + 1)
+    hk.set_backend()
+
+
+def test_msm_min_terms_default_keeps_small_sums_on_the_cpu(hk, ref):
+    """SECP256K1_AMD_MSM_MIN_TERMS_DEFAULT: below it secp256k1_ecmult_multi_var_amd does not go to the backend at all"""
+    rng = np.random.default_rng(512)
+    seen = []
+    hk.set_backend(msm=_msm_checker(ref, seen))
+    hk.set_msm_min_terms(hookapi.Hooked.MSM_MIN_TERMS_DEFAULT)
+    try:
+        for n, goes in ((13, False), (255, False), (256, True), (300, True)):
+            sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            pts = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(16)])[np.arange(n) % 16]
+            exy, einf = ref.ecmult_multi(sc, pts)
+            seen.clear()
+            xy, fl, _ = hk.ecmult_multi(sc, pts)
+            assert fl == einf and np.array_equal(xy, exy) and (seen == [n]) == goes, n
+    finally:
+        hk.set_msm_min_terms(0)
+        hk.set_backend()

@@ -1,6 +1,8 @@
 """GPU: bench.py's N>1 path end to end with two ranks sharing the one GPU of the test box (gloo rendezvous on 127.0.0.1, since RCCL
-needs one device per rank): proof shards signed per rank and all-gathered, replica verification, the term-sharded MSM with its
-all-gather of Jacobian partials, max-over-ranks timing, one JSON line from rank 0."""
+needs one device per rank): proof shards signed per rank and all-gathered, replica verification, the sharded MSM (2^20 and the 2^24
+strong-scaling entry; term sharding and window sharding) with its all-gather of Jacobian partials as one stream-ordered chain,
+max-over-ranks timing, one JSON line from rank 0 -- and every sharding gives the point of the single-rank run, which bench.py itself
+checks against the reference."""
 import json
 import os
 import subprocess
@@ -10,22 +12,33 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "1", "--warmup", "1", "--batch", "512", "--no-cpu-baseline", "--no-dropin", "--no-distinct"]
+
+
+def _run(world, sharding=None, port=29517):
+    env = dict(os.environ, S2K_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    if sharding:
+        env["S2K_MSM_SHARDING"] = sharding
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + COMMON
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + COMMON
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # only rank 0 prints
+    return json.loads(lines[0])
 
 
 def test_bench_two_ranks_one_gpu():
-    env = dict(os.environ, S2K_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "512", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                  # only rank 0 prints
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["batch_per_gpu"] == 512
-    assert j["msm"]["terms"] == 1 << 20 and len(j["msm"]["result_x"]) == 16
-    # the sharded MSM must give the same point as the single-rank run of the same seeded inputs
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "512", "--no-cpu-baseline"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert one.returncode == 0, one.stderr[-2000:]
-    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
-    assert j1["msm"]["result_x"] == j["msm"]["result_x"]
+    j1 = _run(1)
+    assert j1["msm"]["verified"] and j1["msm"]["strong_2p24"]["verified"]          # the single-rank points are the reference's
+    for k, (sharding, port) in enumerate((("terms", 29517), ("windows", 29519))):
+        j = _run(2, sharding, port)
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["batch_per_gpu"] == 512
+        m = j["msm"]
+        assert m["terms"] == 1 << 20 and m["terms_per_rank"] == 1 << 19 and m["verified"] and m["frac"] > 0
+        assert m["strong_2p24"]["terms"] == 1 << 24 and m["strong_2p24"]["terms_per_rank"] == 1 << 23 and m["strong_2p24"]["verified"]
+        assert ("windows" in m["sharding"]) == (sharding == "windows")
+        assert m["result_x"] == j1["msm"]["result_x"] and m["strong_2p24"]["result_x"] == j1["msm"]["strong_2p24"]["result_x"]

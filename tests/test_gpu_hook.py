@@ -226,3 +226,70 @@ def test_rewind_through_the_hook(hk, engine, ref):
             assert np.array_equal(got[1][ok], exp[1][ok]) and np.array_equal(got[2][ok], exp[2][ok]) and got[3] == exp[3]
             assert not got[1][~ok].any() and not got[2][~ok].any()
             assert np.array_equal(got[4][ok], exp[4][ok]) and np.array_equal(got[5][ok], exp[5][ok])
+
+
+def test_ecmult_batch_and_bppp_batch_through_the_hook(hk, engine, ref):
+    """secp256k1_ecmult_batch_amd and secp256k1_amd_bppp_norm_product_verify_batch (reference types) on the real engine"""
+    L = engine._lib
+    addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
+    rng = np.random.default_rng(611)
+    hk.set_backend(engine=engine._h, ecmult_batch=addr("s2k_ecmult_batch"), bppp_batch=addr("secp256k1_bppp_norm_product_verify_batch"))
+    n = 300
+    a = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(32)])[np.arange(n) % 32]
+    na = rng.integers(0, 256, (n, 32), dtype=np.uint8); ng = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    inf = np.zeros(n, np.uint8); inf[9] = 1; na[11] = 0; ng[11] = 0; na[12] = 0
+    s0 = hk.stats()
+    for g in (ng, None):
+        exp, einf = ref.ecmult_batch(a, na, g, inf)
+        r, ri = hk.ecmult_batch(a, na, g, inf)
+        assert np.array_equal(ri, einf) and np.array_equal(r, exp)
+    assert hk.stats() == (s0[0] + 2, s0[1])
+    proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(40, rng, 16, 4)
+    proofs[7, 33] ^= 2; cvs[9, 0, 31] ^= 1
+    want = np.array(ref.bppp_verify_many(proofs, trs, rhos, gens, gl, cvs, commits), np.int32)
+    got = hk.bppp_verify_batch(proofs, trs, rhos, gens, gl, cvs, commits)
+    assert np.array_equal(got, want) and want.sum() == 38 and hk.stats() == (s0[0] + 3, s0[1])
+    hk.set_backend()
+
+
+def test_concurrent_verifier_threads_on_one_engine(hk, engine, ref):
+    """include/secp256k1.h:42-52: verification calls may run concurrently.  Four threads push different batches through the hook (one engine:
+    its mutex makes them take turns, its scratch is theirs in turn) while another thread re-installs the backend table: every verdict equals
+    the reference's."""
+    import threading
+    rng = np.random.default_rng(612)
+    jobs = []
+    for t in range(4):
+        c, p, g, _ = ref.make_rangeproofs(24, rng, min_bits=(64, 12, 52, 30)[t])
+        for i in range(0, 24, 5):
+            q = bytearray(p[i]); q[int(rng.integers(0, len(q)))] ^= 1 << int(rng.integers(0, 8)); p[i] = bytes(q)
+        jobs.append((c, p, g, ref.rangeproof_verify_many(c, p, g)))
+    _install(hk, engine, engine._h, ptrs=True)
+    errors = []
+    stop = threading.Event()
+
+    def worker(k):
+        c, p, g, exp = jobs[k]
+        try:
+            for _ in range(6):
+                res, mn, mx = hk.rangeproof_verify_batch(c, p, g)
+                if not (np.array_equal(res, exp[0]) and np.array_equal(mn, exp[1]) and np.array_equal(mx, exp[2])):
+                    errors.append(k)
+        except Exception as ex:          # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    def reinstaller():
+        import time
+        while not stop.is_set():
+            _install(hk, engine, engine._h, ptrs=True)
+            time.sleep(0.02)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    ri = threading.Thread(target=reinstaller)
+    ri.start()
+    for t in th: t.start()
+    for t in th: t.join()
+    stop.set(); ri.join()
+    assert errors == []
+    assert hk.stats()[1] == hk.stats()[1]          # (no fallbacks are expected, but a fallback would still have produced the reference's verdicts)
+    hk.set_backend()
