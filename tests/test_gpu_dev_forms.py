@@ -168,3 +168,49 @@ def test_dev_calls_on_two_streams_share_the_scratch_safely(engine, ref):
     for j in jobs:
         assert (j["inf"].cpu().numpy() == np.asarray(j["winf"]).reshape(-1)).all()
         assert (j["r"].cpu().numpy().reshape(-1, 64) == np.asarray(j["want"]).reshape(-1, 64)).all()
+
+
+def test_rewind_dev_behind_a_queued_msm_with_inputs_ready(engine, ref):
+    """S2K_OPT_RP_INPUTS_READY promises that the caller's INPUT arrays are complete, nothing about the engine's own scratch: the rewind `_dev`
+    form replays the prover's random stream on a side stream into the shared workspace, which an MSM queued just before on the same stream is
+    still using.  The engine orders the two (the rewind form always waits for the caller's stream); both results must be right, repeatedly."""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    from tests.refapi import G_XY
+    L = engine._lib
+    rng = np.random.default_rng(88)
+    n_msm = 1 << 16
+    k = rng.integers(0, 256, (n_msm, 32), dtype=np.uint8)
+    g = np.frombuffer(G_XY * n_msm, np.uint8).reshape(n_msm, 64)
+    pts, _ = engine.ecmult_batch(g, np.zeros((n_msm, 32), np.uint8), k)
+    sc = rng.integers(0, 256, (n_msm, 32), dtype=np.uint8)
+    want_xy, want_inf = engine.ecmult_multi(sc, pts)
+    commits, plist, gens, values, blinds, nonces, msgs_ = ref.make_rangeproofs_msg(48, rng, msg_len=24, min_bits=64)
+    nonces[5, 1] ^= 2
+    eh = engine.rangeproof_rewind_batch(commits, plist, gens, nonces, msg_capacity=64)
+    data, poff = engine.pack(plist)
+    m = len(plist)
+    d_sc, d_pt = _d(sc), _d(pts)
+    r_xy = torch.zeros(64, dtype=torch.uint8, device="cuda"); r_inf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = torch.zeros(m, dtype=torch.int32, device="cuda"); bl = torch.zeros(m * 32, dtype=torch.uint8, device="cuda"); val = torch.zeros(m, dtype=torch.int64, device="cuda")
+    msg = torch.zeros(m * 64, dtype=torch.uint8, device="cuda"); ol = torch.full((m,), 64, dtype=torch.int64, device="cuda")
+    mn = torch.zeros(m, dtype=torch.int64, device="cuda"); mx = torch.zeros(m, dtype=torch.int64, device="cuda")
+    dno, dc, dpr, dgen = _d(nonces), _d(commits), _d(np.concatenate([data, np.zeros(64, np.uint8)])), _d(gens)
+    doff = torch.tensor(poff.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    engine.set_option(Engine.OPT_RP_INPUTS_READY, 1)
+    try:
+        for rep in range(4):
+            r_xy.zero_(); res.zero_(); ol.fill_(64)
+            torch.cuda.synchronize()
+            engine.ecmult_multi_dev(r_xy, r_inf, d_sc, d_pt)
+            assert L.secp256k1_rangeproof_rewind_batch_dev(engine._h, None, _p(res), _p(bl), _p(val), _p(msg), _p(ol), 64, _p(dno), _p(mn), _p(mx), _p(dc), _p(dpr),
+                                                           _p(doff), None, None, _p(dgen), m) == 1
+            engine.ecmult_multi_dev(r_xy, r_inf, d_sc, d_pt)
+            engine.sync()
+            assert bytes(r_xy.cpu().numpy()) == bytes(want_xy) and int(r_inf.item()) == int(want_inf)
+            r = res.cpu().numpy()
+            assert np.array_equal(r, eh[0]) and r.sum() == m - 1
+            assert np.array_equal(bl.cpu().numpy().reshape(m, 32), eh[1]) and np.array_equal(val.cpu().numpy().view(np.uint64), eh[2])
+    finally:
+        engine.set_option(Engine.OPT_RP_INPUTS_READY, 0)
