@@ -159,6 +159,22 @@ S2K_API int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, u
 S2K_API int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                    const void* const* commit_objs, const unsigned char* const* proofs, const size_t* plens,
                                                    const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n);
+/* Asynchronous pair over the two host-buffer forms, for callers with a stream of batches (the blocks of a chain sync, the transactions of a
+ * mempool): `_submit` gathers the inputs, queues the copies and the kernels and returns a ticket; `_wait(ticket)` blocks until that batch is
+ * done and only then fills results / min_value / max_value (which must stay valid until then; `results` holds zeros in between).  The
+ * INPUT arrays may be reused as soon as `_submit` returns.  At most TWO submissions may be in flight -- a third `_submit` fails (argument
+ * error) until the older ticket has been waited for -- and tickets may be waited for in any order, from any thread.  With
+ *     submit(k+1); wait(k); submit(k+2); wait(k+1); ...
+ * the gathering and the PCIe copies of batch k+1 run underneath the kernels of batch k and the GPU never idles: the throughput of the
+ * host-buffer path becomes that of the device-resident one (bench.py: dropin.value_two_in_flight).  The synchronous forms above are
+ * submit + wait.  A ticket is never 0. */
+S2K_API int secp256k1_rangeproof_verify_batch_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                     const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                     const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+S2K_API int secp256k1_rangeproof_verify_batch_ptrs_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                          const void* const* commit_objs, const unsigned char* const* proofs, const size_t* plens,
+                                                          const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n);
+S2K_API int secp256k1_rangeproof_verify_batch_wait(s2k_engine* e, uint64_t ticket);
 S2K_API int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                   const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                   const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);

@@ -7,6 +7,7 @@
  */
 #include "secp256k1_amd_hook.h"
 
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -57,6 +58,56 @@ void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n
  * results[i], min_value[i], max_value[i] are what the single call returns / writes for item i.  Returns 1 when the batch
  * was processed (on the engine or on the CPU), 0 only for illegal arguments.
  * --------------------------------------------------------------------------------------------------------------- */
+/* Asynchronous pair for callers with a stream of batches: `_submit` hands the batch to the engine and returns at once with a ticket (the
+ * engine has gathered the inputs by then: they may be reused; results / min_value / max_value must stay valid), `_wait` blocks until the
+ * verdicts are in them.  At most two submissions in flight.  Without a backend -- or when the engine refuses the submission -- `_submit`
+ * runs the library's own loop then and there and hands out ticket 0, which `_wait` accepts as "done".  `_wait` returning 0 (the device failed
+ * underneath a batch it had accepted) leaves results all 0 = nothing verified: verify those items again through the synchronous call. */
+#if INT_MAX != 0x7fffffff
+#error "the asynchronous adapters hand `int *results` to the engine as int32_t"
+#endif
+int secp256k1_amd_rangeproof_verify_batch_submit(const secp256k1_context *ctx, uint64_t *ticket, int *results, uint64_t *min_value, uint64_t *max_value,
+        const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
+        const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
+    const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
+    size_t i;
+    VERIFY_CHECK(ctx != NULL);
+    ARG_CHECK(ticket != NULL);
+    *ticket = 0;
+    ARG_CHECK(results != NULL);
+    ARG_CHECK(min_value != NULL);
+    ARG_CHECK(max_value != NULL);
+    ARG_CHECK(commits != NULL);
+    ARG_CHECK(proofs != NULL);
+    ARG_CHECK(plens != NULL);
+    ARG_CHECK(gens != NULL);
+    ARG_CHECK(extra_commits == NULL || extra_commit_lens != NULL);
+    for (i = 0; i < n; i++) {
+        ARG_CHECK(commits[i] != NULL);
+        ARG_CHECK(proofs[i] != NULL);
+        ARG_CHECK(gens[i] != NULL);
+        ARG_CHECK(extra_commits == NULL || extra_commits[i] != NULL || extra_commit_lens[i] == 0);
+    }
+    if (n == 0) return 1;
+    if (be->rangeproof_verify_batch_ptrs_submit != NULL && be->rangeproof_verify_batch_wait != NULL) {
+        if (be->rangeproof_verify_batch_ptrs_submit(be->engine, ticket, (int32_t*)results, min_value, max_value, (const void *const *)commits, proofs, plens,
+                                                    extra_commits, extra_commit_lens, (const void *const *)gens, n)) { secp256k1_amd_served++; return 1; }
+        *ticket = 0;
+        secp256k1_amd_fell_back++;
+    }
+    for (i = 0; i < n; i++) {
+        results[i] = secp256k1_rangeproof_verify(ctx, &min_value[i], &max_value[i], commits[i], proofs[i], plens[i],
+                                                 extra_commits != NULL ? extra_commits[i] : NULL, extra_commits != NULL ? extra_commit_lens[i] : 0, gens[i]);
+    }
+    return 1;
+}
+int secp256k1_amd_rangeproof_verify_batch_wait(const secp256k1_context *ctx, uint64_t ticket) {
+    const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
+    VERIFY_CHECK(ctx != NULL);
+    if (ticket == 0) return 1;
+    ARG_CHECK(be->rangeproof_verify_batch_wait != NULL);
+    return be->rangeproof_verify_batch_wait(be->engine, ticket);
+}
 int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *results, uint64_t *min_value, uint64_t *max_value,
         const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
         const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {

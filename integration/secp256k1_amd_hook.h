@@ -43,6 +43,11 @@ typedef int (*secp256k1_amd_rangeproof_verify_batch_fn)(void *engine, int32_t *r
 typedef int (*secp256k1_amd_rangeproof_verify_batch_ptrs_fn)(void *engine, int32_t *results, uint64_t *min_value, uint64_t *max_value,
         const void *const *commit_objs, const unsigned char *const *proofs, const size_t *plens,
         const unsigned char *const *extra, const size_t *elens, const void *const *gen_objs, size_t n);
+/* secp256k1_rangeproof_verify_batch_ptrs_submit / secp256k1_rangeproof_verify_batch_wait: the same, asynchronously (two batches in flight) */
+typedef int (*secp256k1_amd_rangeproof_verify_batch_ptrs_submit_fn)(void *engine, uint64_t *ticket, int32_t *results, uint64_t *min_value, uint64_t *max_value,
+        const void *const *commit_objs, const unsigned char *const *proofs, const size_t *plens,
+        const unsigned char *const *extra, const size_t *elens, const void *const *gen_objs, size_t n);
+typedef int (*secp256k1_amd_rangeproof_verify_batch_wait_fn)(void *engine, uint64_t ticket);
 typedef int (*secp256k1_amd_ecmult_multi_fn)(void *engine, unsigned char *r_xy, int32_t *r_inf, const unsigned char *g_sc,
         const unsigned char *sc, const unsigned char *pt_xy, const unsigned char *pt_inf, size_t n);
 typedef int (*secp256k1_amd_schnorrsig_verify_batch_fn)(void *engine, int32_t *results, const unsigned char *sigs, const unsigned char *msgs,
@@ -76,6 +81,8 @@ typedef struct secp256k1_amd_backend {
     secp256k1_amd_rangeproof_verify_batch_ptrs_fn rangeproof_verify_batch_ptrs;   /* preferred over rangeproof_verify_batch when set: no packing here */
     secp256k1_amd_ecmult_batch_fn ecmult_batch;                                   /* s2k_ecmult_batch */
     secp256k1_amd_bppp_norm_product_verify_batch_fn bppp_norm_product_verify_batch;   /* secp256k1_bppp_norm_product_verify_batch */
+    secp256k1_amd_rangeproof_verify_batch_ptrs_submit_fn rangeproof_verify_batch_ptrs_submit;   /* both or neither: the asynchronous pair */
+    secp256k1_amd_rangeproof_verify_batch_wait_fn rangeproof_verify_batch_wait;
 } secp256k1_amd_backend;
 
 /* Install (copy) a backend table; NULL restores the pure CPU library.  The table is published with ONE pointer store (release order) and

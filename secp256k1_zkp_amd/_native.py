@@ -41,6 +41,9 @@ SIGNATURES = {
     "secp256k1_pedersen_verify_tally_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_verify_batch": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_verify_batch_ptrs": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_batch_submit": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_batch_ptrs_submit": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_batch_wait": (_c.c_int, [_vp, _c.c_uint64]),
     "secp256k1_rangeproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 9 + [_sz]),
     "secp256k1_rangeproof_rewind_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_verify_amd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -229,6 +229,27 @@ class Engine:
                                                                  _p(edata), _p(eoff), _p(gens64), n), "secp256k1_rangeproof_verify_batch")
         return res, mn, mx
 
+    def rangeproof_verify_batch_submit(self, commits33, proofs, gens64, extra=None):
+        """Asynchronous form: gathers and queues the batch, returns a ticket object; `rangeproof_verify_batch_wait(ticket)` returns
+        (results, min_value, max_value).  At most two tickets may be outstanding (include/secp256k1_zkp_amd.h)."""
+        data, off = proofs if isinstance(proofs, tuple) else self.pack(list(proofs))
+        n = off.size - 1
+        commits33 = _u8(commits33); gens64 = _u8(gens64)
+        edata = eoff = None
+        if extra is not None:
+            edata, eoff = extra if isinstance(extra, tuple) else self.pack(list(extra))
+        self._check_rp_shapes("rangeproof_verify_batch_submit", n, commits33, gens64, data, off, edata, eoff)
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        t = ctypes.c_uint64(0)
+        self._check(self._lib.secp256k1_rangeproof_verify_batch_submit(self._h, ctypes.byref(t), _p(res), _p(mn), _p(mx), _p(commits33), _p(data), _p(off),
+                                                                        _p(edata), _p(eoff), _p(gens64), n), "secp256k1_rangeproof_verify_batch_submit")
+        return (t.value, res, mn, mx)                  # the output arrays live in the ticket until it is waited for
+
+    def rangeproof_verify_batch_wait(self, ticket):
+        t, res, mn, mx = ticket
+        self._check(self._lib.secp256k1_rangeproof_verify_batch_wait(self._h, ctypes.c_uint64(t)), "secp256k1_rangeproof_verify_batch_wait")
+        return res, mn, mx
+
     @staticmethod
     def _check_rp_shapes(what, n, commits33, gens64, data, off, edata, eoff):
         _need(what + " commits33", commits33, 33 * n); _need(what + " gens64", gens64, 64 * n)

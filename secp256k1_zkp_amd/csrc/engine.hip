@@ -97,10 +97,18 @@ struct s2k_engine {
     rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
     hipEvent_t ev_mbox; int mbox_pending;
     std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;
-    // pinned staging of the host-buffer rangeproof entry points (rp_host_run): inputs are packed into it by a few host threads, chunk by
+    // pinned staging of the host-buffer rangeproof entry points (rp_host_submit): inputs are packed into it by a few host threads, chunk by
     // chunk, and every finished chunk goes to HBM at once (true DMA from pinned memory: the copies overlap the packing of the next chunks)
-    unsigned char* stage; size_t stage_bytes;
-    unsigned char* stage_out; size_t stage_out_bytes;
+    // Two such sets (pinned in / pinned out / their device images), so that a second batch can be gathered and copied while the first one
+    // computes (secp256k1_rangeproof_verify_batch_submit / _wait); the copies run on their own stream.
+    struct stage_set {
+        unsigned char* in; size_t in_bytes; unsigned char* out; size_t out_bytes; unsigned char* dev; size_t dev_bytes;
+        hipEvent_t ev_h2d, ev_out; int used;
+        uint64_t ticket;                                  // 0: free; otherwise the submission that owns the set until it is waited for
+        int32_t* results; uint64_t* min_value; uint64_t* max_value; size_t n, o_res, o_min, o_max;
+    } stage[2];
+    uint64_t next_ticket;
+    hipStream_t stream_copy;
     int stage_threads;
     std::recursive_mutex mu;
 };
@@ -350,7 +358,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
-    e->stage = nullptr; e->stage_bytes = 0; e->stage_out = nullptr; e->stage_out_bytes = 0;
+    for (int i = 0; i < 2; i++) { auto& S = e->stage[i]; S.in = S.out = S.dev = nullptr; S.in_bytes = S.out_bytes = S.dev_bytes = 0; S.ev_h2d = S.ev_out = nullptr; S.used = 0; S.ticket = 0; }
+    e->next_ticket = 1; e->stream_copy = nullptr;
     { unsigned hc = std::thread::hardware_concurrency(); e->stage_threads = (int)std::min(8u, std::max(1u, hc / 2)); }
     if (const char* th = getenv("S2K_STAGE_THREADS")) { const int v = atoi(th); if (v >= 1 && v <= 64) e->stage_threads = v; }
     if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
@@ -380,6 +389,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_join, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
+    S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { S2K_CREATE_CHK(hipEventCreateWithFlags(&e->stage[i].ev_h2d, hipEventDisableTiming)); S2K_CREATE_CHK(hipEventCreateWithFlags(&e->stage[i].ev_out, hipEventDisableTiming)); }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_draws, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_rewound, hipEventDisableTiming));
@@ -417,8 +428,15 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->gtab) hipFree(e->gtab);
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
-    if (e->stage) hipHostFree(e->stage);
-    if (e->stage_out) hipHostFree(e->stage_out);
+    for (int i = 0; i < 2; i++) {
+        auto& S = e->stage[i];
+        if (S.in) hipHostFree(S.in);
+        if (S.out) hipHostFree(S.out);
+        if (S.dev) hipFree(S.dev);
+        if (S.ev_h2d) hipEventDestroy(S.ev_h2d);
+        if (S.ev_out) hipEventDestroy(S.ev_out);
+    }
+    if (e->stream_copy) hipStreamDestroy(e->stream_copy);
     if (e->dev_flags) hipFree(e->dev_flags);
     for (int i = 0; i < RP_GEN_SLOTS; i++) { if (e->gen[i].tab) hipFree(e->gen[i].tab); if (e->gen[i].xmul) hipFree(e->gen[i].xmul); }
     if (e->gen_keys) hipFree(e->gen_keys);
@@ -775,7 +793,8 @@ static int engine_rp_slots(s2k_engine* e, size_t nw) {
 #define RP_CHUNK (e->max_lanes / RP_MAX_RINGS)     /* proofs per launch group */
 static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra,
-                     const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr, int inputs_on_stream = 0) {
+                     const uint64_t* extra_off, const unsigned char* gens64, size_t n, const rp_rewind_args* rewind = nullptr, int inputs_on_stream = 0,
+                     hipEvent_t inputs_ev = nullptr) {
     const size_t nw = std::min(n, RP_CHUNK);
     if (!engine_rp_slots(e, nw)) return 0;
     if (!engine_rtab(e, nw * RP_MAX_RINGS)) return 0;
@@ -787,7 +806,9 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     HIPCHK(hipEventRecord(e->ev[0], st));
     const hipStream_t sp = e->stream_pre;
     // (a table built or replaced since the last call was queued on `st`: the side stream must see it, too)
-    if (inputs_on_stream || !e->rp_inputs_ready || e->gen_dirty) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); e->gen_dirty = 0; }
+    // (inputs_ev: the inputs arrive on another stream, which recorded this event behind them -- the host-buffer entry points' copy stream)
+    if (inputs_ev) HIPCHK(hipStreamWaitEvent(sp, inputs_ev, 0));
+    if (inputs_on_stream || (!inputs_ev && !e->rp_inputs_ready) || e->gen_dirty) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); e->gen_dirty = 0; }
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
         const size_t m = std::min(n - p0, RP_CHUNK);
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
@@ -902,29 +923,38 @@ struct rp_host_src {
     // pointer form (used when commit_objs != nullptr)
     const void* const* commit_objs; const unsigned char* const* proof_ptrs; const size_t* plens; const unsigned char* const* extra_ptrs; const size_t* elens; const void* const* gen_objs;
 };
-static int engine_stage(s2k_engine* e, size_t in_bytes, size_t out_bytes) {
-    if (in_bytes > e->stage_bytes) {
+static int engine_stage(s2k_engine* e, s2k_engine::stage_set& S, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > S.in_bytes || in_bytes + out_bytes + 512 > S.dev_bytes) {
         HIPCHK(hipDeviceSynchronize());
-        if (e->stage) HIPCHK(hipHostFree(e->stage));
-        e->stage = nullptr; e->stage_bytes = 0;
+        if (S.in) HIPCHK(hipHostFree(S.in));
+        if (S.dev) HIPCHK(hipFree(S.dev));
+        S.in = nullptr; S.in_bytes = 0; S.dev = nullptr; S.dev_bytes = 0;
         in_bytes = (in_bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-        HIPCHK(hipHostMalloc((void**)&e->stage, in_bytes, hipHostMallocDefault));
-        e->stage_bytes = in_bytes;
+        HIPCHK(hipHostMalloc((void**)&S.in, in_bytes, hipHostMallocDefault));
+        S.in_bytes = in_bytes;
+        const size_t db = in_bytes + ((out_bytes + 65535) & ~size_t(65535)) + 65536;
+        HIPCHK(hipMalloc((void**)&S.dev, db));
+        S.dev_bytes = db;
     }
-    if (out_bytes > e->stage_out_bytes) {
+    if (out_bytes > S.out_bytes) {
         HIPCHK(hipDeviceSynchronize());
-        if (e->stage_out) HIPCHK(hipHostFree(e->stage_out));
-        e->stage_out = nullptr; e->stage_out_bytes = 0;
+        if (S.out) HIPCHK(hipHostFree(S.out));
+        S.out = nullptr; S.out_bytes = 0;
         out_bytes = (out_bytes + 65535) & ~size_t(65535);
-        HIPCHK(hipHostMalloc((void**)&e->stage_out, out_bytes, hipHostMallocDefault));
-        e->stage_out_bytes = out_bytes;
+        HIPCHK(hipHostMalloc((void**)&S.out, out_bytes, hipHostMallocDefault));
+        S.out_bytes = out_bytes;
     }
     return 1;
 }
 #define RP_STAGE_CHUNKS 16
-static int rp_host_run(s2k_engine* e, const char* who, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n) {
+// Gather, copy and launch one batch; what comes back is the ticket of the staging set that now belongs to it (rp_host_wait hands it back).
+// The copies go on the engine's copy stream and the first stage of the pipeline waits for them by event, so that a batch submitted while
+// the one before it computes has its inputs in HBM -- and its header / prologue stage done -- by the time the rings kernel is free.
+static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n) {
     const int ptrs = src.commit_objs != nullptr;
     const int has_extra = ptrs ? (src.extra_ptrs != nullptr) : (src.extra != nullptr && src.extra_off != nullptr);
+    s2k_engine::stage_set& S = e->stage[e->next_ticket & 1u];
+    if (S.ticket) return s2k_fail_arg(who, "two batches in flight already: wait for the older ticket first");
     // sizes and offsets
     std::vector<uint64_t> poff_v, eoff_v;
     const uint64_t* poff = src.proof_off; const uint64_t* eoff = src.extra_off;
@@ -939,17 +969,18 @@ static int rp_host_run(s2k_engine* e, const char* who, int32_t* results, uint64_
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_begin = now();
-    // one layout for the pinned staging area and for the device workspace
+    // one layout for the pinned staging area and for its device image
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
     const size_t o_com = take(33 * n), o_gen = take(64 * n), o_off = take(8 * (n + 1)), o_eoff = take(8 * (n + 1)), o_ex = take(ebytes + 64), o_pr = take(pbytes + 64);
     const size_t in_bytes = off + 256;
     const size_t o_res = 0, o_min = (4 * n + 255) & ~size_t(255), o_max = o_min + ((8 * n + 255) & ~size_t(255)), out_bytes = o_max + 8 * n + 256;
-    if (!engine_stage(e, in_bytes, out_bytes)) return 0;
-    if (!engine_workspace(e, in_bytes + out_bytes + 512)) return 0;
-    unsigned char* const hs = e->stage; unsigned char* const ds = e->ws; unsigned char* const dout = e->ws + ((in_bytes + 255) & ~size_t(255));
-    hipStream_t st = e->stream;
+    if (!engine_stage(e, S, in_bytes, out_bytes)) return 0;
+    unsigned char* const hs = S.in; unsigned char* const ds = S.dev; unsigned char* const dout = S.dev + ((in_bytes + 255) & ~size_t(255));
+    hipStream_t st = e->stream, cp = e->stream_copy;
     stream_guard sg(e, st);
+    // the set's device image is free once the batch that used it before has its results out (its pinned side: once that batch was waited for)
+    if (S.used) HIPCHK(hipStreamWaitEvent(cp, S.ev_out, 0));
     // small arrays: packed by this thread, queued first
     if (ptrs) {
         for (size_t i = 0; i < n; i++) { memcpy(hs + o_com + 33 * i, src.commit_objs[i], 33); memcpy(hs + o_gen + 64 * i, src.gen_objs[i], 64); }
@@ -964,7 +995,7 @@ static int rp_host_run(s2k_engine* e, const char* who, int32_t* results, uint64_
     }
     gen_cache_scan_host(e, st, hs + o_gen, n);
     const auto t_small = now();
-    HIPCHK(hipMemcpyAsync(ds + o_com, hs + o_com, o_pr - o_com, hipMemcpyHostToDevice, st));          // everything in front of the proofs in one piece
+    HIPCHK(hipMemcpyAsync(ds + o_com, hs + o_com, o_pr - o_com, hipMemcpyHostToDevice, cp));          // everything in front of the proofs in one piece
     // proofs: RP_STAGE_CHUNKS pieces of whole proofs, packed by `nt` threads (piece c by thread c % nt), queued as they complete
     const int nchunk = (int)std::min<size_t>(RP_STAGE_CHUNKS, std::max<size_t>(1, n / 64));
     const int nt = (pbytes >= (size_t(4) << 20)) ? std::min(e->stage_threads, nchunk) : 1;
@@ -972,54 +1003,100 @@ static int rp_host_run(s2k_engine* e, const char* who, int32_t* results, uint64_
     for (int c = 0; c <= nchunk; c++) cb[c] = (size_t)((unsigned long long)n * (unsigned)c / (unsigned)nchunk);
     std::vector<std::atomic<int>> ready(nchunk);
     for (auto& r : ready) r.store(0);
-    auto pack = [&](int t) {
-        for (int c = t; c < nchunk; c += nt) {
-            if (ptrs) { for (size_t i = cb[c]; i < cb[c + 1]; i++) if (src.plens[i]) memcpy(hs + o_pr + poff[i], src.proof_ptrs[i], src.plens[i]); }
-            else if (poff[cb[c + 1]] > poff[cb[c]]) memcpy(hs + o_pr + poff[cb[c]], src.proofs + poff[cb[c]], (size_t)(poff[cb[c + 1]] - poff[cb[c]]));
-            ready[c].store(1, std::memory_order_release);
-        }
+    auto pack_piece = [&](int c) {
+        if (ptrs) { for (size_t i = cb[c]; i < cb[c + 1]; i++) if (src.plens[i]) memcpy(hs + o_pr + poff[i], src.proof_ptrs[i], src.plens[i]); }
+        else if (poff[cb[c + 1]] > poff[cb[c]]) memcpy(hs + o_pr + poff[cb[c]], src.proofs + poff[cb[c]], (size_t)(poff[cb[c + 1]] - poff[cb[c]]));
+        ready[c].store(1, std::memory_order_release);
     };
-    std::vector<std::thread> workers;
-    for (int t = 1; t < nt; t++) workers.emplace_back(pack, t);
-    int ok = 1;
-    if (nt == 1) pack(0);
-    else {
-        // this thread packs its own share too, and queues whatever has become ready in order
-        int next = 0;
-        for (int c = 0; c < nchunk; c += nt) {
-            if (ptrs) { for (size_t i = cb[c]; i < cb[c + 1]; i++) if (src.plens[i]) memcpy(hs + o_pr + poff[i], src.proof_ptrs[i], src.plens[i]); }
-            else if (poff[cb[c + 1]] > poff[cb[c]]) memcpy(hs + o_pr + poff[cb[c]], src.proofs + poff[cb[c]], (size_t)(poff[cb[c + 1]] - poff[cb[c]]));
-            ready[c].store(1, std::memory_order_release);
-            while (ok && next < nchunk && ready[next].load(std::memory_order_acquire)) {
-                const size_t b0 = (size_t)poff[cb[next]], b1 = (size_t)poff[cb[next + 1]];
-                if (b1 > b0 && hipMemcpyAsync(ds + o_pr + b0, hs + o_pr + b0, b1 - b0, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0;
-                next++;
-            }
-        }
-        for (auto& w : workers) w.join();
-        workers.clear();
-        while (ok && next < nchunk) {
+    auto pack = [&](int t) { for (int c = t; c < nchunk; c += nt) pack_piece(c); };
+    int ok = 1, next = 0;
+    auto queue_ready = [&](bool all) {
+        while (ok && next < nchunk && (all || ready[next].load(std::memory_order_acquire))) {
             const size_t b0 = (size_t)poff[cb[next]], b1 = (size_t)poff[cb[next + 1]];
-            if (b1 > b0 && hipMemcpyAsync(ds + o_pr + b0, hs + o_pr + b0, b1 - b0, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0;
+            if (b1 > b0 && hipMemcpyAsync(ds + o_pr + b0, hs + o_pr + b0, b1 - b0, hipMemcpyHostToDevice, cp) != hipSuccess) ok = 0;
             next++;
         }
+    };
+    if (nt == 1) {
+        pack(0);
+        if (pbytes && hipMemcpyAsync(ds + o_pr, hs + o_pr, pbytes, hipMemcpyHostToDevice, cp) != hipSuccess) ok = 0;
+    } else {
+        std::vector<std::thread> workers;
+        for (int t = 1; t < nt; t++) workers.emplace_back(pack, t);
+        for (int c = 0; c < nchunk; c += nt) { pack_piece(c); queue_ready(false); }      // this thread packs its share and queues whatever is ready, in order
+        for (auto& w : workers) w.join();
+        queue_ready(true);
     }
-    if (nt == 1 && pbytes) { if (hipMemcpyAsync(ds + o_pr, hs + o_pr, pbytes, hipMemcpyHostToDevice, st) != hipSuccess) ok = 0; }
-    if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); return s2k_fail(who, "host to device copy failed"); }
+    if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(cp); return s2k_fail(who, "host to device copy failed"); }
+    HIPCHK(hipEventRecord(S.ev_h2d, cp));
     const auto t_packed = now();
-    if (tlog) (void)hipStreamSynchronize(st);
+    if (tlog) (void)hipStreamSynchronize(cp);
     const auto t_h2d = now();
     int32_t* d_res = (int32_t*)(dout + o_res); uint64_t* d_min = (uint64_t*)(dout + o_min); uint64_t* d_max = (uint64_t*)(dout + o_max);
     if (!rp_launch(e, st, d_res, d_min, d_max, ds + o_com, ds + o_pr, (const uint64_t*)(ds + o_off), has_extra ? ds + o_ex : nullptr, has_extra ? (const uint64_t*)(ds + o_eoff) : nullptr,
-                   ds + o_gen, n, nullptr, 1)) return 0;
-    const auto t_launched = now();
-    HIPCHK(hipMemcpyAsync(e->stage_out, dout, out_bytes - 256, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const auto t_done = now();
-    memcpy(results, e->stage_out + o_res, 4 * n); memcpy(min_value, e->stage_out + o_min, 8 * n); memcpy(max_value, e->stage_out + o_max, 8 * n);
-    if (tlog) fprintf(stderr, "[s2k stage] n=%zu threads=%d: small arrays %.2f ms, proofs packed+queued %.2f ms, H2D drained +%.2f ms, launch %.2f ms, kernels+D2H %.2f ms, copy-out %.2f ms\n",
-                      n, nt, ms(t_begin, t_small), ms(t_small, t_packed), ms(t_packed, t_h2d), ms(t_h2d, t_launched), ms(t_launched, t_done), ms(t_done, now()));
+                   ds + o_gen, n, nullptr, 0, S.ev_h2d)) { (void)hipStreamSynchronize(cp); return 0; }
+    HIPCHK(hipMemcpyAsync(S.out, dout, out_bytes - 256, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(S.ev_out, st));
+    S.used = 1; S.ticket = e->next_ticket++; S.results = results; S.min_value = min_value; S.max_value = max_value; S.n = n; S.o_res = o_res; S.o_min = o_min; S.o_max = o_max;
+    *ticket = S.ticket;
+    if (tlog) fprintf(stderr, "[s2k stage] n=%zu threads=%d: small arrays %.2f ms, proofs packed+queued %.2f ms, H2D drained +%.2f ms, launch %.2f ms\n",
+                      n, nt, ms(t_begin, t_small), ms(t_small, t_packed), ms(t_packed, t_h2d), ms(t_h2d, now()));
     return 1;
+}
+// blocks until the batch behind `ticket` is done, hands its results to the arrays given at submission and frees its staging set.
+// Called WITHOUT the engine's mutex held across the wait (another thread may be submitting meanwhile).
+static int rp_host_wait(s2k_engine* e, const char* who, uint64_t ticket) {
+    s2k_engine::stage_set* S = nullptr; hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lock(e->mu);
+        S = &e->stage[ticket & 1u];
+        if (ticket == 0 || S->ticket != ticket) return s2k_fail_arg(who, "unknown ticket (never issued, or waited for already)");
+        ev = S->ev_out;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    const hipError_t err = hipEventSynchronize(ev);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    if (err != hipSuccess) { S->ticket = 0; (void)hipGetLastError(); return s2k_fail(who, hipGetErrorString(err)); }      // (the arrays keep the zeros of submission time)
+    memcpy(S->results, S->out + S->o_res, 4 * S->n); memcpy(S->min_value, S->out + S->o_min, 8 * S->n); memcpy(S->max_value, S->out + S->o_max, 8 * S->n);
+    S->ticket = 0;
+    return 1;
+}
+static int rp_ptrs_check(const char* who, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs, const unsigned char* const* proofs,
+                         const size_t* plens, const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n) {
+    if (!results || !min_value || !max_value || !commit_objs || !proofs || !plens || !gen_objs || (extra && !elens)) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    for (size_t i = 0; i < n; i++) if (!commit_objs[i] || !gen_objs[i] || (!proofs[i] && plens[i]) || (extra && !extra[i] && elens[i]))
+        return s2k_fail_arg(who, "illegal argument (ARG_CHECK): null item");
+    return 1;
+}
+// ---- asynchronous pair: submit gathers + queues and returns; wait blocks for the results (at most two submissions in flight) ---------
+extern "C" int secp256k1_rangeproof_verify_batch_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                        const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                        const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
+    const char* who = "secp256k1_rangeproof_verify_batch_submit";
+    if (!e) return s2k_fail(who, "null engine");
+    if (!ticket || n == 0 || !results || !min_value || !max_value || !commits33 || !proofs || !proof_off || !gens64) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    memset(results, 0, sizeof(int32_t) * n);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    rp_host_src src{}; src.commits33 = commits33; src.proofs = proofs; src.proof_off = proof_off; src.extra = extra; src.extra_off = extra_off; src.gens64 = gens64;
+    return rp_host_submit(e, who, ticket, results, min_value, max_value, src, n);
+}
+extern "C" int secp256k1_rangeproof_verify_batch_ptrs_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                             const void* const* commit_objs, const unsigned char* const* proofs, const size_t* plens,
+                                                             const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n) {
+    const char* who = "secp256k1_rangeproof_verify_batch_ptrs_submit";
+    if (!e) return s2k_fail(who, "null engine");
+    if (!ticket || n == 0) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    if (!rp_ptrs_check(who, results, min_value, max_value, commit_objs, proofs, plens, extra, elens, gen_objs, n)) return 0;
+    memset(results, 0, sizeof(int32_t) * n);
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    rp_host_src src{}; src.commit_objs = commit_objs; src.proof_ptrs = proofs; src.plens = plens; src.extra_ptrs = extra; src.elens = elens; src.gen_objs = gen_objs;
+    return rp_host_submit(e, who, ticket, results, min_value, max_value, src, n);
+}
+extern "C" int secp256k1_rangeproof_verify_batch_wait(s2k_engine* e, uint64_t ticket) {
+    if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_wait", "null engine");
+    return rp_host_wait(e, "secp256k1_rangeproof_verify_batch_wait", ticket);
 }
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
@@ -1027,25 +1104,31 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch", "null engine");
     if (n == 0) return 1;
     memset(results, 0, sizeof(int32_t) * n);
-    std::lock_guard<std::recursive_mutex> lock(e->mu);
-    HIPCHK(hipSetDevice(e->device));
     rp_host_src src{}; src.commits33 = commits33; src.proofs = proofs; src.proof_off = proof_off; src.extra = extra; src.extra_off = extra_off; src.gens64 = gens64;
-    return rp_host_run(e, "secp256k1_rangeproof_verify_batch", results, min_value, max_value, src, n);
+    uint64_t ticket = 0;
+    {
+        std::lock_guard<std::recursive_mutex> lock(e->mu);
+        HIPCHK(hipSetDevice(e->device));
+        if (!rp_host_submit(e, "secp256k1_rangeproof_verify_batch", &ticket, results, min_value, max_value, src, n)) return 0;
+    }
+    return rp_host_wait(e, "secp256k1_rangeproof_verify_batch", ticket);
 }
 extern "C" int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs,
                                                       const unsigned char* const* proofs, const size_t* plens, const unsigned char* const* extra, const size_t* elens,
                                                       const void* const* gen_objs, size_t n) {
-    if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_ptrs", "null engine");
+    const char* who = "secp256k1_rangeproof_verify_batch_ptrs";
+    if (!e) return s2k_fail(who, "null engine");
     if (n == 0) return 1;
-    if (!results || !min_value || !max_value || !commit_objs || !proofs || !plens || !gen_objs || (extra && !elens))
-        return s2k_fail_arg("secp256k1_rangeproof_verify_batch_ptrs", "illegal argument (ARG_CHECK)");
-    for (size_t i = 0; i < n; i++) if (!commit_objs[i] || !gen_objs[i] || (!proofs[i] && plens[i]) || (extra && !extra[i] && elens[i]))
-        return s2k_fail_arg("secp256k1_rangeproof_verify_batch_ptrs", "illegal argument (ARG_CHECK): null item");
+    if (!rp_ptrs_check(who, results, min_value, max_value, commit_objs, proofs, plens, extra, elens, gen_objs, n)) return 0;
     memset(results, 0, sizeof(int32_t) * n);
-    std::lock_guard<std::recursive_mutex> lock(e->mu);
-    HIPCHK(hipSetDevice(e->device));
     rp_host_src src{}; src.commit_objs = commit_objs; src.proof_ptrs = proofs; src.plens = plens; src.extra_ptrs = extra; src.elens = elens; src.gen_objs = gen_objs;
-    return rp_host_run(e, "secp256k1_rangeproof_verify_batch_ptrs", results, min_value, max_value, src, n);
+    uint64_t ticket = 0;
+    {
+        std::lock_guard<std::recursive_mutex> lock(e->mu);
+        HIPCHK(hipSetDevice(e->device));
+        if (!rp_host_submit(e, who, &ticket, results, min_value, max_value, src, n)) return 0;
+    }
+    return rp_host_wait(e, who, ticket);
 }
 // rewind: verification + recovery (rangeproof_rewind.h); host buffers
 extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, unsigned char* blind_out, uint64_t* value_out, unsigned char* message_out,

@@ -22,7 +22,7 @@ class Backend(ctypes.Structure):
     """struct secp256k1_amd_backend (integration/secp256k1_amd_hook.h)"""
     _fields_ = [("engine", _vp), ("rangeproof_verify_batch", _vp), ("ecmult_multi", _vp), ("schnorrsig_verify_batch", _vp),
                 ("surjectionproof_verify_batch", _vp), ("pedersen_verify_tally_batch", _vp), ("schnorrsig_aggverify", _vp), ("rangeproof_rewind_batch", _vp), ("rangeproof_verify_batch_ptrs", _vp), ("ecmult_batch", _vp),
-                ("bppp_norm_product_verify_batch", _vp)]
+                ("bppp_norm_product_verify_batch", _vp), ("rangeproof_verify_batch_ptrs_submit", _vp), ("rangeproof_verify_batch_wait", _vp)]
 
 
 def fnptr(cfunc):
@@ -47,6 +47,8 @@ class Hooked:
         L.secp256k1_amd_set_backend.argtypes = [_vp]; L.secp256k1_amd_set_backend.restype = None
         L.secp256k1_amd_stats.argtypes = [ctypes.POINTER(_sz), ctypes.POINTER(_sz)]
         L.secp256k1_amd_rangeproof_verify_batch.argtypes = [_vp] * 10 + [_sz]
+        L.secp256k1_amd_rangeproof_verify_batch_submit.argtypes = [_vp] * 11 + [_sz]
+        L.secp256k1_amd_rangeproof_verify_batch_wait.argtypes = [_vp, ctypes.c_uint64]
         L.secp256k1_amd_schnorrsig_verify_batch.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp, _sz]
         L.secp256k1_amd_surjectionproof_verify_batch.argtypes = [_vp] * 6 + [_sz]
         L.secp256k1_amd_pedersen_verify_tally_batch.argtypes = [_vp] * 6 + [_sz]
@@ -62,15 +64,17 @@ class Hooked:
         self.ctx = L.secp256k1_context_create(self.SECP256K1_CONTEXT_NONE)
         self._keep = None
 
-    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None, rangeproof_ptrs=None, ecmult_batch=None, bppp_batch=None):
+    def set_backend(self, engine=None, rangeproof=None, msm=None, schnorr=None, surjection=None, tally=None, aggverify=None, rewind=None, rangeproof_ptrs=None, ecmult_batch=None, bppp_batch=None,
+                    rangeproof_submit=None, rangeproof_wait=None):
         """install function pointers (ctypes callbacks or raw addresses); all None -> CPU library"""
         def addr(f):
             return f if isinstance(f, int) or f is None else fnptr(f)
-        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch)):
+        if all(f is None for f in (rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch, rangeproof_submit, rangeproof_wait)):
             self.lib.secp256k1_amd_set_backend(None); self._keep = None
             return
-        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind), addr(rangeproof_ptrs), addr(ecmult_batch), addr(bppp_batch))
-        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch)
+        b = Backend(engine, addr(rangeproof), addr(msm), addr(schnorr), addr(surjection), addr(tally), addr(aggverify), addr(rewind), addr(rangeproof_ptrs), addr(ecmult_batch), addr(bppp_batch),
+                    addr(rangeproof_submit), addr(rangeproof_wait))
+        self._keep = (b, rangeproof, msm, schnorr, surjection, tally, aggverify, rewind, rangeproof_ptrs, ecmult_batch, bppp_batch, rangeproof_submit, rangeproof_wait)
         self.lib.secp256k1_amd_set_backend(ctypes.byref(b))
 
     def stats(self):
@@ -93,6 +97,25 @@ class Hooked:
             ep = _ptr_array(ebufs); el = (_sz * n)(*[len(e) for e in extra])
         r = self.lib.secp256k1_amd_rangeproof_verify_batch(self.ctx, res, mn.ctypes.data, mx.ctypes.data, cp, pp, plens, ep, el, gp, n)
         assert r == 1
+        return np.array(list(res), np.int32), mn, mx
+
+    def rangeproof_verify_batch_submit(self, commits33, plist, gens64):
+        """asynchronous adapter: -> ticket object for rangeproof_verify_batch_wait (which returns results, min, max)"""
+        n = len(plist)
+        cobj = np.zeros((n, 64), np.uint8); cobj[:, :33] = np.ascontiguousarray(commits33, np.uint8).reshape(n, 33)
+        gobj = np.ascontiguousarray(gens64, np.uint8).reshape(n, 64).copy()
+        pbufs = [np.frombuffer(p if len(p) else b"\0", np.uint8).copy() for p in plist]
+        plens = (_sz * n)(*[len(p) for p in plist])
+        cp = _ptr_array([cobj[i] for i in range(n)]); gp = _ptr_array([gobj[i] for i in range(n)]); pp = _ptr_array(pbufs)
+        res = (_int * n)(); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        tk = ctypes.c_uint64(0)
+        r = self.lib.secp256k1_amd_rangeproof_verify_batch_submit(self.ctx, ctypes.byref(tk), res, mn.ctypes.data, mx.ctypes.data, cp, pp, plens, None, None, gp, n)
+        assert r == 1
+        return (tk.value, res, mn, mx)
+
+    def rangeproof_verify_batch_wait(self, ticket):
+        tk, res, mn, mx = ticket
+        assert self.lib.secp256k1_amd_rangeproof_verify_batch_wait(self.ctx, ctypes.c_uint64(tk)) == 1
         return np.array(list(res), np.int32), mn, mx
 
     def rangeproof_rewind_batch(self, commits33, plist, gens64, nonces, msg_capacity=4096):

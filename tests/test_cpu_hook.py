@@ -408,3 +408,33 @@ def test_msm_min_terms_default_keeps_small_sums_on_the_cpu(hk, ref):
     finally:
         hk.set_msm_min_terms(0)
         hk.set_backend()
+
+
+def test_asynchronous_adapter_without_a_backend(hk, ref):
+    """secp256k1_amd_rangeproof_verify_batch_submit / _wait with no backend installed (and with only half of the pair): the library's
+    own loop runs at submission time, the ticket is 0, waiting for it is a no-op -- same verdicts as the synchronous adapter."""
+    rng = np.random.default_rng(515)
+    commits, proofs, gens, _ = ref.make_rangeproofs(5, rng, min_bits=8)
+    plist = list(proofs); bad = bytearray(plist[2]); bad[40] ^= 1; plist[2] = bytes(bad)
+    exp = ref.rangeproof_verify_many(commits, plist, gens)
+    hk.set_backend()
+    t = hk.rangeproof_verify_batch_submit(commits, plist, gens)
+    assert t[0] == 0
+    r = hk.rangeproof_verify_batch_wait(t)
+    assert np.array_equal(r[0], exp[0]) and np.array_equal(r[1], exp[1]) and np.array_equal(r[2], exp[2]) and r[0].sum() == 4
+    calls = []
+    def sub(engine, ticket, *a):
+        calls.append(1)
+        return 0
+    SUB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, *([ctypes.c_void_p] * 9), ctypes.c_size_t)
+    WAIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64)
+    fs, fw = SUB(sub), WAIT(lambda e, t: 0)
+    s0 = hk.stats()
+    hk.set_backend(rangeproof_submit=fs)                                 # half a pair: not used
+    t = hk.rangeproof_verify_batch_submit(commits, plist, gens)
+    assert t[0] == 0 and not calls and hk.stats() == s0
+    hk.set_backend(rangeproof_submit=fs, rangeproof_wait=fw)             # a backend that refuses: fallback at submission time
+    t = hk.rangeproof_verify_batch_submit(commits, plist, gens)
+    assert t[0] == 0 and calls == [1] and hk.stats() == (s0[0], s0[1] + 1)
+    assert np.array_equal(hk.rangeproof_verify_batch_wait(t)[0], exp[0])
+    hk.set_backend()

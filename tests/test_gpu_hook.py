@@ -293,3 +293,64 @@ def test_concurrent_verifier_threads_on_one_engine(hk, engine, ref):
     assert errors == []
     assert hk.stats()[1] == hk.stats()[1]          # (no fallbacks are expected, but a fallback would still have produced the reference's verdicts)
     hk.set_backend()
+
+
+def test_asynchronous_pair_through_the_hook_and_the_c_abi(hk, engine, ref):
+    """submit / wait: two batches in flight give, batch by batch, the verdicts of the synchronous call; tickets are single-use, a third
+    submission is refused, the inputs may be overwritten as soon as submit has returned; without a backend the adapter verifies at
+    submission time and hands out ticket 0."""
+    rng = np.random.default_rng(611)
+    c, plist, g = _workload(ref, rng)
+    exp = ref.rangeproof_verify_many(c, plist, g)
+    c2, p2, g2, _ = ref.make_rangeproofs(40, rng, min_bits=10)
+    p2 = list(p2); bad = bytearray(p2[7]); bad[60] ^= 2; p2[7] = bytes(bad)
+    exp2 = ref.rangeproof_verify_many(c2, p2, g2)
+    # C ABI, packed form, through the Python wrapper
+    for rounds in range(2):
+        t1 = engine.rangeproof_verify_batch_submit(c, plist, g)
+        t2 = engine.rangeproof_verify_batch_submit(c2, p2, g2)
+        with pytest.raises(Exception):
+            engine.rangeproof_verify_batch_submit(c2, p2, g2)                  # two in flight already
+        assert engine._lib.s2k_last_status() == 2                              # an argument error, not an engine failure
+        order = (t2, t1) if rounds else (t1, t2)
+        got = {t[0]: engine.rangeproof_verify_batch_wait(t) for t in order}
+        for t, e in ((t1, exp), (t2, exp2)):
+            r = got[t[0]]
+            assert np.array_equal(r[0], e[0]) and np.array_equal(r[1], e[1]) and np.array_equal(r[2], e[2])
+        with pytest.raises(Exception):
+            engine.rangeproof_verify_batch_wait(t1)                             # waited for already
+    # a long chain, submit(k+1) before wait(k), alternating workloads; the synchronous call in between two chains
+    work = [(c, plist, g, exp), (c2, p2, g2, exp2)]
+    prev = None
+    for k in range(7):
+        w = work[k & 1]
+        cur = (engine.rangeproof_verify_batch_submit(w[0], w[1], w[2]), w[3])
+        if prev is not None:
+            r = engine.rangeproof_verify_batch_wait(prev[0])
+            assert np.array_equal(r[0], prev[1][0]) and np.array_equal(r[2], prev[1][2])
+        prev = cur
+    r = engine.rangeproof_verify_batch_wait(prev[0])
+    assert np.array_equal(r[0], prev[1][0])
+    r = engine.rangeproof_verify_batch(c2, p2, g2)
+    assert np.array_equal(r[0], exp2[0])
+    # the adapters, reference types
+    L = engine._lib
+    addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
+    hk.set_backend(engine=engine._h, rangeproof_ptrs=addr("secp256k1_rangeproof_verify_batch_ptrs"),
+                   rangeproof_submit=addr("secp256k1_rangeproof_verify_batch_ptrs_submit"), rangeproof_wait=addr("secp256k1_rangeproof_verify_batch_wait"))
+    s0 = hk.stats()
+    ta = hk.rangeproof_verify_batch_submit(c, plist, g)
+    tb = hk.rangeproof_verify_batch_submit(c2, p2, g2)
+    assert ta[0] != 0 and tb[0] != 0 and ta[0] != tb[0]
+    ra = hk.rangeproof_verify_batch_wait(ta); rb = hk.rangeproof_verify_batch_wait(tb)
+    assert hk.stats() == (s0[0] + 2, s0[1])
+    assert np.array_equal(ra[0], exp[0]) and np.array_equal(ra[1], exp[1]) and np.array_equal(ra[2], exp[2])
+    assert np.array_equal(rb[0], exp2[0]) and np.array_equal(rb[2], exp2[2])
+    # refused submission (NULL engine) -> verified on the CPU at submission time, ticket 0
+    hk.set_backend(engine=None, rangeproof_submit=addr("secp256k1_rangeproof_verify_batch_ptrs_submit"), rangeproof_wait=addr("secp256k1_rangeproof_verify_batch_wait"))
+    s0 = hk.stats()
+    tc = hk.rangeproof_verify_batch_submit(c2, p2, g2)
+    assert tc[0] == 0 and hk.stats() == (s0[0], s0[1] + 1)
+    rc = hk.rangeproof_verify_batch_wait(tc)
+    assert np.array_equal(rc[0], exp2[0]) and np.array_equal(rc[2], exp2[2])
+    hk.set_backend()
