@@ -146,7 +146,8 @@ def measure_dropin(eng, commits, proofs, gens, steps):
         if os.path.exists(hookapi.HOOKED_PATH):
             hk = hookapi.Hooked()
             addr = lambda name: ctypes.cast(getattr(L, name), ctypes.c_void_p).value
-            hk.set_backend(engine=eng._h, rangeproof=addr("secp256k1_rangeproof_verify_batch"), rangeproof_ptrs=addr("secp256k1_rangeproof_verify_batch_ptrs"))
+            hk.set_backend(engine=eng._h, rangeproof=addr("secp256k1_rangeproof_verify_batch"), rangeproof_ptrs=addr("secp256k1_rangeproof_verify_batch_ptrs"),
+                           rangeproof_submit=addr("secp256k1_rangeproof_verify_batch_ptrs_submit"), rangeproof_wait=addr("secp256k1_rangeproof_verify_batch_wait"))
             cobj = np.zeros((n, 64), np.uint8); cobj[:, :33] = c.reshape(n, 33)
             gobj = g.reshape(n, 64).copy()
             pbufs = [np.frombuffer(p, np.uint8).copy() for p in proofs]            # every proof its own allocation, as a caller's objects would be
@@ -166,6 +167,28 @@ def measure_dropin(eng, commits, proofs, gens, steps):
             assert all(r32[i] == 1 for i in range(0, n, 97)) and int(mx2.min()) == 2**64 - 1
             out["hooked_reference_types"] = {"entry": "secp256k1_amd_rangeproof_verify_batch (libsecp256k1_hooked.so: the unmodified reference + integration/secp256k1_amd_hook.c)",
                                              "value": n / dth, "ms_per_call": dth * 1e3, "served": s1[0] - s0[0], "fell_back": s1[1] - s0[1]}
+            # (ii') the asynchronous adapters, two batches in flight
+            r32b = [(ctypes.c_int * n)() for _ in range(2)]; mnb = [np.zeros(n, np.uint64) for _ in range(2)]; mxb = [np.zeros(n, np.uint64) for _ in range(2)]
+            def hsubmit(k):
+                tk = ctypes.c_uint64(0)
+                assert hk.lib.secp256k1_amd_rangeproof_verify_batch_submit(hk.ctx, ctypes.byref(tk), r32b[k & 1], mnb[k & 1].ctypes.data, mxb[k & 1].ctypes.data,
+                                                                           cp, pp, plens, None, None, gp, n) == 1
+                assert tk.value != 0, "the hook verified on the CPU at submission time"
+                return tk.value
+            def hwait(tk):
+                assert hk.lib.secp256k1_amd_rangeproof_verify_batch_wait(hk.ctx, ctypes.c_uint64(tk)) == 1
+            hwait(hsubmit(0))
+            t = time.perf_counter()
+            prev = hsubmit(0)
+            for k in range(1, k2):
+                cur = hsubmit(k)
+                hwait(prev)
+                prev = cur
+            hwait(prev)
+            dtb = (time.perf_counter() - t) / k2
+            assert all(r32b[j][i] == 1 for j in range(2) for i in range(0, n, 97)) and int(mxb[1].min()) == 2**64 - 1
+            out["hooked_two_in_flight"] = {"entry": "secp256k1_amd_rangeproof_verify_batch_submit / _wait (reference types, submit(k+1) before wait(k))",
+                                           "value": n / dtb, "ms_per_call": dtb * 1e3, "batches": k2}
             hk.set_backend()
     except OSError as ex:
         out["hooked_reference_types"] = {"skipped": str(ex)}

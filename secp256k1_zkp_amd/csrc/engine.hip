@@ -1357,7 +1357,6 @@ k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned cha
 // The top window's few values would put n/2 points into each of a handful of buckets, and the depth of the partial-sum rounds follows
 // the fullest region: so every value v of the top window is SPREAD over `sub` buckets, (v - 1) * sub + (term index mod sub) + 1 --
 // all with the weight v (msm_bucket_weight) -- which brings the top window's regions down to the size of the others.
-struct msm_layout { u32 cap, cap_top, top_used, sub; };     // top_used: buckets 0..top_used-1 of the top window have a region; sub: power of two
 __host__ __device__ __forceinline__ u32 msm_bucket_weight(const msm_layout& L, const msm_plan& pl, u32 k) {      // k = w * nb + b, w local to the share
     const u32 b = k % pl.nb;
     const int top = (pl.w0 + k / pl.nb + 1 == pl.windows);
@@ -1501,6 +1500,38 @@ k_msm_finish(u32* bucket_out28, const u32* in28, const u32* off_last, u32 nk, ms
     msm_scale(o, v, b);
     gej_store28(bucket_out28 + (size_t)k * 28, o);
 }
+// Small inputs (msm_make_plan keeps every bucket region within MSM_ONE_ROUND_CAP references): rounds, bucket weights and the first level
+// of the window sums in ONE launch -- workgroup (chunk of 256 buckets, window), a lane per bucket: the bucket's references summed, the sum
+// scaled by the bucket's weight, a tree over the workgroup.  Replaces counts + scan + round 1 + finish + the first tree level: these
+// sizes are a chain of latency-bound stages, and what counts is how many there are.
+__global__ void __launch_bounds__(256)
+k_msm_small_windows(u32* out28, const u32* refs, const u32* gcnt, const u32* term, msm_plan pl, msm_layout L, u32 nchunks) {
+    __shared__ u32 sh[256 * 28];
+    const u32 w = blockIdx.y, t = threadIdx.x, b = 1u + blockIdx.x * 256u + t;
+    gej o; gej_set_infinity(o);
+    if (b < pl.nb) {
+        const u32 k = w * pl.nb + b;
+        const int top = (pl.w0 + w + 1 == pl.windows);
+        const u32 cap = top ? (b < L.top_used ? L.cap_top : 0u) : L.cap;
+        u32 cnt = gcnt[k]; cnt = cnt < cap ? cnt : cap;            // (an overflowing region raised the flag: the result comes from the exact path)
+        if (cnt) {
+            const size_t first = msm_region(L, pl, w, b);
+            gej v; msm_sum_refs(v, refs, first, first + cnt, term);
+            msm_scale(o, v, msm_bucket_weight(L, pl, k));
+        }
+    }
+    gej_store28(sh + t * 28, o);
+    __syncthreads();
+    for (u32 d = 128; d >= 1; d >>= 1) {
+        if (t < d) {
+            gej a, c, r; gej_load28(a, sh + t * 28); gej_load28(c, sh + (t + d) * 28);
+            gej_add_var(r, a, c);
+            gej_store28(sh + t * 28, r);
+        }
+        __syncthreads();
+    }
+    if (t < 28) out28[((size_t)w * nchunks + blockIdx.x) * 28 + t] = sh[t];
+}
 // segmented tree sum: block (seg, chunk) adds up items [chunk*per_block, ...) of segment `seg` (seg_len items each).  BS lanes per block:
 // 256 for long segments; 64 (one wavefront, six tree levels instead of eight, a quarter of the LDS) when a segment has at most 256
 // items -- the per-proof sums of the BP++ verifier (~80 terms), the per-window sums of a small MSM -- where most of a 256-lane
@@ -1538,8 +1569,9 @@ k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
     gej r; msm_combine(r, wsum28, pl);
     if (threadIdx.x == 0) gej_store28(out28, r);
 }
-// exact path: final <- exact result when the binning pass overflowed a bucket region
-__global__ void k_msm_pick(u32* final28, const u32* exact28, const u32* flags) {
+// exact path: final <- exact result when the binning pass overflowed a bucket region; the flag goes to the engine's status word
+__global__ void k_msm_pick(u32* final28, const u32* exact28, const u32* flags, u32* dev_flags) {
+    if (threadIdx.x == 0) dev_flags[0] = flags[0];
     if (flags[0] == 0) return;
     for (int i = threadIdx.x; i < 28; i += blockDim.x) final28[i] = exact28[i];
 }
@@ -1588,30 +1620,6 @@ static const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u3
     }
     return cur;
 }
-// bucket-region capacity of the fixed-capacity layout: the mean load plus ten standard deviations of a uniform digit
-static u32 msm_cap_for(double mean) {
-    double sd = 1.0; while (sd * sd < mean) sd += 1.0;
-    size_t cap = (size_t)(mean + 10.0 * sd) + 8;
-    return (u32)((cap + 7) & ~size_t(7));
-}
-static msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
-    msm_layout L;
-    const double mean = 2.0 * (double)nt / (double)(pl.nb - 1);
-    L.cap = msm_cap_for(mean);
-    const u32 top_bits = 128u - pl.c * (pl.windows - 1);              // live bits of the top window (0: only the carry reaches it)
-    const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
-    // |k1| and |k2| stay below ~2^127.4 and ~2^126.9 (the GLV lattice bounds), so the top window's values are not uniform:
-    // the low ones carry up to ~1.9x the uniform share.  4x (never more than every reference) leaves the same margin as below.
-    double mean_top = 8.0 * (double)nt / (double)top_vals; if (mean_top > 2.0 * (double)nt) mean_top = 2.0 * (double)nt;
-    // spread every value over `sub` buckets (see msm_layout) until its regions are about as full as the other windows', as far as the
-    // window's nb - 1 bucket slots go
-    u32 sub = 1;
-    while (sub * 2 * top_vals <= pl.nb - 1 && mean_top / (double)sub > 1.5 * mean) sub *= 2;
-    L.sub = sub;
-    L.top_used = top_vals * sub + 1;
-    L.cap_top = msm_cap_for(mean_top / (double)sub);
-    return L;
-}
 static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
     if (pl.wn == 0) return 8;
     const int has_top = (pl.w0 + pl.wn == pl.windows);
@@ -1619,8 +1627,11 @@ static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
 }
 // run lengths of the partial-sum rounds: round 1 sums up to T references per lane (about 1.3e5 lanes' worth at the largest
 // sizes), later rounds up to MSM_T2 partial sums -- short, because there are only a few per bucket left and lanes are scarce
-static u32 msm_run_len(size_t E) {
+static u32 msm_run_len(size_t E, const msm_plan& pl, const msm_layout& L) {
     if (const char* t = getenv("S2K_MSM_T")) { const int v = atoi(t); if (v >= 2 && v <= 1024) return (u32)v; }      // diagnostic override
+    // small inputs (the plan keeps their bucket regions short): one lane per bucket takes the whole region, no second round
+    const u32 maxcap = msm_max_cap(pl, L);
+    if (maxcap <= MSM_ONE_ROUND_CAP) return maxcap;
     // ~6 lanes per resident lane slot (131 072) at the largest sizes, so that the last, partly filled round of workgroups is a small share
     // (measured at 2^20 terms: T = 24 2.17 ms, T = 128 2.33 ms; at 2^22: T = 48 7.26 ms, T = 128 7.38 ms)
     u32 T = (u32)(E / 786432); if (T < 8) T = 8; if (T > 64) T = 64; return T;
@@ -1630,7 +1641,7 @@ static u32 msm_run_len(size_t E) {
 static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
-    const size_t T = msm_run_len(E); const msm_layout L = msm_make_layout(nt, pl);
+    const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(E, pl, L);
     return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
                     msm_refs_words(pl, L) * 4, nk * 28 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
                     (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2}) + 32 * 256;
@@ -1683,7 +1694,9 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     if (!engine_ptab(e, MSM_DIRECT_LANES)) return 0;
     const u32 nk = pl.wn * pl.nb;
     const size_t E = nt * 2 * pl.wn;                           // upper bound on this share's bucket references
-    const u32 T = msm_run_len(nt * 2 * pl.windows), T2 = MSM_T2; const msm_layout L = msm_make_layout(nt, pl);
+    const msm_layout L = msm_make_layout(nt, pl);
+    const msm_plan full = msm_make_plan(nt);                   // (run length as msm_ws_bytes sized the buffers for: from the whole plan, not the share)
+    const u32 T = msm_run_len(nt * 2 * pl.windows, full, L), T2 = MSM_T2;
     const size_t bound1 = (size_t)nk + E / T + 2;
     u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
     u32* gcnt = c.take<u32>(nk + 1); u32* gclamp = c.take<u32>(nk + 1); u32* spare = c.take<u32>(nk + 1);
@@ -1704,6 +1717,16 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, e->stream2, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
     const u32* ex = launch_gej_reduce(e->stream2, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
     HIPCHK(hipEventRecord(e->ev_msm_join, e->stream2));
+    if (msm_max_cap(full, L) <= MSM_ONE_ROUND_CAP && !getenv("S2K_MSM_NO_SMALL")) {
+        const u32 nchunks = (pl.nb - 1 + 255) / 256;
+        hipLaunchKernelGGL(k_msm_small_windows, dim3(nchunks, pl.wn), dim3(256), 0, st, partA, refs_cap, gcnt, term, pl, L, nchunks);
+        const u32* wsum = launch_gej_reduce(st, partA, bufA, bufB, pl.wn, nchunks);
+        hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
+        HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
+        hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
+        HIPCHK(hipGetLastError());
+        return 1;
+    }
     hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl);
     // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
     const int has_top = (pl.w0 + pl.wn == pl.windows);
@@ -1729,8 +1752,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
     HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
-    hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags);
-    hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
+    hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
     HIPCHK(hipGetLastError());
     return 1;
 }

@@ -29,6 +29,7 @@
 #pragma once
 #include "gtable.h"
 #include "cofield.h"
+#include <cstdlib>
 
 #define MSM_SMALL_N 32
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
@@ -40,11 +41,59 @@
 // the shares simply add up.
 struct msm_plan { u32 c; u32 windows; u32 nb; u32 w0; u32 wn; };
 
+// Fixed-capacity bucket regions (binning pass, engine.hip): see k_msm_bin.  top_used: buckets 0..top_used-1 of the top window have a
+// region; sub: power of two (every value of the top window is spread over `sub` buckets).
+struct msm_layout { u32 cap, cap_top, top_used, sub; };     // top_used: buckets 0..top_used-1 of the top window have a region; sub: power of two
+// bucket-region capacity of the fixed-capacity layout: the mean load plus ten standard deviations of a uniform digit
+static inline u32 msm_cap_for(double mean) {
+    double sd = 1.0; while (sd * sd < mean) sd += 1.0;
+    size_t cap = (size_t)(mean + 10.0 * sd) + 8;
+    return (u32)((cap + 7) & ~size_t(7));
+}
+static inline msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
+    msm_layout L;
+    const double mean = 2.0 * (double)nt / (double)(pl.nb - 1);
+    L.cap = msm_cap_for(mean);
+    const u32 top_bits = 128u - pl.c * (pl.windows - 1);              // live bits of the top window (0: only the carry reaches it)
+    const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
+    // |k1| and |k2| stay below ~2^127.4 and ~2^126.9 (the GLV lattice bounds), so the top window's values are not uniform:
+    // the low ones carry up to ~1.9x the uniform share.  4x (never more than every reference) leaves the same margin as below.
+    double mean_top = 8.0 * (double)nt / (double)top_vals; if (mean_top > 2.0 * (double)nt) mean_top = 2.0 * (double)nt;
+    // spread every value over `sub` buckets (see msm_layout) until its regions are about as full as the other windows', as far as the
+    // window's nb - 1 bucket slots go
+    u32 sub = 1;
+    while (sub * 2 * top_vals <= pl.nb - 1 && mean_top / (double)sub > 1.5 * mean) sub *= 2;
+    L.sub = sub;
+    L.top_used = top_vals * sub + 1;
+    L.cap_top = msm_cap_for(mean_top / (double)sub);
+    return L;
+}
+static inline u32 msm_max_cap(const msm_plan& pl, const msm_layout& L) {
+    const int has_top = (pl.w0 + pl.wn == pl.windows);
+    const u32 a = pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, b = has_top ? L.cap_top : 0u;
+    return a > b ? a : b;
+}
+static inline msm_plan msm_plan_for(u32 c) {
+    msm_plan p; p.c = c; p.windows = (129 + c - 1) / c; p.nb = (1u << (c - 1)) + 1u; p.w0 = 0; p.wn = p.windows;
+    return p;
+}
+// Window width.  Large inputs: the width that minimises the work W*(2n + 23*2^(c-1)), capped by the binning pass's LDS histogram (13).
+// Below 2^14 terms the call is a chain of latency-bound stages whatever c is, and what counts is their number: the smallest width (from
+// 7) whose bucket regions are short enough for ONE round of partial sums (a lane per bucket walks its whole region: no counts / scan /
+// second and third round), which also means fewer windows for the Horner tail.  In between: measured (profiles/r03c_msm_c_sweep.txt).
+#define MSM_ONE_ROUND_CAP 40u
 static inline msm_plan msm_make_plan(size_t n_terms) {
     u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n_terms) lg++;
-    int c = (int)lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;      // minimises W*(2n + 23*2^(c-1)) over the sizes of interest
-    msm_plan p; p.c = (u32)c; p.windows = (129 + c - 1) / c; p.nb = (1u << (c - 1)) + 1u; p.w0 = 0; p.wn = p.windows;
-    return p;
+    int c = (int)lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
+    if (lg <= 13) {
+        c = 13;
+        for (int t = 7; t <= 13; t++) { const msm_plan p = msm_plan_for((u32)t); if (msm_max_cap(p, msm_make_layout(n_terms, p)) <= MSM_ONE_ROUND_CAP) { c = t; break; } }
+    } else if (lg <= 15) c = 10;
+    else if (lg <= 17) c = 12;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (const char* o = getenv("S2K_MSM_C")) { const int v = atoi(o); if (v >= 4 && v <= 13) c = v; }      // diagnostic override
+#endif
+    return msm_plan_for((u32)c);
 }
 // share `part` of `parts` of the windows (contiguous, sizes differ by at most one; parts > windows leaves some shares empty)
 static inline void msm_plan_share(msm_plan& p, u32 part, u32 parts) {

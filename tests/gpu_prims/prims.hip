@@ -69,13 +69,14 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
     } break;
     case 39: {   // wave-cooperative field arithmetic (cofield.h) against the integers / the reference: one item per WAVEFRONT (n = 64 * items,
                  // 64-lane blocks).  a, b: 9 raw limbs each (lazy magnitudes chosen by the test), c: an affine point.
-                 // out (192 bytes per item, written by lane 0): a*b | a*b + b*b | b - 3a/2 | 2^13 * c (x, y)
+                 // out (288 bytes per item, written by lane 0): a*b | a*b + b*b | b - 3a/2 | 2^13 * c (x, y) | grouped product: a*b | b*b | a*a
         const int it = i >> 6;
         fe fa, fb; for (int k = 0; k < 9; k++) { fa.n[k] = ((const u32*)a)[9 * it + k]; fb.n[k] = ((const u32*)b)[9 * it + k]; }
         cfe ca, cb, r1, r2, r3; cfe_from_fe(ca, fa); cfe_from_fe(cb, fb);
         cfe_mul(r1, ca, cb);
         cfe_muladd(r2, ca, cb, cb, cb);
         r3 = ca; cfe_mul_int(r3, 3); cfe_half(r3); cfe_norm_weak(r3); cfe_neg(r3, r3, 1); cfe_add(r3, cb); cfe_norm_weak(r3);
+        cfe m3, g0, g1, g2; cfe_mul3(m3, ca, cb, cb, cb, ca, ca); cfe_pick(g0, m3, 0); cfe_pick(g1, m3, 1); cfe_pick(g2, m3, 2);
         ge p; fe_set_b32_mod(p.x, c + 64 * it); fe_set_b32_mod(p.y, c + 64 * it + 32);
         gej j; gej_set_ge(j, p); gej_double_n_cooperative(j, 13);
         ge o; ge_set_gej(o, j);
@@ -96,10 +97,14 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         }
         fe q1, q2, q3; cfe_to_fe(q1, r1); cfe_to_fe(q2, r2); cfe_to_fe(q3, r3);
         // lanes >= 9 must still hold zero
-        const u32 stray = (co_lane() >= 9) ? (r1.v | r2.v | r3.v) : 0u;
+        fe q4, q5, q6; cfe_to_fe(q4, g0); cfe_to_fe(q5, g1); cfe_to_fe(q6, g2);
+        // the three copies of a replicated element agree
+        const u32 differ = (g0.v ^ co_bcast(g0.v, 1)) | (g1.v ^ co_bcast(g1.v, 2)) | (r1.v ^ co_bcast(r1.v, 2)) | (r3.v ^ co_bcast(r3.v, 1));
+        const u32 stray = ((co_lane() >= 9) ? (r1.v | r2.v | r3.v | g0.v | g1.v | g2.v) : 0u) | differ;
         const int clean = !__any((int)(stray != 0u));
         if ((i & 63) == 0) {
-            unsigned char* w = out + 192 * it;
+            unsigned char* w = out + 288 * it;
+            fe_normalize(q4); fe_get_b32(w + 192, q4); fe_normalize(q5); fe_get_b32(w + 224, q5); fe_normalize(q6); fe_get_b32(w + 256, q6);
             fe_normalize(q1); fe_get_b32(w, q1); fe_normalize(q2); fe_get_b32(w + 32, q2); fe_normalize(q3); fe_get_b32(w + 64, q3);
             fe_normalize(o.x); fe_normalize(o.y); fe_get_b32(w + 96, o.x); fe_get_b32(w + 128, o.y);
             flag[i] = clean | addok;

@@ -294,7 +294,7 @@ def test_cooperative_field_arithmetic(prims, ref):
     mags = [(1, 1), (2, 1), (1, 2), (2, 1), (1, 1), (1, 2)]
     for it in range(items):
         ma, mb = mags[it % len(mags)]
-        assert ma * mb + mb * mb <= 7 and 3 * ma <= 7
+        assert ma * mb + mb * mb <= 7 and 3 * ma <= 7 and ma * ma <= 7
         a = int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "big") % P
         b = int.from_bytes(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), "big") % P
         if it < 8:
@@ -302,12 +302,14 @@ def test_cooperative_field_arithmetic(prims, ref):
         la, lb = rep(a, ma, full=(it % 16 == 9)), rep(b, mb, full=(it % 16 == 9 or it % 16 == 10))
         A[it] = la; B[it] = lb
         a, b = val(la) % P, val(lb) % P
-        want.append((a * b % P, (a * b + b * b) % P, (b - 3 * a * pow(2, -1, P)) % P))
+        want.append((a * b % P, (a * b + b * b) % P, (b - 3 * a * pow(2, -1, P)) % P, a * b % P, b * b % P, a * a % P))
     dbl, _ = ref.ecmult_batch(pts, np.tile(np.frombuffer(_b(2**13), np.uint8), (items, 1)))
-    got, flag = prims(39, 64 * items, 3, A.view(np.uint8), B.view(np.uint8), pts)
-    got = got.reshape(-1)[:192 * items].reshape(items, 192)
+    got, flag = prims(39, 64 * items, 5, A.view(np.uint8), B.view(np.uint8), pts)
+    got = got.reshape(-1)[:288 * items].reshape(items, 288)
     assert (flag[::64] == 15).all()                      # bit 0: lanes >= 9 still hold zero after every routine; bits 1-3: the three addition cases
     for it in range(items):
         for k in range(3):
             assert got[it, 32 * k:32 * k + 32].tobytes() == _b(want[it][k]), (it, k)
         assert got[it, 96:160].tobytes() == dbl[it].tobytes(), it
+        for k in range(3):                               # the grouped product (three different products in one pass)
+            assert got[it, 192 + 32 * k:224 + 32 * k].tobytes() == _b(want[it][3 + k]), (it, k)
