@@ -92,7 +92,7 @@ typedef struct secp256k1_amd_backend {
  * Thread safety of the engine behind the table: one s2k_engine serialises its callers (a mutex per engine; their launches share its stream
  * and scratch), so concurrent verifier threads are safe and take turns; give every thread its own engine for parallel submission. */
 void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend);
-/* secp256k1_ecmult_multi_var calls with fewer terms than this stay on the CPU (default 256: an engine round trip costs ~0.65 ms whatever
+/* secp256k1_ecmult_multi_var calls with fewer terms than this stay on the CPU (default 256: an engine round trip costs ~0.45-0.6 ms whatever
  * the size, the CPU ~3-6 us per term); 0 sends everything to the engine. */
 void secp256k1_amd_set_msm_min_terms(size_t n);
 /* Counters for tests / monitoring: batches served by the backend, batches that fell back to the CPU after a backend failure. */

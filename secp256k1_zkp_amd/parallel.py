@@ -46,6 +46,8 @@ def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
     lo, hi = shard_range(n, rank, world)
+    if world == 1 and hasattr(backend, "msm_whole"):
+        return backend.msm_whole(sc, pt_xy, g_sc, pt_inf, to_host)      # nothing to exchange: the engine's complete call (no partial / sum stage)
     with _chain(backend):
         part = backend.msm_partial(sc[lo:hi], pt_xy[lo:hi], g_sc if rank == 0 else None, None if pt_inf is None else pt_inf[lo:hi])
         return _gather_and_sum(backend, part, group, to_host)
@@ -84,7 +86,7 @@ def msm_window_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, t
         return _gather_and_sum(backend, part, group, to_host)
 
 
-# Terms at which one bucket MSM call stops being pure latency on MI355X (the call costs ~0.65 ms up to 2^16 terms and grows from there:
+# Terms at which one bucket MSM call stops being pure latency on MI355X (the call costs 0.45-0.75 ms up to 2^16 terms and grows from there:
 # profiles/r03*_msm_sweep.txt); a backend may carry its own measured value as `floor_terms`.
 MSM_FLOOR_TERMS = 1 << 16
 
@@ -160,6 +162,22 @@ class EngineBackend:
         self.engine.ecmult_multi_partial_dev(out, sc, pt_xy, g_sc, pt_inf, stream=h)
         self._leave()
         return out
+
+    def msm_whole(self, sc, pt_xy, g_sc, pt_inf, to_host=True):
+        """the whole sum on this GPU (s2k_ecmult_multi_dev): what a one-rank job runs"""
+        import torch
+        r = torch.zeros(64, dtype=torch.uint8, device=self.dev); inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if sc.numel() == 0 and g_sc is None:
+            inf += 1
+        else:
+            sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
+            h = self._enter()
+            self.engine.ecmult_multi_dev(r, inf, sc, pt_xy, g_sc=g_sc, pt_inf=pt_inf, stream=h)
+            self._leave()
+        if not to_host:
+            return r, inf
+        self.stream.synchronize()
+        return r.cpu().numpy(), int(inf.item())
 
     def msm_window_partial(self, sc, pt_xy, g_sc, pt_inf, part, parts):
         import torch
