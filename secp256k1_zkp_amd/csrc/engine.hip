@@ -1709,6 +1709,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
+    if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
     hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
     // empty) launches do not sit behind the Horner tail of every call

@@ -20,7 +20,7 @@ def _points(engine, rng, n):
     return pts
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 50, 191, 192, 193, 1000, 5000, 40000])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 50, 191, 192, 193, 1000, 5000, 8191, 8192, 16384, 40000, 65536, 262144])      # (window width and the fused small-input stage switch at 2^14, 2^16, 2^18 terms)
 def test_msm_sizes(engine, ref, n):
     rng = np.random.default_rng(1000 + n)
     pts = _points(engine, rng, max(n, 1))[:n]
