@@ -1366,14 +1366,18 @@ __host__ __device__ __forceinline__ u32 msm_bucket_weight(const msm_layout& L, c
 __device__ __forceinline__ size_t msm_region(const msm_layout& L, const msm_plan& pl, u32 w, u32 b) {
     return (pl.w0 + w + 1 < pl.windows) ? ((size_t)w * pl.nb + b) * L.cap : (size_t)(pl.wn - 1) * pl.nb * L.cap + (size_t)b * L.cap_top;
 }
+// WIDE (c = 14..16, the largest inputs): 2^(c-1) + 1 counters would not fit the LDS twice, so two 16-bit counters share a word (a chunk
+// has at most 16 384 half-scalars, and a region of these plans fewer than 32 768 slots: msm_make_plan) and the (bucket, rank) pair in
+// registers is 16 + 14 bits instead of 13 + 16.
 #define MSM_BIN_THREADS 1024
+template <int WIDE>
 __global__ void __launch_bounds__(MSM_BIN_THREADS)
 k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt, msm_plan pl, msm_layout L, u32 chunk) {
-    __shared__ u32 s_cnt[4097 + 7];
+    __shared__ u32 s_cnt[(WIDE ? 16385 : 4097) + 7];
     const u32 w = blockIdx.y, tid = threadIdx.x;
     const size_t t0 = (size_t)blockIdx.x * chunk;
     const size_t t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
-    for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) s_cnt[b] = 0;
+    for (u32 b = tid; b < (WIDE ? (pl.nb + 1u) / 2u : pl.nb); b += MSM_BIN_THREADS) s_cnt[b] = 0;
     msm_wconst wc; msm_window_const(wc, pl.w0 + w, pl.c);
     __syncthreads();
     // sweep: digit of every half-scalar of the chunk, rank inside the workgroup from the LDS histogram; the (bucket, rank, sign)
@@ -1399,15 +1403,31 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
                         if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }      // a value the top window cannot hold for a reduced half
                         bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
                     }
-                    const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                    if (WIDE) {
+                        const u32 sh = (bkt & 1u) * 16u;
+                        const u32 rank = (atomicAdd(&s_cnt[bkt >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 14) | rank;
+                    } else {
+                        const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) {
-        const u32 c = s_cnt[b];
-        s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;          // one global atomic per non-empty (workgroup, bucket)
+    if (WIDE) {
+        for (u32 wd = tid; wd < (pl.nb + 1u) / 2u; wd += MSM_BIN_THREADS) {
+            const u32 v = s_cnt[wd], c0 = v & 0xFFFFu, c1 = v >> 16;
+            u32 b0 = c0 ? atomicAdd(&gcnt[w * pl.nb + 2u * wd], c0) : 0u;
+            u32 b1 = c1 ? atomicAdd(&gcnt[w * pl.nb + 2u * wd + 1u], c1) : 0u;
+            b0 = b0 < 49151u ? b0 : 49151u; b1 = b1 < 49151u ? b1 : 49151u;      // (beyond any region of these plans; base + rank stays inside 16 bits)
+            s_cnt[wd] = b0 | (b1 << 16);
+        }
+    } else {
+        for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) {
+            const u32 c = s_cnt[b];
+            s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;          // one global atomic per non-empty (workgroup, bucket)
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -1417,7 +1437,8 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
         for (int half = 0; half < 2; half++) {
             const u32 k = kv[it][half];
             if (k) {
-                const u32 bkt = (k >> 16) & 0x1FFFu, slot = s_cnt[bkt] + (k & 0xFFFFu);
+                const u32 bkt = WIDE ? (k >> 14) & 0xFFFFu : (k >> 16) & 0x1FFFu;
+                const u32 slot = WIDE ? ((s_cnt[bkt >> 1] >> ((bkt & 1u) * 16u)) & 0xFFFFu) + (k & 0x3FFFu) : s_cnt[bkt] + (k & 0xFFFFu);
                 if (slot < (top ? L.cap_top : L.cap) && (!top || bkt < L.top_used)) refs[msm_region(L, pl, w, bkt) + slot] = (u32)(t << 2) | ((u32)half << 1) | (k >> 31);
                 else over = 1;
             }
@@ -1710,7 +1731,8 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
-    hipLaunchKernelGGL(k_msm_bin, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
     // empty) launches do not sit behind the Horner tail of every call
     HIPCHK(hipEventRecord(e->ev_msm_fork, st));

@@ -90,9 +90,14 @@ static inline msm_plan msm_make_plan(size_t n_terms) {
         for (int t = 7; t <= 13; t++) { const msm_plan p = msm_plan_for((u32)t); if (msm_max_cap(p, msm_make_layout(n_terms, p)) <= MSM_ONE_ROUND_CAP) { c = t; break; } }
     } else if (lg <= 15) c = 10;
     else if (lg <= 17) c = 12;
+    else if (lg >= 22) c = 16;      // 9 windows, the ninth only holds the carries: 8.2 bucket additions per half-scalar instead of 10 (k_msm_bin<1>)
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if (const char* o = getenv("S2K_MSM_C")) { const int v = atoi(o); if (v >= 4 && v <= 13) c = v; }      // diagnostic override
+    if (const char* o = getenv("S2K_MSM_C")) { const int v = atoi(o); if (v >= 4 && v <= 16) c = v; }      // diagnostic override
 #endif
+    if (c > 13) {                   // the wide binning pass packs region offsets into 16 bits
+        const msm_plan p = msm_plan_for((u32)c); const msm_layout L = msm_make_layout(n_terms, p);
+        if (L.cap >= 32768u || L.cap_top >= 32768u) c = 13;
+    }
     return msm_plan_for((u32)c);
 }
 // share `part` of `parts` of the windows (contiguous, sizes differ by at most one; parts > windows leaves some shares empty)
