@@ -1446,6 +1446,149 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     }
     if (over) flags[0] = 1u;
 }
+// Two-pass binning for the widest windows (c = 14..16: from 2^22 terms).  With 2^15 buckets per window a workgroup of the single-pass
+// form has one or two references per bucket, every one a lone 4-byte store into its own region, and 2^15 counters to clear, reserve
+// and scan per workgroup.  Here the references first go, as (reference, bucket) pairs, into COARSE bins of 2^shift adjacent buckets --
+// the half-scalar records are read once for all windows -- and then one workgroup per coarse bin distributes its pairs over the bin's
+// buckets, tile by tile through LDS, so that a bucket region is written in runs by exactly one workgroup; the bucket counts come out of
+// that workgroup's running totals (no global atomics per bucket).  2^24 terms: 5.25 -> 3.3 ms; at 2^20 (c = 13) the single pass is as fast.
+struct msm_coarse { u32 shift, nco, cap, cap_top; };          // nco bins per window; cap / cap_top pairs per bin (other windows / top window)
+__host__ __device__ __forceinline__ size_t msm_coarse_region(const msm_coarse& C, const msm_plan& pl, u32 w, u32 co) {
+    return (pl.w0 + w + 1 < pl.windows) ? ((size_t)w * C.nco + co) * C.cap : (size_t)(pl.wn - 1) * C.nco * C.cap + (size_t)co * C.cap_top;
+}
+// exclusive prefix over cnt[0..n) (n <= 320) by the first wavefront: five consecutive bins per lane, a shuffle scan across the lanes
+__device__ __forceinline__ void msm_scan320(u32* off, const u32* cnt, u32 n) {
+    if (threadIdx.x < 64) {
+        const u32 l = threadIdx.x;
+        u32 v[5], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const u32 b = l * 5u + (u32)j; v[j] = b < n ? cnt[b] : 0u; sum += v[j]; }
+        u32 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 x = (u32)__shfl_up((int)inc, d, 64); if (l >= (u32)d) inc += x; }
+        u32 run = inc - sum;
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const u32 b = l * 5u + (u32)j; if (b <= n) off[b] = run; run += v[j]; }
+    }
+}
+// pass 1: a workgroup takes MSM_COARSE_TERMS terms and ALL windows of the share -- the half-scalar records are read once (the single-pass
+// form reads them once per window) and stay in registers for both sweeps: count, reserve (one global atomic per non-empty (window,
+// coarse bin)), write.  (Measured variants, 2^24 terms: this one 2.06 ms; digits from one addition per half, msm_sum_full: 2.46;
+// the pairs ordered in LDS and written in runs: 2.94 -- ten windows x five barriers of a 1 024-lane workgroup cost more than the
+// runs save; one workgroup per window with the ranks kept in registers: 3.27.)
+#define MSM_COARSE_PER_THREAD 2
+#define MSM_COARSE_TERMS (MSM_COARSE_PER_THREAD * MSM_BIN_THREADS)
+#define MSM_COARSE_LDS (9 * 257 + 7)          /* wn * nco: 9 x 257 (c = 16), 9 x 129 (c = 15), 10 x 65 (c = 14) */
+__global__ void __launch_bounds__(MSM_BIN_THREADS)
+k_msm_bin_coarse(unsigned long long* __restrict__ pairs, u32* __restrict__ ccnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt,
+                 msm_plan pl, msm_layout L, msm_coarse C) {
+    __shared__ u32 s_cnt[MSM_COARSE_LDS];
+    const u32 tid = threadIdx.x, nbins = pl.wn * C.nco;
+    const size_t t0 = (size_t)blockIdx.x * MSM_COARSE_TERMS;
+    for (u32 b = tid; b < nbins; b += MSM_BIN_THREADS) s_cnt[b] = 0;
+    u32 h[MSM_COARSE_PER_THREAD][MSM_HALF_WORDS];
+#pragma unroll
+    for (int it = 0; it < MSM_COARSE_PER_THREAD; it++) {
+        const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
+        if (t < nt) {
+            const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[it][4 * q] = v.x; h[it][4 * q + 1] = v.y; h[it][4 * q + 2] = v.z; h[it][4 * q + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MSM_HALF_WORDS; q++) h[it][q] = 0;            // flags word 0: inactive
+        }
+    }
+    __syncthreads();
+    int over = 0;
+    // sweep 1 counts, sweep 2 (after the reservation) takes its slots in the same histogram, which then holds the bins' bases
+    for (int sweep = 0; sweep < 2; sweep++) {
+#pragma unroll 1
+        for (u32 w = 0; w < pl.wn; w++) {
+            msm_wconst wc; msm_window_const(wc, pl.w0 + w, pl.c);
+            const int top = (pl.w0 + w + 1 == pl.windows);
+            const u32 cap = top ? C.cap_top : C.cap;
+#pragma unroll
+            for (int it = 0; it < MSM_COARSE_PER_THREAD; it++) {
+                const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const u32 key = msm_key_at(h[it], half, 0, wc, pl);
+                    if (!key) continue;
+                    u32 bkt = key >> 1;
+                    if (top) {
+                        if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }
+                        bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
+                    }
+                    const u32 co = bkt >> C.shift;
+                    const u32 slot = atomicAdd(&s_cnt[w * C.nco + co], 1u);
+                    if (sweep) {
+                        const u32 ref = (u32)(t << 2) | ((u32)half << 1) | (key & 1u);
+                        if (slot < cap) pairs[msm_coarse_region(C, pl, w, co) + slot] = (unsigned long long)ref | ((unsigned long long)bkt << 32);
+                        else over = 1;
+                    }
+                }
+            }
+        }
+        if (sweep == 0) {
+            __syncthreads();
+            for (u32 b = tid; b < nbins; b += MSM_BIN_THREADS) {
+                const u32 c = s_cnt[b];
+                s_cnt[b] = c ? atomicAdd(&ccnt[b], c) : 0u;
+            }
+            __syncthreads();
+        }
+    }
+    if (over) flags[0] = 1u;
+}
+// pass 2: one workgroup per (coarse bin, window), tiles of MSM_FINE_TILE pairs: counted per bucket, ordered by bucket in LDS, written out
+// in runs behind what the earlier tiles put into the bucket's region.  The bucket counts come out of the running totals.
+#define MSM_FINE_THREADS 256
+#define MSM_FINE_TILE (8 * MSM_FINE_THREADS)
+__global__ void __launch_bounds__(MSM_FINE_THREADS)
+k_msm_bin_fine(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const unsigned long long* __restrict__ pairs, const u32* __restrict__ ccnt,
+               msm_plan pl, msm_layout L, msm_coarse C) {
+    __shared__ u32 stage[MSM_FINE_TILE];
+    __shared__ unsigned char stage_f[MSM_FINE_TILE];
+    __shared__ u32 s_cnt[136], s_loff[136], s_tot[136];
+    const u32 co = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nfine = 1u << C.shift, first = co << C.shift;
+    if (tid < nfine) s_tot[tid] = 0;
+    const int top = (pl.w0 + w + 1 == pl.windows);
+    const u32 ccap = top ? C.cap_top : C.cap, cap = top ? L.cap_top : L.cap;
+    u32 n = ccnt[w * C.nco + co]; n = n < ccap ? n : ccap;
+    const unsigned long long* src = pairs + msm_coarse_region(C, pl, w, co);
+    int over = 0;
+    for (u32 i0 = 0; i0 < n; i0 += MSM_FINE_TILE) {
+        if (tid < nfine) s_cnt[tid] = 0;
+        unsigned long long pr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u32 i = i0 + (u32)j * MSM_FINE_THREADS + tid; pr[j] = i < n ? src[i] : 0ull; }
+        __syncthreads();
+        u32 rank[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u32 bkt = (u32)(pr[j] >> 32); rank[j] = bkt ? atomicAdd(&s_cnt[bkt - first], 1u) : 0u; }      // (bucket 0 never occurs)
+        __syncthreads();
+        msm_scan320(s_loff, s_cnt, nfine);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 bkt = (u32)(pr[j] >> 32);
+            if (bkt) { const u32 f = bkt - first, at = s_loff[f] + rank[j]; stage[at] = (u32)pr[j]; stage_f[at] = (unsigned char)f; }
+        }
+        __syncthreads();
+        const u32 total = s_loff[nfine];
+        for (u32 i = tid; i < total; i += MSM_FINE_THREADS) {
+            const u32 f = stage_f[i], bkt = first + f, slot = s_tot[f] + (i - s_loff[f]);
+            if (slot < cap && (!top || bkt < L.top_used)) refs[msm_region(L, pl, w, bkt) + slot] = stage[i];
+            else over = 1;
+        }
+        __syncthreads();
+        if (tid < nfine) s_tot[tid] += s_cnt[tid];
+    }
+    __syncthreads();
+    if (tid < nfine && first + tid < pl.nb) gcnt[w * pl.nb + first + tid] = s_tot[tid];
+    if (over) flags[0] = 1u;
+}
 // exclusive scan of in[0..nk) into off[0..nk] (and a copy in cur if non-null): tiles of 1024, then the tile totals
 __global__ void __launch_bounds__(256)
 k_scan_tiles(u32* off, u32* tile_sum, const u32* in, u32 nk) {
@@ -1648,6 +1791,26 @@ static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
 }
 // run lengths of the partial-sum rounds: round 1 sums up to T references per lane (about 1.3e5 lanes' worth at the largest
 // sizes), later rounds up to MSM_T2 partial sums -- short, because there are only a few per bucket left and lanes are scarce
+static msm_coarse msm_make_coarse(size_t nt, const msm_plan& pl, const msm_layout& L) {
+    msm_coarse C;
+    C.shift = pl.c > 13 ? 7u : (pl.c > 7 ? 6u : 0u);
+    C.nco = ((pl.nb - 1u) >> C.shift) + 1u;                       // <= 2^(16 - 1 - 7) + 1 = 257
+    const double mean = 2.0 * (double)nt / (double)(pl.nb - 1) * (double)(1u << C.shift);
+    // the layout's own capacities are per bucket: mean + 10 standard deviations (+ the non-uniform values of the highest windows, see
+    // msm_make_layout); the same rule for the sum over 2^shift buckets
+    const u32 top_bits = 128u - pl.c * (pl.windows - 1);
+    C.cap = msm_cap_for(top_bits == 0 ? 1.5 * mean : mean);
+    const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
+    double mean_top = 8.0 * (double)nt / (double)top_vals; if (mean_top > 2.0 * (double)nt) mean_top = 2.0 * (double)nt;
+    double per_bin = mean_top / (double)L.sub * (double)(1u << C.shift); if (per_bin > 2.0 * (double)nt) per_bin = 2.0 * (double)nt;
+    C.cap_top = msm_cap_for(per_bin);
+    return C;
+}
+static size_t msm_pairs_words(size_t nt, const msm_plan& pl, const msm_layout& L) {
+    if (!(pl.c > 13 || getenv("S2K_MSM_TWO_PASS"))) return 8;
+    const msm_coarse C = msm_make_coarse(nt, pl, L);
+    return (size_t)pl.windows * C.nco * (size_t)std::max(C.cap, C.cap_top) + 8;
+}
 static u32 msm_run_len(size_t E, const msm_plan& pl, const msm_layout& L) {
     if (const char* t = getenv("S2K_MSM_T")) { const int v = atoi(t); if (v >= 2 && v <= 1024) return (u32)v; }      // diagnostic override
     // small inputs (the plan keeps their bucket regions short): one lane per bucket takes the whole region, no second round
@@ -1664,7 +1827,7 @@ static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
     const size_t E = nt * 2 * pl.windows;
     const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(E, pl, L);
     return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
-                    msm_refs_words(pl, L) * 4, nk * 28 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
+                    msm_refs_words(pl, L) * 4, nk * 28 * 4, msm_pairs_words(nt, pl, L) * 8, (size_t)pl.windows * 520 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
                     (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2}) + 32 * 256;
 }
 static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
@@ -1724,6 +1887,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
     u32* tile_sum = c.take<u32>(1024); (void)spare;
     u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* buckets = c.take<u32>((size_t)nk * 28);
+    unsigned long long* pairs = c.take<unsigned long long>(msm_pairs_words(nt, pl, L)); u32* ccnt = c.take<u32>((size_t)pl.windows * 520);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
     HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
@@ -1731,7 +1895,13 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
-    if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    const int two_pass = (pl.c > 13 || getenv("S2K_MSM_TWO_PASS")) && !getenv("S2K_MSM_ONE_PASS");
+    if (two_pass) {
+        const msm_coarse C = msm_make_coarse(nt, pl, L);
+        HIPCHK(hipMemsetAsync(ccnt, 0, (size_t)pl.wn * C.nco * 4, st));
+        hipLaunchKernelGGL(k_msm_bin_coarse, dim3((unsigned)((nt + MSM_COARSE_TERMS - 1) / MSM_COARSE_TERMS)), dim3(MSM_BIN_THREADS), 0, st, pairs, ccnt, flags, halves, nt, pl, L, C);
+        hipLaunchKernelGGL(k_msm_bin_fine, dim3(C.nco, pl.wn), dim3(MSM_FINE_THREADS), 0, st, refs_cap, gcnt, flags, (const unsigned long long*)pairs, (const u32*)ccnt, pl, L, C);
+    } else if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
     else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
     // empty) launches do not sit behind the Horner tail of every call

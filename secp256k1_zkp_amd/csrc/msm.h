@@ -53,8 +53,11 @@ static inline u32 msm_cap_for(double mean) {
 static inline msm_layout msm_make_layout(size_t nt, const msm_plan& pl) {
     msm_layout L;
     const double mean = 2.0 * (double)nt / (double)(pl.nb - 1);
-    L.cap = msm_cap_for(mean);
     const u32 top_bits = 128u - pl.c * (pl.windows - 1);              // live bits of the top window (0: only the carry reaches it)
+    // c | 128: the top window only holds carries, and the window below it ends at bit 127, where the halves are NOT uniform (|k1| < 2^127.4,
+    // |k2| < 2^126.9): its raw values stop at 0.66 * 2^c, so after the signed recoding the magnitudes above 0.34 * 2^c collect 1.29x the
+    // uniform share (1.52x from k1, 1.07x from k2).  Those plans size every region for 1.5x.
+    L.cap = msm_cap_for(top_bits == 0 ? 1.5 * mean : mean);
     const u32 top_vals = (top_bits >= pl.c - 1) ? (pl.nb - 1) : (1u << top_bits);
     // |k1| and |k2| stay below ~2^127.4 and ~2^126.9 (the GLV lattice bounds), so the top window's values are not uniform:
     // the low ones carry up to ~1.9x the uniform share.  4x (never more than every reference) leaves the same margin as below.
@@ -147,6 +150,28 @@ S2K_HD int msm_digit_at(const u32 k[5], const msm_wconst& wc, u32 c) {
     return d > (1u << (c - 1)) ? (int)d - (int)(1u << c) : (int)d;
 }
 
+// All windows of one half-scalar from ONE addition: C_w is the low part of C_full = C_(W-1) (the pattern in every window but the top
+// one) and a carry into window w only depends on what lies below it, so s = k + C_full has, in window w, raw_w + carry_w plus the
+// pattern's own (2^(c-1) - 1) there -- which comes off again mod 2^c (the top window has no pattern).  Same digits as msm_digit /
+// msm_digit_at, bit for bit (tests/test_cpu_oracle.py::test_msm_digit_forms_agree).
+struct msm_sfull { u32 s[6]; };
+S2K_HD void msm_sum_full(msm_sfull& sf, const u32 k[5], u32 c, u32 windows) {
+    msm_wconst wc; msm_window_const(wc, windows - 1u, c);
+    u64 cy = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { cy += (u64)k[i] + wc.add[i]; sf.s[i] = (u32)cy; cy >>= 32; }
+    sf.s[5] = (u32)cy;
+}
+S2K_HD int msm_digit_full(const msm_sfull& sf, u32 w, u32 c, u32 windows) {
+    const u32 bit = w * c, word = bit >> 5, sh = bit & 31;
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) if ((u32)i == word) v = (u64)sf.s[i] | ((u64)sf.s[i + 1] << 32);
+    const u32 mask = (1u << c) - 1u;
+    u32 t = (u32)(v >> sh) & mask;
+    if (w + 1u < windows) t = (t - ((1u << (c - 1)) - 1u)) & mask;
+    return t > (1u << (c - 1)) ? (int)t - (int)(1u << c) : (int)t;
+}
 // half-scalar record of a term: k1 magnitude [5], k2 magnitude [5], flags (bit0 k1 negative, bit1 k2 negative, bit2 active), pad
 #define MSM_HALF_WORDS 12
 // byte decode + GLV split of one term (no digits): term record as below, half-scalar record as above

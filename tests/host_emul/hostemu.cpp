@@ -323,6 +323,20 @@ int emu_msm(unsigned char* r64, const unsigned char* g_sc, const unsigned char* 
     gej r; gej_load28_h(r, o);
     return gej_to_b64(r64, r);
 }
+// the three forms of the signed window digits of a 129-bit magnitude: the carry recurrence, one window on its own (per-window constant),
+// all windows from one addition; out: 3 x windows ints
+int emu_msm_digit_forms(int* out, const u32* k5, unsigned c) {
+    const msm_plan pl = msm_plan_for(c);
+    int carry = 0;
+    msm_sfull sf; msm_sum_full(sf, k5, pl.c, pl.windows);
+    for (u32 w = 0; w < pl.windows; w++) {
+        out[w] = msm_digit(k5, w, pl.c, carry);
+        msm_wconst wc; msm_window_const(wc, w, pl.c);
+        out[pl.windows + w] = msm_digit_at(k5, wc, pl.c);
+        out[2 * pl.windows + w] = msm_digit_full(sf, w, pl.c, pl.windows);
+    }
+    return (int)pl.windows;
+}
 // a window share's partial by the bucket path (direct = 0) or by the bucket-free exact path of k_msm_direct (direct = 1)
 int emu_msm_window_partial(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n,
                            unsigned part, unsigned parts, int direct, int force_c) {

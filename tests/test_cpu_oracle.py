@@ -256,6 +256,23 @@ def test_emu_msm(emu, ref):
         assert i1 == i2 and r1.tobytes() == out.raw, (n, g, c)
 
 
+def test_msm_digit_forms_agree(emu):
+    """msm.h's three ways to the signed window digits of a half-scalar (carry recurrence; one window from its own constant; all windows
+    from one addition, the binning pass's form) give the same digits for every width the plans use, and the digits add up to the value."""
+    rng = np.random.default_rng(77)
+    edge = [0, 1, 2**128 - 1, 2**128, 2**127, 2**127 - 1, int("5" * 32, 16), int("a" * 32, 16), int("7f" * 16, 16), int("80" * 16, 16)]
+    vals = edge + [int.from_bytes(rng.integers(0, 256, 16, dtype=np.uint8).tobytes(), "big") for _ in range(200)]
+    for c in range(4, 17):
+        W = (129 + c - 1) // c
+        for v in vals + [(1 << (c * j + c - 1)) + d for j in range(0, W - 1, 3) for d in (-1, 0, 1)] + [sum(((1 << (c - 1)) + e) << (c * j) for j in range(W - 1)) & (2**128 - 1) for e in (-1, 0, 1)]:
+            k5 = (ctypes.c_uint32 * 5)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(5)])
+            out = (ctypes.c_int * (3 * W))()
+            assert emu.emu_msm_digit_forms(out, k5, c) == W
+            a, b, f = list(out[:W]), list(out[W:2 * W]), list(out[2 * W:])
+            assert a == b == f, (c, hex(v))
+            assert sum(d << (c * w) for w, d in enumerate(a)) == v and all(abs(d) <= 1 << (c - 1) for d in a)
+
+
 def _emu_rewind(emu, commit33, proof, gen64, nonce, capacity):
     bl = ctypes.create_string_buffer(32); val = ctypes.c_ulonglong(0); msg = ctypes.create_string_buffer(4096); ol = ctypes.c_ulonglong(capacity)
     mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0)
