@@ -47,7 +47,8 @@ def msm_sharded(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=
     n = sc.shape[0] if hasattr(sc, "shape") and len(sc.shape) > 1 else len(sc) // 32
     lo, hi = shard_range(n, rank, world)
     if world == 1 and hasattr(backend, "msm_whole"):
-        return backend.msm_whole(sc, pt_xy, g_sc, pt_inf, to_host)      # nothing to exchange: the engine's complete call (no partial / sum stage)
+        with _chain(backend):                                           # (on the backend's stream like the sharded chain: no cross-stream hops per call)
+            return backend.msm_whole(sc, pt_xy, g_sc, pt_inf, to_host)  # nothing to exchange: the engine's complete call (no partial / sum stage)
     with _chain(backend):
         part = backend.msm_partial(sc[lo:hi], pt_xy[lo:hi], g_sc if rank == 0 else None, None if pt_inf is None else pt_inf[lo:hi])
         return _gather_and_sum(backend, part, group, to_host)
@@ -166,9 +167,9 @@ class EngineBackend:
     def msm_whole(self, sc, pt_xy, g_sc, pt_inf, to_host=True):
         """the whole sum on this GPU (s2k_ecmult_multi_dev): what a one-rank job runs"""
         import torch
-        r = torch.zeros(64, dtype=torch.uint8, device=self.dev); inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        r = torch.empty(64, dtype=torch.uint8, device=self.dev); inf = torch.empty(1, dtype=torch.int32, device=self.dev)      # (the call writes both, always)
         if sc.numel() == 0 and g_sc is None:
-            inf += 1
+            r.zero_(); inf.fill_(1)
         else:
             sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
             h = self._enter()
