@@ -354,3 +354,34 @@ def test_asynchronous_pair_through_the_hook_and_the_c_abi(hk, engine, ref):
     rc = hk.rangeproof_verify_batch_wait(tc)
     assert np.array_equal(rc[0], exp2[0]) and np.array_equal(rc[2], exp2[2])
     hk.set_backend()
+
+
+def test_asynchronous_pair_large_batches_and_extra_commit(engine, ref):
+    """submit / wait with batches that span several launch groups (more than 32 768 proofs: the pipeline's chunks alternate the two scratch
+    sets while the other submission's chunks are queued behind them), with extra_commit data, and waited for from another thread."""
+    import threading
+    rng = np.random.default_rng(613)
+    base = 96
+    extra = [b"" if i % 4 else b"commit-%d" % i for i in range(base)]
+    c, p, g = ref.make_rangeproofs_extra(base, rng, extra, min_bits=6)
+    p = list(p); bad = bytearray(p[5]); bad[-1] ^= 1; p[5] = bytes(bad); extra[9] = b"other"
+    exp = ref.rangeproof_verify_many_extra(c, p, g, extra)
+    assert 0 < exp[0].sum() < base
+    reps = 400                                                        # 38 400 proofs per batch: two launch groups
+    idx = np.tile(np.arange(base), reps)
+    C = c[idx]; G = g[idx]; P = [p[i] for i in idx]; E = [extra[i] for i in idx]
+    pk = engine.pack(P); ek = engine.pack(E)
+    c2, p2, g2, _ = ref.make_rangeproofs(64, rng, min_bits=9)
+    exp2 = ref.rangeproof_verify_many(c2, list(p2), g2)
+    t1 = engine.rangeproof_verify_batch_submit(C, pk, G, extra=ek)
+    t2 = engine.rangeproof_verify_batch_submit(c2, list(p2), g2)
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault(2, engine.rangeproof_verify_batch_wait(t2)))      # the younger ticket first, elsewhere
+    th.start(); th.join()
+    got[1] = engine.rangeproof_verify_batch_wait(t1)
+    assert np.array_equal(got[2][0], exp2[0]) and np.array_equal(got[2][2], exp2[2])
+    r = got[1]
+    assert np.array_equal(r[0], exp[0][idx]) and np.array_equal(r[1], exp[1][idx]) and np.array_equal(r[2], exp[2][idx])
+    # and the same big batch synchronously
+    r = engine.rangeproof_verify_batch(C, pk, G, extra=ek)
+    assert np.array_equal(r[0], exp[0][idx]) and np.array_equal(r[2], exp[2][idx])
