@@ -166,8 +166,10 @@ S2K_API int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* resul
  * error) until the older ticket has been waited for -- and tickets may be waited for in any order, from any thread.  With
  *     submit(k+1); wait(k); submit(k+2); wait(k+1); ...
  * the gathering and the PCIe copies of batch k+1 run underneath the kernels of batch k and the GPU never idles: the throughput of the
- * host-buffer path becomes that of the device-resident one (bench.py: dropin.value_two_in_flight).  The synchronous forms above are
- * submit + wait.  A ticket is never 0. */
+ * host-buffer path becomes that of the device-resident one (bench.py: dropin.two_in_flight).  The synchronous forms above are
+ * submit + wait on one of the same two staging sets: concurrent synchronous callers (verifier threads sharing an engine) queue for a
+ * set -- two of them overlap, none is turned away -- unless both sets are held by tickets nobody waits for (error after 60 s).
+ * A ticket is never 0. */
 S2K_API int secp256k1_rangeproof_verify_batch_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                      const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);

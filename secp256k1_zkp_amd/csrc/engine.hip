@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <array>
 #include <mutex>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -108,6 +109,7 @@ struct s2k_engine {
         int32_t* results; uint64_t* min_value; uint64_t* max_value; size_t n, o_res, o_min, o_max;
     } stage[2];
     uint64_t next_ticket;
+    std::condition_variable_any stage_cv;                 // a staging set was handed back (synchronous callers queue for one)
     hipStream_t stream_copy;
     int stage_threads;
     std::recursive_mutex mu;
@@ -950,11 +952,22 @@ static int engine_stage(s2k_engine* e, s2k_engine::stage_set& S, size_t in_bytes
 // Gather, copy and launch one batch; what comes back is the ticket of the staging set that now belongs to it (rp_host_wait hands it back).
 // The copies go on the engine's copy stream and the first stage of the pipeline waits for them by event, so that a batch submitted while
 // the one before it computes has its inputs in HBM -- and its header / prologue stage done -- by the time the rings kernel is free.
-static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n) {
+// `queue`: the caller's lock on the engine when it is a SYNCHRONOUS entry point -- such a call waits its turn for a staging set (several
+// verifier threads on one engine take turns, two of them overlapping) where the asynchronous `_submit` reports "two in flight".
+static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n,
+                          std::unique_lock<std::recursive_mutex>* queue = nullptr) {
     const int ptrs = src.commit_objs != nullptr;
     const int has_extra = ptrs ? (src.extra_ptrs != nullptr) : (src.extra != nullptr && src.extra_off != nullptr);
-    s2k_engine::stage_set& S = e->stage[e->next_ticket & 1u];
-    if (S.ticket) return s2k_fail_arg(who, "two batches in flight already: wait for the older ticket first");
+    int si = -1;
+    for (;;) {
+        const int pref = (int)(e->next_ticket & 1u);
+        si = !e->stage[pref].ticket ? pref : (!e->stage[pref ^ 1].ticket ? (pref ^ 1) : -1);
+        if (si >= 0) break;
+        if (!queue) return s2k_fail_arg(who, "two batches in flight already: wait for a ticket first");
+        if (e->stage_cv.wait_for(*queue, std::chrono::seconds(60)) == std::cv_status::timeout && e->stage[0].ticket && e->stage[1].ticket)
+            return s2k_fail_arg(who, "both staging sets are held by tickets nobody waits for");
+    }
+    s2k_engine::stage_set& S = e->stage[si];
     // sizes and offsets
     std::vector<uint64_t> poff_v, eoff_v;
     const uint64_t* poff = src.proof_off; const uint64_t* eoff = src.extra_off;
@@ -1049,16 +1062,18 @@ static int rp_host_wait(s2k_engine* e, const char* who, uint64_t ticket) {
     s2k_engine::stage_set* S = nullptr; hipEvent_t ev = nullptr;
     {
         std::lock_guard<std::recursive_mutex> lock(e->mu);
-        S = &e->stage[ticket & 1u];
-        if (ticket == 0 || S->ticket != ticket) return s2k_fail_arg(who, "unknown ticket (never issued, or waited for already)");
+        for (int i = 0; i < 2; i++) if (ticket != 0 && e->stage[i].ticket == ticket) S = &e->stage[i];
+        if (!S) return s2k_fail_arg(who, "unknown ticket (never issued, or waited for already)");
         ev = S->ev_out;
     }
     HIPCHK(hipSetDevice(e->device));
     const hipError_t err = hipEventSynchronize(ev);
     std::lock_guard<std::recursive_mutex> lock(e->mu);
-    if (err != hipSuccess) { S->ticket = 0; (void)hipGetLastError(); return s2k_fail(who, hipGetErrorString(err)); }      // (the arrays keep the zeros of submission time)
+    if (S->ticket != ticket) return s2k_fail_arg(who, "unknown ticket (waited for by another thread meanwhile)");
+    if (err != hipSuccess) { S->ticket = 0; e->stage_cv.notify_all(); (void)hipGetLastError(); return s2k_fail(who, hipGetErrorString(err)); }      // (the arrays keep the zeros of submission time)
     memcpy(S->results, S->out + S->o_res, 4 * S->n); memcpy(S->min_value, S->out + S->o_min, 8 * S->n); memcpy(S->max_value, S->out + S->o_max, 8 * S->n);
     S->ticket = 0;
+    e->stage_cv.notify_all();
     return 1;
 }
 static int rp_ptrs_check(const char* who, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs, const unsigned char* const* proofs,
@@ -1107,9 +1122,9 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     rp_host_src src{}; src.commits33 = commits33; src.proofs = proofs; src.proof_off = proof_off; src.extra = extra; src.extra_off = extra_off; src.gens64 = gens64;
     uint64_t ticket = 0;
     {
-        std::lock_guard<std::recursive_mutex> lock(e->mu);
+        std::unique_lock<std::recursive_mutex> lock(e->mu);
         HIPCHK(hipSetDevice(e->device));
-        if (!rp_host_submit(e, "secp256k1_rangeproof_verify_batch", &ticket, results, min_value, max_value, src, n)) return 0;
+        if (!rp_host_submit(e, "secp256k1_rangeproof_verify_batch", &ticket, results, min_value, max_value, src, n, &lock)) return 0;
     }
     return rp_host_wait(e, "secp256k1_rangeproof_verify_batch", ticket);
 }
@@ -1124,9 +1139,9 @@ extern "C" int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* re
     rp_host_src src{}; src.commit_objs = commit_objs; src.proof_ptrs = proofs; src.plens = plens; src.extra_ptrs = extra; src.elens = elens; src.gen_objs = gen_objs;
     uint64_t ticket = 0;
     {
-        std::lock_guard<std::recursive_mutex> lock(e->mu);
+        std::unique_lock<std::recursive_mutex> lock(e->mu);
         HIPCHK(hipSetDevice(e->device));
-        if (!rp_host_submit(e, who, &ticket, results, min_value, max_value, src, n)) return 0;
+        if (!rp_host_submit(e, who, &ticket, results, min_value, max_value, src, n, &lock)) return 0;
     }
     return rp_host_wait(e, who, ticket);
 }

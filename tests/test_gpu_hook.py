@@ -286,12 +286,16 @@ def test_concurrent_verifier_threads_on_one_engine(hk, engine, ref):
 
     th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
     ri = threading.Thread(target=reinstaller)
+    s0 = hk.stats()
     ri.start()
     for t in th: t.start()
     for t in th: t.join()
     stop.set(); ri.join()
     assert errors == []
-    assert hk.stats()[1] == hk.stats()[1]          # (no fallbacks are expected, but a fallback would still have produced the reference's verdicts)
+    # every call was served by the engine: synchronous callers queue for one of the engine's two staging sets, they are not turned away
+    # (the counters are plain size_t's updated by concurrent adapters: allow for a lost update, not for a fallback)
+    s1 = hk.stats()
+    assert s1[1] == s0[1] and s0[0] + 20 <= s1[0] <= s0[0] + 24
     hk.set_backend()
 
 
