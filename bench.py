@@ -140,6 +140,30 @@ def measure_dropin(eng, commits, proofs, gens, steps):
     assert outs[0][0].all() and outs[1][0].all() and int(outs[1][2].min()) == 2**64 - 1
     out["two_in_flight"] = {"entry": "secp256k1_rangeproof_verify_batch_submit / _wait (packed arrays; submit(k+1) before wait(k))", "value": n / dta, "ms_per_call": dta * 1e3,
                             "batches": k2}
+    # (i'') the SYNCHRONOUS call from two verifier threads sharing the engine: each queues for one of the two staging sets, so the gathering
+    # and the copies of one thread's batch run underneath the kernels of the other's (ctypes releases the GIL for the duration of a call)
+    import threading
+    def two_threads(call_with):
+        errs = []
+        def worker(k):
+            try:
+                for _ in range(steps):
+                    call_with(k)
+            except Exception as ex:          # noqa: BLE001
+                errs.append(repr(ex))
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        t = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt2 = (time.perf_counter() - t) / (2 * steps)
+        assert not errs, errs
+        return dt2
+    def call_packed_k(k):
+        r, a, b = outs[k]
+        assert L.secp256k1_rangeproof_verify_batch(eng._h, vp(r), vp(a), vp(b), vp(c), vp(pdata), vp(poff), None, None, vp(g), n) == 1
+    dtt = two_threads(call_packed_k)
+    assert outs[0][0].all() and outs[1][0].all()
+    out["two_threads_synchronous"] = {"entry": "secp256k1_rangeproof_verify_batch from two threads on one engine", "value": n / dtt, "ms_per_call": dtt * 1e3}
     # (ii) reference types through the hooked reference library
     try:
         from tests import hookapi
@@ -167,8 +191,16 @@ def measure_dropin(eng, commits, proofs, gens, steps):
             assert all(r32[i] == 1 for i in range(0, n, 97)) and int(mx2.min()) == 2**64 - 1
             out["hooked_reference_types"] = {"entry": "secp256k1_amd_rangeproof_verify_batch (libsecp256k1_hooked.so: the unmodified reference + integration/secp256k1_amd_hook.c)",
                                              "value": n / dth, "ms_per_call": dth * 1e3, "served": s1[0] - s0[0], "fell_back": s1[1] - s0[1]}
-            # (ii') the asynchronous adapters, two batches in flight
+            # (ii'') the synchronous adapter from two verifier threads
+            def call_hook_k(k):
+                assert hk.lib.secp256k1_amd_rangeproof_verify_batch(hk.ctx, r32b[k], mnb[k].ctypes.data, mxb[k].ctypes.data, cp, pp, plens, None, None, gp, n) == 1
             r32b = [(ctypes.c_int * n)() for _ in range(2)]; mnb = [np.zeros(n, np.uint64) for _ in range(2)]; mxb = [np.zeros(n, np.uint64) for _ in range(2)]
+            s0 = hk.stats()
+            dtt = two_threads(call_hook_k)
+            s1 = hk.stats()
+            assert s1[1] == s0[1], "the hook fell back to the CPU"
+            out["hooked_two_threads_synchronous"] = {"entry": "secp256k1_amd_rangeproof_verify_batch from two threads (one context, one engine)", "value": n / dtt, "ms_per_call": dtt * 1e3}
+            # (ii') the asynchronous adapters, two batches in flight
             def hsubmit(k):
                 tk = ctypes.c_uint64(0)
                 assert hk.lib.secp256k1_amd_rangeproof_verify_batch_submit(hk.ctx, ctypes.byref(tk), r32b[k & 1], mnb[k & 1].ctypes.data, mxb[k & 1].ctypes.data,
