@@ -565,6 +565,9 @@ def main():
         import hashlib
         from secp256k1_zkp_amd import _native
         lib_sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()
+        # (hipcc's output is not reproducible byte for byte -- two builds of one source tree differ in the offload bundle's ids -- so a file
+        #  also counts when it carries the sha256 of the library's SOURCES, csrc/* + the public header, as they are in this tree)
+        src_sha = _native.sources_sha256()
         traffic, traffic_src, issued = None, None, None
         def _stamped(pattern):
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
@@ -572,13 +575,13 @@ def main():
                     j = json.load(open(f))
                 except Exception:
                     continue
-                if j.get("so_sha256") == lib_sha:
+                if j.get("so_sha256") == lib_sha or (src_sha and j.get("src_sha256") == src_sha):
                     return f, j
             return None, None
         f_pmc, pj = _stamped("*pmc_rp_rings.json")
         if pj:
             traffic = pj["hbm_bytes_per_launch_raw"] * n / 16384.0
-            traffic_src = os.path.relpath(f_pmc, ROOT)
+            traffic_src = os.path.relpath(f_pmc, ROOT) + (" (same library binary)" if pj.get("so_sha256") == lib_sha else " (same library sources, another build)")
         else:
             traffic_src = "no profiles/*pmc_rp_rings.json stamped with this library's sha256 (%s...): run tools/profile_round.sh on this build" % lib_sha[:12]
         # issued (not algorithmic) integer-MAC rate: SQ counter passes of this same command; SQ_INSTS_VALU_INT64 counts wave-level 64-bit
@@ -613,7 +616,7 @@ def main():
             "roofline": {"bound": "valu", "kernel": "k_rp_rings_shared (+ k_rp_rings for wavefronts without a generator table)", "achieved": mad_rate / 1e12, "peak": MAD32_PEAK / 1e12,
                          "unit": "T lane-MAC/s (v_mad_u64_u32, 32x32+64)", "frac": mad_rate / MAD32_PEAK, "frac_of_architectural_peak": mad_rate / MAD32_PEAK_ARCH,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, incl. Infinity-Cache hits)", "traffic_source": traffic_src,
-                         "kernel_ms": kms, "kernel_ms_with_calls_in_flight": float(np.mean(kern_ms_pipe)), "issued": issued, "library_sha256": lib_sha,
+                         "kernel_ms": kms, "kernel_ms_with_calls_in_flight": float(np.mean(kern_ms_pipe)), "issued": issued, "library_sha256": lib_sha, "library_sources_sha256": src_sha,
                          "note": "achieved = algorithmic 6.6e6 MAC64/proof (reference schedule, SURVEY 8d) x 4 v_mad_u64_u32 x proofs / kernel time (HIP events on the launch stream); "
                                  "peak measured with >= 10 ms launches (tools/ubench/issue_model.hip, profiles/r02a_issue_model.txt)"},
             "hbm_roofline": {"bound": "hbm", "kernel": "k_rp_rings_shared + k_rp_rings", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -83,3 +83,18 @@ def load():
 
 def last_error():
     return load().s2k_last_error().decode()
+
+
+def sources_sha256():
+    """sha256 over the library's sources (csrc/*, sorted by name, and the public header): what tools/profile_round.sh stamps into the
+    counter files next to the binary's own hash -- hipcc's output is not reproducible byte for byte.  None when the sources are not there."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc"); hdr = os.path.join(os.path.dirname(_HERE), "include", "secp256k1_zkp_amd.h")
+    try:
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(csrc)):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+        h.update(open(hdr, "rb").read())
+        return h.hexdigest()
+    except OSError:
+        return None

@@ -30,7 +30,9 @@ tag = sys.argv[1]
 so_sha = hashlib.sha256(open("secp256k1_zkp_amd/libsecp256k1_zkp_amd.so", "rb").read()).hexdigest()
 import os
 head = os.environ.get("S2K_GIT_HEAD", "unknown")      # the GPU box has no .git: pass it in,  S2K_GIT_HEAD=$(git rev-parse HEAD) bash tools/profile_round.sh <tag>
-stamp = {"so_sha256": so_sha, "git_head": head}
+sys.path.insert(0, ".")
+from secp256k1_zkp_amd import _native
+stamp = {"so_sha256": so_sha, "src_sha256": _native.sources_sha256(), "git_head": head}
 def collect(pattern, prefix="k_"):
     out = {}
     for f in glob.glob(pattern, recursive=True):
