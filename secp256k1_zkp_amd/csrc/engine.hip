@@ -1397,33 +1397,46 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     __syncthreads();
     // sweep: digit of every half-scalar of the chunk, rank inside the workgroup from the LDS histogram; the (bucket, rank, sign)
     // of the at most 8 terms x 2 halves a thread owns stay in registers (chunk <= 8 * MSM_BIN_THREADS)
+    // (the kernel waits for memory three quarters of its time -- SQ_WAIT_ANY, profiles/r03f_msm_1048576_pmc.json -- so the records of four
+    //  terms are requested before the first one is used: two round trips per lane instead of eight)
     u32 kv[8][2];
     int over = 0;
     const int top = (pl.w0 + w + 1 == pl.windows);
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        kv[it][0] = 0; kv[it][1] = 0;
-        const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
-        if (t < t1) {
-            u32 h[MSM_HALF_WORDS];
-            const uint4* src = (const uint4*)(halves + t * MSM_HALF_WORDS);
+    for (int it0 = 0; it0 < 8; it0 += 4) {
+        uint4 hv[4][3];
 #pragma unroll
-            for (int q = 0; q < 3; q++) { const uint4 v = src[q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+        for (int j = 0; j < 4; j++) {
+            const size_t t = t0 + tid + (size_t)(it0 + j) * MSM_BIN_THREADS;
+            const uint4* src = (const uint4*)(halves + (t < t1 ? t : t0) * MSM_HALF_WORDS);
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
-                if (key) {
-                    u32 bkt = key >> 1;
-                    if (top) {                                           // value v -> one of its `sub` buckets, by term index
-                        if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }      // a value the top window cannot hold for a reduced half
-                        bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
-                    }
-                    if (WIDE) {
-                        const u32 sh = (bkt & 1u) * 16u;
-                        const u32 rank = (atomicAdd(&s_cnt[bkt >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 14) | rank;
-                    } else {
-                        const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+            for (int q = 0; q < 3; q++) hv[j][q] = src[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int it = it0 + j;
+            kv[it][0] = 0; kv[it][1] = 0;
+            const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
+            if (t < t1) {
+                u32 h[MSM_HALF_WORDS];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { const uint4 v = hv[j][q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const u32 key = msm_key_at(h, half, 0, wc, pl);          // window offset 0: local bucket index
+                    if (key) {
+                        u32 bkt = key >> 1;
+                        if (top) {                                           // value v -> one of its `sub` buckets, by term index
+                            if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }      // a value the top window cannot hold for a reduced half
+                            bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
+                        }
+                        if (WIDE) {
+                            const u32 sh = (bkt & 1u) * 16u;
+                            const u32 rank = (atomicAdd(&s_cnt[bkt >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                            kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 14) | rank;
+                        } else {
+                            const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                        }
                     }
                 }
             }
@@ -1439,10 +1452,14 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
             s_cnt[wd] = b0 | (b1 << 16);
         }
     } else {
-        for (u32 b = tid; b < pl.nb; b += MSM_BIN_THREADS) {
-            const u32 c = s_cnt[b];
-            s_cnt[b] = c ? atomicAdd(&gcnt[w * pl.nb + b], c) : 0u;          // one global atomic per non-empty (workgroup, bucket)
-        }
+        // one global atomic per non-empty (workgroup, bucket); a lane's (up to five) atomics are all in flight before the first is awaited
+        u32 cc[5], bb[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; cc[j] = b < pl.nb ? s_cnt[b] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; bb[j] = cc[j] ? atomicAdd(&gcnt[w * pl.nb + b], cc[j]) : 0u; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; if (b < pl.nb) s_cnt[b] = bb[j]; }
     }
     __syncthreads();
 #pragma unroll
