@@ -1387,8 +1387,9 @@ __device__ __forceinline__ size_t msm_region(const msm_layout& L, const msm_plan
 #define MSM_BIN_THREADS 1024
 template <int WIDE>
 __global__ void __launch_bounds__(MSM_BIN_THREADS)
-k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt, msm_plan pl, msm_layout L, u32 chunk) {
+k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt, msm_plan pl, msm_layout L, u32 chunk_dbg) {
     __shared__ u32 s_cnt[(WIDE ? 16385 : 4097) + 7];
+    const u32 chunk = chunk_dbg & 0xFFFFFFu, dbg = chunk_dbg >> 24;      // dbg (S2K_MSM_BIN_DEBUG, diagnostic launches: results are meaningless): 1 no reference stores, 2 no global atomics, 4 no LDS atomics
     const u32 w = blockIdx.y, tid = threadIdx.x;
     const size_t t0 = (size_t)blockIdx.x * chunk;
     const size_t t1 = (t0 + chunk < nt) ? t0 + chunk : nt;
@@ -1435,7 +1436,7 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
                             const u32 rank = (atomicAdd(&s_cnt[bkt >> 1], 1u << sh) >> sh) & 0xFFFFu;
                             kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 14) | rank;
                         } else {
-                            const u32 rank = atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                            const u32 rank = (dbg & 4u) ? 0u : atomicAdd(&s_cnt[bkt], 1u); kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
                         }
                     }
                 }
@@ -1457,7 +1458,7 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
 #pragma unroll
         for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; cc[j] = b < pl.nb ? s_cnt[b] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; bb[j] = cc[j] ? atomicAdd(&gcnt[w * pl.nb + b], cc[j]) : 0u; }
+        for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; bb[j] = (cc[j] && !(dbg & 2u)) ? atomicAdd(&gcnt[w * pl.nb + b], cc[j]) : 0u; }
 #pragma unroll
         for (int j = 0; j < 5; j++) { const u32 b = tid + (u32)j * MSM_BIN_THREADS; if (b < pl.nb) s_cnt[b] = bb[j]; }
     }
@@ -1471,7 +1472,7 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
             if (k) {
                 const u32 bkt = WIDE ? (k >> 14) & 0xFFFFu : (k >> 16) & 0x1FFFu;
                 const u32 slot = WIDE ? ((s_cnt[bkt >> 1] >> ((bkt & 1u) * 16u)) & 0xFFFFu) + (k & 0x3FFFu) : s_cnt[bkt] + (k & 0xFFFFu);
-                if (slot < (top ? L.cap_top : L.cap) && (!top || bkt < L.top_used)) refs[msm_region(L, pl, w, bkt) + slot] = (u32)(t << 2) | ((u32)half << 1) | (k >> 31);
+                if (slot < (top ? L.cap_top : L.cap) && (!top || bkt < L.top_used)) { if (!(dbg & 1u)) refs[msm_region(L, pl, w, bkt) + slot] = (u32)(t << 2) | ((u32)half << 1) | (k >> 31); }
                 else over = 1;
             }
         }
@@ -1927,14 +1928,15 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
+    u32 bin_dbg = 0; if (const char* bd = getenv("S2K_MSM_BIN_DEBUG")) bin_dbg = ((u32)atoi(bd) & 7u) << 24;      // diagnostic launches of k_msm_bin (parts switched off)
     const int two_pass = (pl.c > 13 || getenv("S2K_MSM_TWO_PASS")) && !getenv("S2K_MSM_ONE_PASS");
     if (two_pass) {
         const msm_coarse C = msm_make_coarse(nt, pl, L);
         HIPCHK(hipMemsetAsync(ccnt, 0, (size_t)pl.wn * C.nco * 4, st));
         hipLaunchKernelGGL(k_msm_bin_coarse, dim3((unsigned)((nt + MSM_COARSE_TERMS - 1) / MSM_COARSE_TERMS)), dim3(MSM_BIN_THREADS), 0, st, pairs, ccnt, flags, halves, nt, pl, L, C);
         hipLaunchKernelGGL(k_msm_bin_fine, dim3(C.nco, pl.wn), dim3(MSM_FINE_THREADS), 0, st, refs_cap, gcnt, flags, (const unsigned long long*)pairs, (const u32*)ccnt, pl, L, C);
-    } else if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
-    else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk);
+    } else if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
+    else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
     // empty) launches do not sit behind the Horner tail of every call
     HIPCHK(hipEventRecord(e->ev_msm_fork, st));
