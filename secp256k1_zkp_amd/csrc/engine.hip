@@ -1479,6 +1479,105 @@ k_msm_bin(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flag
     }
     if (over) flags[0] = 1u;
 }
+// The single pass with its output ordered in LDS (c <= 13, from 2^15 terms).  Two thirds of k_msm_bin<0> are its lone 4-byte stores
+// (profiles/r03g_msm_bin_parts.txt: one L2 request per reference).  Here a workgroup's references are first laid out by bucket in LDS --
+// one 28-bit word each: bucket, term index inside the chunk, half, sign -- and then written with consecutive lanes on consecutive
+// slots, so that the ~3 references a workgroup has for a bucket leave as one request.  6 144 terms per workgroup (48 KB of staging +
+// counters: two workgroups per CU).
+#define MSM_STAGED_PER_THREAD 6
+#define MSM_STAGED_TERMS (MSM_STAGED_PER_THREAD * MSM_BIN_THREADS)
+__global__ void __launch_bounds__(MSM_BIN_THREADS)
+k_msm_bin_staged(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt, msm_plan pl, msm_layout L) {
+    __shared__ u32 stage[2 * MSM_STAGED_TERMS];
+    __shared__ u32 s_cnt[4104];                 // counts, then (in place) the buckets' offsets in `stage`; [4097]: the total
+    __shared__ unsigned short s_gbase[4104];    // the workgroup's first slot in every bucket region
+    __shared__ u32 s_wave[17];
+    const u32 w = blockIdx.y, tid = threadIdx.x;
+    const size_t t0 = (size_t)blockIdx.x * MSM_STAGED_TERMS;
+    const size_t t1 = (t0 + MSM_STAGED_TERMS < nt) ? t0 + MSM_STAGED_TERMS : nt;
+    for (u32 b = tid; b < 4104; b += MSM_BIN_THREADS) s_cnt[b] = 0;
+    msm_wconst wc; msm_window_const(wc, pl.w0 + w, pl.c);
+    __syncthreads();
+    u32 kv[MSM_STAGED_PER_THREAD][2];           // valid << 30 | sign << 31 | bucket << 16 | rank
+    int over = 0;
+    const int top = (pl.w0 + w + 1 == pl.windows);
+#pragma unroll
+    for (int it0 = 0; it0 < MSM_STAGED_PER_THREAD; it0 += 3) {
+        uint4 hv[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const size_t t = t0 + tid + (size_t)(it0 + j) * MSM_BIN_THREADS;
+            const uint4* src = (const uint4*)(halves + (t < t1 ? t : t0) * MSM_HALF_WORDS);
+#pragma unroll
+            for (int q = 0; q < 3; q++) hv[j][q] = src[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int it = it0 + j;
+            kv[it][0] = 0; kv[it][1] = 0;
+            const size_t t = t0 + tid + (size_t)it * MSM_BIN_THREADS;
+            if (t < t1) {
+                u32 h[MSM_HALF_WORDS];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { const uint4 v = hv[j][q]; h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w; }
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const u32 key = msm_key_at(h, half, 0, wc, pl);
+                    if (key) {
+                        u32 bkt = key >> 1;
+                        if (top) {
+                            if (bkt * L.sub > L.top_used - 1u) { over = 1; continue; }
+                            bkt = (bkt - 1u) * L.sub + ((u32)t & (L.sub - 1u)) + 1u;
+                        }
+                        const u32 rank = atomicAdd(&s_cnt[bkt], 1u);
+                        kv[it][half] = 0x40000000u | ((key & 1u) << 31) | (bkt << 16) | rank;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // reservation + exclusive scan: lane t owns counters 4t .. 4t+3 (lane 1023 also the last one, 4096)
+    u32 c[5], g[5], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const u32 b = 4u * tid + (u32)j; c[j] = (j < 4 || tid == MSM_BIN_THREADS - 1) ? s_cnt[b] : 0u; sum += c[j]; }
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const u32 b = 4u * tid + (u32)j; g[j] = (c[j] && b < pl.nb) ? atomicAdd(&gcnt[w * pl.nb + b], c[j]) : 0u; }
+    u32 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 x = (u32)__shfl_up((int)inc, d, 64); if ((tid & 63u) >= (u32)d) inc += x; }
+    if ((tid & 63u) == 63u) s_wave[tid >> 6] = inc;
+    __syncthreads();
+    if (tid == 0) { u32 run = 0; for (int q = 0; q < 16; q++) { const u32 x = s_wave[q]; s_wave[q] = run; run += x; } s_wave[16] = run; }
+    __syncthreads();
+    u32 run = s_wave[tid >> 6] + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const u32 b = 4u * tid + (u32)j;
+        if (j < 4 || tid == MSM_BIN_THREADS - 1) { s_cnt[b] = run; s_gbase[b] = (unsigned short)(g[j] < 65535u ? g[j] : 65535u); run += c[j]; }
+    }
+    if (tid == MSM_BIN_THREADS - 1) s_cnt[4097] = run;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MSM_STAGED_PER_THREAD; it++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const u32 k = kv[it][half];
+            if (k) {
+                const u32 bkt = (k >> 16) & 0x1FFFu;
+                stage[s_cnt[bkt] + (k & 0xFFFFu)] = (bkt << 15) | ((tid + (u32)it * MSM_BIN_THREADS) << 2) | ((u32)half << 1) | (k >> 31);
+            }
+        }
+    }
+    __syncthreads();
+    const u32 total = s_cnt[4097], cap = top ? L.cap_top : L.cap;
+    for (u32 i = tid; i < total; i += MSM_BIN_THREADS) {
+        const u32 v = stage[i], bkt = v >> 15, slot = (u32)s_gbase[bkt] + (i - s_cnt[bkt]);
+        if (slot < cap && (!top || bkt < L.top_used)) refs[msm_region(L, pl, w, bkt) + slot] = (u32)((t0 + ((v >> 2) & 8191u)) << 2) | (v & 3u);
+        else over = 1;
+    }
+    if (over) flags[0] = 1u;
+}
 // Two-pass binning for the widest windows (c = 14..16: from 2^22 terms).  With 2^15 buckets per window a workgroup of the single-pass
 // form has one or two references per bucket, every one a lone 4-byte store into its own region, and 2^15 counters to clear, reserve
 // and scan per workgroup.  Here the references first go, as (reference, bucket) pairs, into COARSE bins of 2^shift adjacent buckets --
@@ -1935,6 +2034,8 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
         HIPCHK(hipMemsetAsync(ccnt, 0, (size_t)pl.wn * C.nco * 4, st));
         hipLaunchKernelGGL(k_msm_bin_coarse, dim3((unsigned)((nt + MSM_COARSE_TERMS - 1) / MSM_COARSE_TERMS)), dim3(MSM_BIN_THREADS), 0, st, pairs, ccnt, flags, halves, nt, pl, L, C);
         hipLaunchKernelGGL(k_msm_bin_fine, dim3(C.nco, pl.wn), dim3(MSM_FINE_THREADS), 0, st, refs_cap, gcnt, flags, (const unsigned long long*)pairs, (const u32*)ccnt, pl, L, C);
+    } else if (pl.c <= 13 && nt >= (size_t(1) << 15) && !getenv("S2K_MSM_BIN_PLAIN")) {
+        hipLaunchKernelGGL(k_msm_bin_staged, dim3((unsigned)((nt + MSM_STAGED_TERMS - 1) / MSM_STAGED_TERMS), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L);
     } else if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
     else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
