@@ -1113,6 +1113,51 @@ extern "C" int secp256k1_rangeproof_verify_batch_wait(s2k_engine* e, uint64_t ti
     if (!e) return s2k_fail("secp256k1_rangeproof_verify_batch_wait", "null engine");
     return rp_host_wait(e, "secp256k1_rangeproof_verify_batch_wait", ticket);
 }
+// A synchronous call that finds both staging sets free takes BOTH: the batch goes as two halves, and the second half is gathered and copied
+// while the first one computes (a lone caller thread otherwise leaves the GPU idle for the ~3 ms of gathering and PCIe time of every
+// batch).  With other callers about -- a second verifier thread, tickets in flight -- the sets are not both free and the call goes in one
+// piece, as before: those callers overlap among themselves.  $S2K_SYNC_SPLIT=0 turns the halving off.
+#define RP_SYNC_SPLIT_MIN 8192
+static int rp_host_sync(s2k_engine* e, const char* who, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n) {
+    uint64_t ticket[2] = {0, 0};
+    int parts = 1;
+    {
+        std::unique_lock<std::recursive_mutex> lock(e->mu);
+        HIPCHK(hipSetDevice(e->device));
+        static const int allow = [] { const char* v = getenv("S2K_SYNC_SPLIT"); return v ? atoi(v) != 0 : 1; }();
+        if (allow && n >= RP_SYNC_SPLIT_MIN && !e->stage[0].ticket && !e->stage[1].ticket) parts = 2;
+        const size_t h = parts == 2 ? ((n / 2 + 63) & ~size_t(63)) : n;
+        rp_host_src a = src, b = src;
+        std::vector<uint64_t> poff_b, eoff_b;
+        if (parts == 2) {
+            if (src.commit_objs) {
+                b.commit_objs += h; b.proof_ptrs += h; b.plens += h; b.gen_objs += h;
+                if (src.extra_ptrs) { b.extra_ptrs += h; b.elens += h; }
+            } else {
+                b.commits33 += 33 * h; b.gens64 += 64 * h;
+                poff_b.resize(n - h + 1);
+                for (size_t i = 0; i <= n - h; i++) poff_b[i] = src.proof_off[h + i] - src.proof_off[h];
+                b.proofs += src.proof_off[h]; b.proof_off = poff_b.data();
+                if (src.extra && src.extra_off) {
+                    eoff_b.resize(n - h + 1);
+                    for (size_t i = 0; i <= n - h; i++) eoff_b[i] = src.extra_off[h + i] - src.extra_off[h];
+                    b.extra += src.extra_off[h]; b.extra_off = eoff_b.data();
+                }
+            }
+        }
+        if (!rp_host_submit(e, who, &ticket[0], results, min_value, max_value, a, h, &lock)) return 0;
+        if (parts == 2 && !rp_host_submit(e, who, &ticket[1], results + h, min_value + h, max_value + h, b, n - h, &lock)) {
+            lock.unlock();
+            (void)rp_host_wait(e, who, ticket[0]);
+            memset(results, 0, sizeof(int32_t) * n);                      // an engine failure never leaves part of a batch marked valid
+            return 0;
+        }
+    }
+    int ok = rp_host_wait(e, who, ticket[0]);
+    if (parts == 2) ok &= rp_host_wait(e, who, ticket[1]);
+    if (!ok) memset(results, 0, sizeof(int32_t) * n);
+    return ok;
+}
 extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                  const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
                                                  const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n) {
@@ -1120,13 +1165,7 @@ extern "C" int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results
     if (n == 0) return 1;
     memset(results, 0, sizeof(int32_t) * n);
     rp_host_src src{}; src.commits33 = commits33; src.proofs = proofs; src.proof_off = proof_off; src.extra = extra; src.extra_off = extra_off; src.gens64 = gens64;
-    uint64_t ticket = 0;
-    {
-        std::unique_lock<std::recursive_mutex> lock(e->mu);
-        HIPCHK(hipSetDevice(e->device));
-        if (!rp_host_submit(e, "secp256k1_rangeproof_verify_batch", &ticket, results, min_value, max_value, src, n, &lock)) return 0;
-    }
-    return rp_host_wait(e, "secp256k1_rangeproof_verify_batch", ticket);
+    return rp_host_sync(e, "secp256k1_rangeproof_verify_batch", results, min_value, max_value, src, n);
 }
 extern "C" int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs,
                                                       const unsigned char* const* proofs, const size_t* plens, const unsigned char* const* extra, const size_t* elens,
@@ -1137,13 +1176,7 @@ extern "C" int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* re
     if (!rp_ptrs_check(who, results, min_value, max_value, commit_objs, proofs, plens, extra, elens, gen_objs, n)) return 0;
     memset(results, 0, sizeof(int32_t) * n);
     rp_host_src src{}; src.commit_objs = commit_objs; src.proof_ptrs = proofs; src.plens = plens; src.extra_ptrs = extra; src.elens = elens; src.gen_objs = gen_objs;
-    uint64_t ticket = 0;
-    {
-        std::unique_lock<std::recursive_mutex> lock(e->mu);
-        HIPCHK(hipSetDevice(e->device));
-        if (!rp_host_submit(e, who, &ticket, results, min_value, max_value, src, n, &lock)) return 0;
-    }
-    return rp_host_wait(e, who, ticket);
+    return rp_host_sync(e, who, results, min_value, max_value, src, n);
 }
 // rewind: verification + recovery (rangeproof_rewind.h); host buffers
 extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results, unsigned char* blind_out, uint64_t* value_out, unsigned char* message_out,
