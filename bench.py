@@ -288,6 +288,11 @@ def cpu_baseline_ref_benches():
     out["bench_rangeproof_64_all_cores"] = {"processes": len(rs), "pinned_to": cpus, "wall_s": wall,
                                             "verifies_per_s": sum(1e6 / (64 * r[1]) for r in rs),
                                             "us_per_bit_avg_min_max_over_processes": (min(r[1] for r in rs), max(r[1] for r in rs))}
+    bmain = os.path.join(d, "bench")                                           # src/bench.c (public API): BIP-340 verification per item
+    if os.path.exists(bmain) and os.access(bmain, os.X_OK):
+        sv = _run_ref_bench(bmain, ["schnorrsig_verify"], 4000).get("schnorrsig_verify")
+        if sv:
+            out["bench_schnorrsig_verify"] = {"us_per_verify_min_avg_max": sv, "verifies_per_s_one_process": 1e6 / sv[1]}
     ec = _run_ref_bench(bec, ["pippenger_wnaf"], 400)
     big = ec.get("ecmult_multi_32767p_g")
     if big:
