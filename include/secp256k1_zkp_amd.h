@@ -55,7 +55,10 @@ S2K_API void s2k_clear_status(void);
  * S2K_OPT_GEN_CACHE_SLOTS (default 2, 0..8; $S2K_GEN_CACHE): how many rangeproof generators may have a fixed-base table at a time
  *   (11.8 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.
  * S2K_OPT_GEN_CACHE_MIN (default 65536; $S2K_GEN_CACHE_MIN): an uncached generator gets a table automatically once this many proofs
- *   carrying it have been seen (host-buffer calls count before the launch, `_dev` calls through a device mailbox read at the next call). */
+ *   carrying it have VERIFIED (the last kernel of a call reports them through a device mailbox that the next call reads: junk proofs
+ *   that merely name a generator never cost a table).  At most one automatic table is built per call, and it only takes a free slot
+ *   or the slot of another automatic table -- never the table of secp256k1_generator_h or one requested through
+ *   s2k_engine_cache_generator. */
 #define S2K_OPT_RP_INPUTS_READY 1
 #define S2K_OPT_RP_SPLIT 2
 #define S2K_OPT_GEN_CACHE_SLOTS 3
@@ -66,7 +69,7 @@ S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
  * generator a ring builds its odd-multiples tables once instead of four times (~20 % less work per proof).  The table of
  * secp256k1_generator_h (include/secp256k1_generator.h:36) is built at the first rangeproof call; other generators get one through
  * this call (gen64: the 64 bytes of a secp256k1_generator object, host memory) or automatically (S2K_OPT_GEN_CACHE_MIN); the least
- * recently used table makes room.  Proofs whose generator has no table take the general form of the kernel: results never depend on
+ * recently used table makes room ("used" = served proofs that verified, whichever entry point they came through).  Proofs whose generator has no table take the general form of the kernel: results never depend on
  * the cache.  s2k_engine_generator_cached: 1 when gen64 has a table now. */
 S2K_API int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* gen64);
 S2K_API int s2k_engine_generator_cached(s2k_engine* e, const unsigned char* gen64);
@@ -83,6 +86,12 @@ S2K_API float s2k_engine_last_ms(s2k_engine* e, int which);
 /* 1 if the most recent MSM launch on this engine overflowed a bucket region and took the exact bucket-free path (diagnostics /
  * tests; synchronises the device). */
 S2K_API int s2k_engine_last_msm_fallback(s2k_engine* e);
+/* Work-list tallies of the most recent rangeproof call on this engine (diagnostics / tests; synchronises the device):
+ * out[0] = ring groups the shared-generator form of the rings kernel was given, out[1] = rings the general form processed (its own
+ * plus the ones handed back), out[2] = rings handed back because a ring key may be the point at infinity (the reference rejects such a
+ * key, src/modules/rangeproof/borromean_impl.h:78), out[3] = rings handed back after an exceptional addition inside a step.
+ * (A call of more than two launch groups reports its last two.) */
+S2K_API int s2k_engine_rp_handback(s2k_engine* e, uint32_t out[4]);
 
 /* ---- batch double multiplication ---------------------------------------------------------------------------
  * r[i] = na[i]*A[i] + ng[i]*G          replaces: static void secp256k1_ecmult(secp256k1_gej *r,

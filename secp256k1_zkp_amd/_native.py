@@ -28,6 +28,7 @@ SIGNATURES = {
     "s2k_engine_gtable": (_vp, [_vp, _c.POINTER(_sz)]),
     "s2k_engine_last_ms": (_c.c_float, [_vp, _c.c_int]),
     "s2k_engine_last_msm_fallback": (_c.c_int, [_vp]),
+    "s2k_engine_rp_handback": (_c.c_int, [_vp, _vp]),
     "s2k_ecmult_batch": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
     "s2k_ecmult_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "s2k_ecmult_multi": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),

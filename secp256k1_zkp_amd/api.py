@@ -100,6 +100,13 @@ class Engine:
         """True if the most recent bucket MSM re-sorted exactly after a bucket region overflowed."""
         return bool(self._lib.s2k_engine_last_msm_fallback(self._h))
 
+    def rp_handback(self):
+        """(groups given to the shared-generator form, rings through the general form, rings handed back as suspect, rings handed back
+        after an exceptional addition) of the most recent rangeproof call (s2k_engine_rp_handback; synchronises)."""
+        out = np.zeros(4, np.uint32)
+        self._check(self._lib.s2k_engine_rp_handback(self._h, _p(out)), "s2k_engine_rp_handback")
+        return tuple(int(x) for x in out)
+
     # ---- secp256k1_ecmult (src/ecmult.h:47), batched ------------------------------------------------------
     def ecmult_batch(self, a_xy, na, ng=None, a_inf=None):
         a_xy = _u8(a_xy); n = a_xy.size // 64

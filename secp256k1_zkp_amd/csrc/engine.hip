@@ -76,6 +76,7 @@ struct s2k_engine {
     hipEvent_t ev_rp_in, ev_rp_fork[2], ev_rp_join[2], ev_rp_pre[2], ev_rp_done[2], ev_rp_draws, ev_rp_rewound;
     int rp_rewound_valid;
     int rp_done_valid[2]; unsigned rp_seq;
+    const u32* rp_last_plan[2];   // the work-list headers of the most recent call's last two launch groups (s2k_engine_rp_handback)
     hipEvent_t ev_ring[32][2]; unsigned ring_seq;   // the dominant kernel of the 32 most recent rangeproof calls (several calls may be in flight)
     hipStream_t last_stream; int last_stream_valid; hipEvent_t ev_last;   // see stream_guard
     hipEvent_t ev_msm_fork, ev_msm_join;   // the MSM's gated exact path runs on the side stream, next to the bucket pipeline
@@ -89,10 +90,11 @@ struct s2k_engine {
     // Fixed-base tables of rangeproof generators (rangeproof.h, shared-generator form of the rings kernel): a small cache keyed by the 64
     // generator bytes.  Slot tables have the layout of gtab (S2K_GTAB_WORDS words, allocated when a slot is first used and then reused by
     // whatever generator takes the slot); xmul is the x-table of the ring-base multiples (RP_XMUL_WORDS).  gen_keys (device) is what
-    // k_rp_header matches a proof's generator against; gen_seen counts the proofs met per uncached generator (host-buffer calls count
-    // directly, `_dev` calls through the device mailbox gen_mbox / its pinned copy) and a generator is built once it reaches gen_min.
-    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; } gen[RP_GEN_SLOTS];
-    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty; int gen_scanned;
+    // k_rp_header matches a proof's generator against; gen_seen counts the VERIFIED proofs met per uncached generator (reported by
+    // k_rp_final through the device mailbox gen_mbox / its pinned copy, read at the next call) and a generator is built once it reaches
+    // gen_min.  `pinned`: secp256k1_generator_h and generators cached explicitly -- an automatic build never evicts those.
+    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; int pinned; } gen[RP_GEN_SLOTS];
+    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty;
     unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
     rp_gen_mbox* gen_mbox;     // device
     rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
@@ -280,13 +282,20 @@ static int gen_cache_find(s2k_engine* e, const unsigned char* key) {
 }
 // Builds (stream-ordered on `st`) the tables of `key` into a free slot or the least recently used one; -1 when there is no memory for a
 // table (the proofs then simply keep the general form).  Everything that may still read the slot's old content was queued on `st`
-// before (stream_guard) or waits for gen_dirty (rp_launch).
-static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key) {
+// before (stream_guard) or waits for gen_dirty (rp_launch).  pinned = 0 is an AUTOMATIC build (a generator that kept coming on valid
+// proofs): it only takes a free slot or the slot of another automatically built table -- never the table of secp256k1_generator_h or
+// one the application asked for -- and returns -1 when there is none.
+static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key, int pinned) {
     int slot = gen_cache_find(e, key);
-    if (slot >= 0) return slot;
+    if (slot >= 0) { if (pinned) e->gen[slot].pinned = 1; return slot; }
     if (e->gen_slots <= 0) return -1;
-    slot = 0;
-    for (int i = 0; i < e->gen_slots; i++) { if (!e->gen[i].valid) { slot = i; break; } if (e->gen[i].stamp < e->gen[slot].stamp) slot = i; }
+    slot = -1;
+    for (int i = 0; i < e->gen_slots; i++) {
+        if (!e->gen[i].valid) { slot = i; break; }
+        if (!pinned && e->gen[i].pinned) continue;
+        if (slot < 0 || e->gen[i].stamp < e->gen[slot].stamp) slot = i;
+    }
+    if (slot < 0) return -1;
     s2k_engine::gen_slot& g = e->gen[slot];
     if (!g.tab) {
         if (hipMalloc((void**)&g.tab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }
@@ -300,7 +309,7 @@ static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* k
     hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, g.tab);
     hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, e->gen_keys + 64 * slot, e->gtab, e->ptab);
     if (hipGetLastError() != hipSuccess) return -1;
-    g.valid = 1; g.stamp = ++e->gen_clock;
+    g.valid = 1; g.pinned = pinned; g.stamp = ++e->gen_clock;
     e->gen_dirty = 1;
     return slot;
 }
@@ -318,18 +327,24 @@ static int gen_note_seen(s2k_engine* e, const unsigned char* key, size_t count) 
 static void gen_forget_seen(s2k_engine* e, const unsigned char* key) {
     for (size_t i = 0; i < e->gen_seen.size(); i++) if (!memcmp(e->gen_seen[i].first.data(), key, 64)) { e->gen_seen.erase(e->gen_seen.begin() + i); return; }
 }
-// Start of a rangeproof call: (1) secp256k1_generator_h gets its table once, (2) what the header kernels of the call before reported
-// through the mailbox is counted (its pinned copy is only read once the copy has completed) and generators that are due are built.
+// Start of a rangeproof call: (1) secp256k1_generator_h gets its table once, (2) what the final kernels of the call before reported
+// through the mailbox (its pinned copy is only read once the copy has completed): tables that served valid proofs get a fresh
+// least-recently-used stamp, uncached generators are counted by their VALID proofs and at most one that is due is built per call.
 static void gen_cache_service(s2k_engine* e, hipStream_t st) {
     if (e->gen_slots <= 0) return;
-    if (e->gen_h == 1) { e->gen_h = 2; (void)gen_cache_build(e, st, k_generator_h); }
+    if (e->gen_h == 1) { e->gen_h = 2; (void)gen_cache_build(e, st, k_generator_h, 1); }
     if (e->mbox_pending && hipEventQuery(e->ev_mbox) == hipSuccess) {
         e->mbox_pending = 0;
+        for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && e->gen_mbox_host->hits[i]) e->gen[i].stamp = ++e->gen_clock;
+        int built = 0;
         for (int m = 0; m < RP_GEN_MBOX; m++) {
             if (!e->gen_mbox_host->tag[m] || !e->gen_mbox_host->count[m]) continue;
             const unsigned char* key = e->gen_mbox_host->key[m];
-            if (gen_cache_find(e, key) >= 0) continue;
-            if (gen_note_seen(e, key, e->gen_mbox_host->count[m]) && gen_cache_build(e, st, key) >= 0) gen_forget_seen(e, key);
+            if (rp_gen_tag(key) != e->gen_mbox_host->tag[m]) continue;          // (key bytes of a slot whose claimant never wrote them)
+            int cached = 0;
+            for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, key, 64)) cached = 1;
+            if (cached) continue;
+            if (gen_note_seen(e, key, e->gen_mbox_host->count[m]) && !built && gen_cache_build(e, st, key, 0) >= 0) { gen_forget_seen(e, key); built = 1; }
         }
     } else if (e->mbox_pending) (void)hipGetLastError();
 }
@@ -357,6 +372,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->last_stream = nullptr; e->last_stream_valid = 0; e->ev_last = nullptr; e->ev_msm_fork = nullptr; e->ev_msm_join = nullptr;
     e->ev_rp_draws = nullptr; e->ev_rp_rewound = nullptr; e->rp_rewound_valid = 0;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
+    e->rp_last_plan[0] = e->rp_last_plan[1] = nullptr;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
@@ -364,9 +380,11 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->next_ticket = 1; e->stream_copy = nullptr;
     { unsigned hc = std::thread::hardware_concurrency(); e->stage_threads = (int)std::min(8u, std::max(1u, hc / 2)); }
     if (const char* th = getenv("S2K_STAGE_THREADS")) { const int v = atoi(th); if (v >= 1 && v <= 64) e->stage_threads = v; }
+#ifdef S2K_DIAG          /* diagnostic builds only (tools/rings_parts.py builds its own library with -DS2K_DIAG): a verifier's verdicts never depend on the environment */
     if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
-    for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; }
-    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0; e->gen_scanned = 0;
+#endif
+    for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; e->gen[i].pinned = 0; }
+    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0;
     e->gen_keys = nullptr; e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
     if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); e->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
     if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) e->gen_min = (size_t)strtoull(gm, nullptr, 10);
@@ -484,6 +502,20 @@ extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) {
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&f, e->dev_flags, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return f != 0;
 }
+extern "C" int s2k_engine_rp_handback(s2k_engine* e, uint32_t out[4]) {
+    if (!e || !out) return s2k_fail_arg("s2k_engine_rp_handback", "illegal argument");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    for (int i = 0; i < 2; i++) {
+        if (!e->rp_last_plan[i]) continue;
+        u32 v[4];
+        HIPCHK(hipMemcpy(v, e->rp_last_plan[i], sizeof(v), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; k++) out[k] += v[k];
+    }
+    return 1;
+}
 #ifdef S2K_PROF
 // diagnostic builds only: read (and clear) the per-region cycle table of s2k_common.h
 extern "C" __attribute__((visibility("default"))) int s2k_prof_read(unsigned long long out[16]) {
@@ -572,17 +604,15 @@ extern "C" int s2k_ecmult_batch(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_rp_header(rp_ws ws, uint64_t* min_value, uint64_t* max_value, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* gens64,
-            rp_gen_dev gc, rp_gen_mbox* mbox, size_t n) {
+            rp_gen_dev gc, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    if (p == 0) { ws.plan[0] = 0; ws.plan[1] = 0; }           // the work lists of K3 (k_rp_sum fills them)
+    if (p == 0) { ws.plan[0] = 0; ws.plan[1] = 0; ws.plan[2] = 0; ws.plan[3] = 0; }           // the work lists of K3 (k_rp_sum fills them) and the hand-back tallies
     uint64_t mn, mx;
     rp_header(ws.rec[p], &mn, &mx, proofs + proof_off[p], proof_off[p + 1] - proof_off[p]);
     min_value[p] = mn; max_value[p] = mx;
-    // which cached generator table (if any) serves this proof; a generator without one is reported for the host's build decision
-    const u32 slot = rp_gen_lookup(gc, gens64 + 64 * p);
-    ws.rec[p].gslot = slot;
-    if (slot == RP_GSLOT_NONE && mbox && (ws.rec[p].hdr & 1u)) rp_gen_report_miss(mbox, gens64 + 64 * p, p, n);
+    // which cached generator table (if any) serves this proof (a generator without one is reported by k_rp_final, for proofs that verified)
+    ws.rec[p].gslot = rp_gen_lookup(gc, gens64 + 64 * p);
 }
 // three waves per 64 proofs: wave 0 commitment + min_value*H, wave 1 generator flag + message hash, wave 2 ring bases
 __global__ void __launch_bounds__(192)
@@ -672,10 +702,11 @@ k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint
                           raw0 + (lanes >> 6) * S2K_RRAW_WAVE_WORDS + wave * (S2K_RP_K * RP_PARK_WORDS * 64) + lane, S2K_LANE_DIG(s_dig)};
     const int served = rp_rings_shared<S2K_RP_K>(rec, ws.pub0 + (p * RP_MAX_RINGS + g * S2K_RP_K) * RP_GEJ_WORDS, ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS,
                                                  proofs + proof_off[p], g * S2K_RP_K, live, gtab, gc.tab[sl], gc.xmul[sl], M, ev ? ev + p * (RP_MAX_RINGS * 32) : nullptr, dbg);
-    if (!served && live) {                          // (wavefront-uniform verdict) hand this lane's rings to the general form
+    if (served != RP_SHARED_SERVED && live) {       // (wavefront-uniform verdict) hand this lane's rings to the general form
         const u32 r0 = g * S2K_RP_K, cnt = rec.rings - r0 < S2K_RP_K ? rec.rings - r0 : S2K_RP_K;
         const u32 base = atomicAdd(&ws.plan[1], cnt);
         for (u32 i = 0; i < cnt; i++) ws.mapG[base + i] = (u32)p | ((r0 + i) << 20);
+        atomicAdd(&ws.plan[served == RP_SHARED_SUSPECT ? 2 : 3], cnt);      // diagnostics: s2k_engine_rp_handback
     }
 }
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
@@ -694,10 +725,23 @@ k_rp_rings(rp_ws ws, const unsigned char* __restrict__ proofs, const uint64_t* _
             split ? ws.dbases + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (const u32*)nullptr, split ? ws.tcur + (p * RP_MAX_RINGS + ring) * RP_GEJ_WORDS : (u32*)nullptr);
 }
 __global__ void __launch_bounds__(64)
-k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {
+k_rp_final(rp_ws ws, int32_t* results, const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* gens64, rp_gen_mbox* mbox, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    results[p] = rp_final(ws.rec[p], ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
+    int ok = 0; u32 gslot = RP_GSLOT_NONE;
+    if (p < n) {
+        ok = rp_final(ws.rec[p], ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS, proofs + proof_off[p]);
+        results[p] = ok;
+        gslot = ws.rec[p].gslot;
+    }
+    // the generator-table cache's bookkeeping, from VERIFIED proofs only: which cached tables were of use (least-recently-used stamps),
+    // which uncached generators keep coming (candidates for a table)
+    if (mbox) {
+        for (u32 sl = 0; sl < RP_GEN_SLOTS; sl++) {
+            const unsigned long long m = __ballot(ok && gslot == sl);
+            if (m && threadIdx.x == 0) atomicAdd(&mbox->hits[sl], (u32)__popcll(m));
+        }
+        rp_gen_report_miss(mbox, gens64 + 64 * (p < n ? p : 0), ok && gslot == RP_GSLOT_NONE);
+    }
 }
 
 // rewinding (rangeproof_rewind.h): one lane per proof that verified
@@ -779,7 +823,7 @@ static int engine_rp_slots(s2k_engine* e, size_t nw) {
     const size_t bytes = (rp_ws_bytes(nw) + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
     if (bytes <= e->rp_mem_bytes) return 1;
     HIPCHK(hipDeviceSynchronize());                 // earlier launches may still use the old records
-    for (int i = 0; i < 2; i++) { if (e->rp_mem[i]) HIPCHK(hipFree(e->rp_mem[i])); e->rp_mem[i] = nullptr; e->rp_done_valid[i] = 0; }
+    for (int i = 0; i < 2; i++) { if (e->rp_mem[i]) HIPCHK(hipFree(e->rp_mem[i])); e->rp_mem[i] = nullptr; e->rp_done_valid[i] = 0; e->rp_last_plan[i] = nullptr; }
     e->rp_mem_bytes = 0;
     for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void**)&e->rp_mem[i], bytes));
     e->rp_mem_bytes = bytes;
@@ -802,8 +846,6 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     if (!engine_rtab(e, nw * RP_MAX_RINGS)) return 0;
     gen_cache_service(e, st);
     const rp_gen_dev gc = gen_dev_view(e);
-    const int count_misses = e->gen_slots > 0 && !e->gen_scanned;      // (a host-buffer call has counted its generators already)
-    e->gen_scanned = 0;
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
     const hipStream_t sp = e->stream_pre;
@@ -816,10 +858,12 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
         const int slot = (int)(e->rp_seq++ & 1u);
         ws_carver c{e->rp_mem[slot], 0}; rp_ws w; rp_ws_carve(w, c, nw);
+        if (p0 == 0) e->rp_last_plan[slot ^ 1] = nullptr;
+        e->rp_last_plan[slot] = w.plan;
         // ---- side streams
         if (e->rp_done_valid[slot]) HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_done[slot], 0));
         hipLaunchKernelGGL(k_rp_header, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, sp, w, min_value + p0, max_value + p0, proofs, proof_off + p0, gens64 + 64 * p0,
-                           gc, count_misses ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
+                           gc, m);
         HIPCHK(hipEventRecord(e->ev_rp_fork[slot], sp));
         HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_rp_fork[slot], 0));
         hipLaunchKernelGGL(k_rp_lift, dim3(b256), dim3(256), 0, e->stream2, w, proofs, proof_off + p0, m);
@@ -846,7 +890,8 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
                                          rewind ? rewind->ev : (u32*)nullptr, gc, (u32)e->rp_debug);
         hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
-        hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, m);
+        hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, gens64 + 64 * p0,
+                           e->gen_slots > 0 ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
         if (rewind) {
             rp_rewind_args ra = *rewind;                      // scratch is per chunk, the caller's arrays are per batch
             ra.blind_out += 32 * p0; ra.value_out += p0; ra.nonces += 32 * p0;
@@ -865,23 +910,6 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
 }
-// Host-side view of a batch's generators (host-buffer entry points): every generator that appears often enough gets its table before
-// the launch, so such a batch takes the shared-generator form from its first call.
-static void gen_cache_scan_host(s2k_engine* e, hipStream_t st, const unsigned char* gens64, size_t n) {
-    if (e->gen_slots <= 0) return;
-    e->gen_scanned = 1;
-    std::vector<std::pair<const unsigned char*, size_t>> distinct;
-    for (size_t i = 0; i < n; i++) {
-        const unsigned char* g = gens64 + 64 * i;
-        size_t k = 0;
-        for (; k < distinct.size(); k++) if (!memcmp(distinct[k].first, g, 64)) { distinct[k].second++; break; }
-        if (k == distinct.size()) { if (distinct.size() >= 32) return; distinct.emplace_back(g, 1); }      // many different generators: nothing to share
-    }
-    for (auto& d : distinct) {
-        if (gen_cache_find(e, d.first) >= 0) continue;
-        if (gen_note_seen(e, d.first, d.second) && gen_cache_build(e, st, d.first) >= 0) gen_forget_seen(e, d.first);
-    }
-}
 // Builds the tables of one generator now (host bytes: the 64-byte secp256k1_generator object, include/secp256k1_generator.h:22-24).
 // Returns 1 when the generator has a table afterwards.
 extern "C" int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* gen64) {
@@ -890,7 +918,7 @@ extern "C" int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* ge
     HIPCHK(hipSetDevice(e->device));
     stream_guard sg(e, e->stream);
     if (e->gen_h == 1 && !memcmp(gen64, k_generator_h, 64)) e->gen_h = 2;
-    if (gen_cache_build(e, e->stream, gen64) < 0) return s2k_fail("s2k_engine_cache_generator", "no slot or no memory for a generator table (S2K_GEN_CACHE)");
+    if (gen_cache_build(e, e->stream, gen64, 1) < 0) return s2k_fail("s2k_engine_cache_generator", "no slot or no memory for a generator table (S2K_GEN_CACHE)");
     return 1;
 }
 // 1 when `gen64` currently has a table
@@ -1006,7 +1034,6 @@ static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int3
         if (ptrs) { for (size_t i = 0; i < n; i++) if (eoff[i + 1] > eoff[i]) memcpy(hs + o_ex + eoff[i], src.extra_ptrs[i], (size_t)(eoff[i + 1] - eoff[i])); }
         else if (ebytes) memcpy(hs + o_ex, src.extra, ebytes);
     }
-    gen_cache_scan_host(e, st, hs + o_gen, n);
     const auto t_small = now();
     HIPCHK(hipMemcpyAsync(ds + o_com, hs + o_com, o_pr - o_com, hipMemcpyHostToDevice, cp));          // everything in front of the proofs in one piece
     // proofs: RP_STAGE_CHUNKS pieces of whole proofs, packed by `nt` threads (piece c by thread c % nt), queued as they complete
@@ -1214,7 +1241,6 @@ extern "C" int secp256k1_rangeproof_rewind_batch(s2k_engine* e, int32_t* results
     HIPCHK(hipMemcpyAsync((void*)ra.nonces, nonces, 32 * n, hipMemcpyHostToDevice, st));
     if (message_out) { HIPCHK(hipMemcpyAsync(ra.outlen, outlen, 8 * n, hipMemcpyHostToDevice, st)); HIPCHK(hipMemsetAsync(ra.msg_out, 0, mbytes, st)); }
     else HIPCHK(hipMemsetAsync(ra.outlen, 0, 8 * n, st));
-    gen_cache_scan_host(e, st, gens64, n);
     if (!rp_launch(e, st, d_res, d_min, d_max, d_com, d_pr, d_off, (extra && extra_off) ? d_ex : nullptr, (extra && extra_off) ? d_eoff : nullptr, d_gen, n, &ra, 1)) return 0;
     HIPCHK(hipMemcpyAsync(results, d_res, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(min_value, d_min, 8 * n, hipMemcpyDeviceToHost, st));
@@ -2060,7 +2086,10 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
-    u32 bin_dbg = 0; if (const char* bd = getenv("S2K_MSM_BIN_DEBUG")) bin_dbg = ((u32)atoi(bd) & 7u) << 24;      // diagnostic launches of k_msm_bin (parts switched off)
+    u32 bin_dbg = 0;
+#ifdef S2K_DIAG          /* diagnostic builds only: launches of k_msm_bin with parts switched off (results are meaningless then) */
+    if (const char* bd = getenv("S2K_MSM_BIN_DEBUG")) bin_dbg = ((u32)atoi(bd) & 7u) << 24;
+#endif
     const int two_pass = (pl.c > 13 || getenv("S2K_MSM_TWO_PASS")) && !getenv("S2K_MSM_ONE_PASS");
     if (two_pass) {
         const msm_coarse C = msm_make_coarse(nt, pl, L);

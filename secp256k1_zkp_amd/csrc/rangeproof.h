@@ -409,11 +409,19 @@ struct rp_gen_dev {                       // by value to the kernels: the cache 
     u32 valid;                            // bit i: slot i holds a table
     u32 any;                              // index of some valid slot (idle lanes read its x-table)
 };
-// generators that had no table: the first few distinct ones of a call with the number of proofs that carried them.  A slot is claimed
-// by a 64-bit tag of the generator bytes (one compare-and-swap; lanes with the same generator then only count), so nothing on the
-// device ever waits for another lane's key bytes -- the host reads those after the kernel.  Two generators with the same tag would
-// share a count: harmless, the count only decides whether a table is worth building.
-struct rp_gen_mbox { unsigned long long tag[RP_GEN_MBOX]; u32 count[RP_GEN_MBOX]; unsigned char key[RP_GEN_MBOX][64]; };
+// Generators that had no table, reported by the LAST stage (k_rp_final) for proofs that VERIFIED only -- an attacker cannot make the
+// engine spend 0.3 s and 11.8 GB on a table by sending junk proofs that merely name a generator (the first few distinct generators of
+// a call, with the number of valid proofs that carried them).  A slot is claimed by a 64-bit tag of the generator bytes (one
+// compare-and-swap; lanes with the same generator then only count), so nothing on the device ever waits for another lane's key bytes
+// -- the host reads those after the call and ignores a slot whose bytes do not hash to its tag.  Two generators with the same tag
+// would share a count: harmless, the count only decides whether a table is worth building.
+// hits[s]: valid proofs served by cached slot s in this call (the host refreshes the slot's least-recently-used stamp from it).
+struct rp_gen_mbox { unsigned long long tag[RP_GEN_MBOX]; u32 count[RP_GEN_MBOX]; u32 hits[RP_GEN_SLOTS]; unsigned char key[RP_GEN_MBOX][64]; };
+S2K_HD unsigned long long rp_gen_tag(const unsigned char* gen64) {
+    unsigned long long h = 0xCBF29CE484222325ull;
+    for (int k = 0; k < 64; k++) { h ^= gen64[k]; h *= 0x100000001B3ull; }
+    return h ? h : 1ull;
+}
 S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
     u32 slot = RP_GSLOT_NONE;
     for (u32 i = 0; i < RP_GEN_SLOTS; i++) {
@@ -425,12 +433,19 @@ S2K_HD u32 rp_gen_lookup(const rp_gen_dev& gc, const unsigned char* gen64) {
     return slot;
 }
 #if defined(__HIPCC__) || defined(__HIP__)
-__device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64, size_t p, size_t n) {
+// called by every lane of a (64-lane) wavefront; `report`: this lane holds a valid proof whose generator has no table
+__device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsigned char* gen64, int report) {
+    const unsigned long long mask = __ballot(report);
+    if (!mask) return;
     // a batch in which every proof has its own generator makes every lane come here: a slot that is taken by another tag is skipped
-    // on a plain load (no atomic), and only every 16th proof counts, for the 16 proofs from itself on -- the count is a heuristic
-    unsigned long long h = 0xCBF29CE484222325ull;
-    for (int k = 0; k < 64; k++) { h ^= gen64[k]; h *= 0x100000001B3ull; }
-    if (!h) h = 1;
+    // on a plain load (no atomic); a wavefront whose reporting lanes all name the same generator (the common case) counts once
+    const int leader = __ffsll((long long)mask) - 1;
+    const unsigned long long h = report ? rp_gen_tag(gen64) : 0ull;
+    const unsigned long long h0 = __shfl(h, leader);
+    const int uniform = __all(!report || h == h0);
+    u32 weight = 1u;
+    if (uniform) { if ((int)(threadIdx.x & 63u) != leader) return; weight = (u32)__popcll(mask); }
+    else if (!report) return;
     for (int m = 0; m < RP_GEN_MBOX; m++) {
         unsigned long long old = *(volatile unsigned long long*)&mb->tag[m];
         if (old != 0ull && old != h) continue;
@@ -439,7 +454,7 @@ __device__ __forceinline__ void rp_gen_report_miss(rp_gen_mbox* mb, const unsign
             if (old == 0ull) { for (int k = 0; k < 64; k++) mb->key[m][k] = gen64[k]; }
             else if (old != h) continue;
         }
-        if ((p & 15u) == 0) atomicAdd(&mb->count[m], (u32)(n - p < 16 ? n - p : 16));
+        atomicAdd(&mb->count[m], weight);
         return;
     }
 }
@@ -487,12 +502,16 @@ S2K_HD int rp_ring_suspect(const gej& C, const u32* xmul /* this (exp, ring)'s 3
 // flag -- is parked next to the point.
 // Memory of a lane (rp_shared_mem): rtab = K x S2K_RTAB_WORDS of its own (finished tables); raw = its column of the wavefront's
 // table-construction parking area; park = its column of the wavefront's K x RP_PARK_WORDS area (word stride S2K_RAW_WS like raw).
-// Returns 0 without having written any result when the wavefront has to take rp_ring instead (a suspect ring, an exceptional addition).
+// Returns RP_SHARED_SERVED, or -- the wavefront then has to take rp_ring instead, nothing this call wrote is final -- RP_SHARED_SUSPECT (a ring
+// key that may be infinity) / RP_SHARED_EXCEPTIONAL (an exceptional addition inside a step).
 // pub28: the key records of the proof's rings from ring0 on (Z = 1: rp_lift; rp_sum brings the last key to affine).
 #ifndef S2K_RP_K
 #define S2K_RP_K 1                      /* rings per lane in the engine's shared-generator kernel; K > 1 shares the inversion of a ring position between K
                                            rings but keeps K times the tables alive: measured on MI355X 15.5 (K=1) / 15.75 (2) / 15.85 ms (4) per 2^14 proofs */
 #endif
+#define RP_SHARED_SUSPECT 0
+#define RP_SHARED_SERVED 1
+#define RP_SHARED_EXCEPTIONAL 2
 #define RP_PARK_WORDS 40                /* 0..26 point (x, y, z or 1/z), 27..34 challenge e, 35 ok, 36 good */
 struct rp_shared_mem { u32* rtab; u32* raw; u32* park; s2k_lds_ptr dig; };
 template <int K>
@@ -514,7 +533,7 @@ S2K_HD int rp_rings_shared(const rp_rec& rec, const u32* pub28, unsigned char* r
             const int ok = (ring < nrings) & !C.inf;
             if (ok) suspect |= rp_ring_suspect(C, xmul + ((size_t)e_idx * RP_MAX_RINGS + ring) * 24);
         }
-        if (S2K_WAVE_ANY(suspect)) return 0;
+        if (S2K_WAVE_ANY(suspect)) return RP_SHARED_SUSPECT;
     }
     S2K_PROF_DECL;
     // ---- per ring: key (a dummy for an idle ring), first challenge, 2^64 chain, both tables
@@ -550,7 +569,7 @@ S2K_HD int rp_rings_shared(const rp_rec& rec, const u32* pub28, unsigned char* r
         if (!(dbg & 2u)) ecmult_ring_tables(M.rtab + (size_t)q * S2K_RTAB_WORDS, M.raw, C, T);
         S2K_PROF_MARK(8);
     }
-    if (dbg & 4u) return 1;
+    if (dbg & 4u) return RP_SHARED_SERVED;
     // dummy scalars of idle rings / idle positions (any fixed nonzero values)
     const scalar dummy_e = {{0x9E3779B9u, 0x7F4A7C15u, 0xF39CC060u, 0x5CEDC834u, 0x1082276Bu, 0xF3A27251u, 0xF86C6A11u, 0x0D5A2B4Fu}};
     const scalar dummy_s = {{0x2545F491u, 0x4F6CDD1Du, 0x6C078965u, 0x5851F42Du, 0x14057B7Eu, 0xF767814Fu, 0x9FB21C65u, 0x1E35A7BDu}};
@@ -584,7 +603,7 @@ S2K_HD int rp_rings_shared(const rp_rec& rec, const u32* pub28, unsigned char* r
             S2K_PROF_MARK(0);
             // an exceptional addition somewhere in the wavefront (an operand with the accumulator's own x: adversarial inputs only): everything
             // goes back to the caller, i.e. to the general form, which starts the rings over on the keys themselves
-            if (!S2K_WAVE_ALL(ecmult_ring_step(R, M.rtab + (size_t)q * S2K_RTAB_WORDS, ens, s, f, j > 0, gtab, htab, M.dig))) return 0;
+            if (!S2K_WAVE_ALL(ecmult_ring_step(R, M.rtab + (size_t)q * S2K_RTAB_WORDS, ens, s, f, j > 0, gtab, htab, M.dig))) return RP_SHARED_EXCEPTIONAL;
             S2K_PROF_RESET;
             fe_norm_weak(R.x); fe_norm_weak(R.y);
 #pragma unroll
@@ -653,7 +672,7 @@ S2K_HD int rp_rings_shared(const rp_rec& rec, const u32* pub28, unsigned char* r
         }
         S2K_PROF_MARK(5);
     }
-    return 1;
+    return RP_SHARED_SERVED;
 }
 
 // ---- K4: close the loop (borromean_impl.h:100-103) ---------------------------------------------------------------------

@@ -128,7 +128,9 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
     } break;
     case 40: {   // the ring form (ecmult.h: ecmult_ring_tables + ecmult_ring_step) as the rangeproof rings use it: R = e*A + s*G + f*G (the table of G
                  // stands in for the generator's); a = points, b = (e || s || f) 96 bytes per item; flag = 2 * completed + infinity.  One wavefront
-                 // per 64 items (64-lane workgroups); scratch behind the flags: n * S2K_RTAB_WORDS, then one parking area per wavefront.
+                 // per 64 items (64-lane workgroups); scratch behind the flags: n * S2K_RTAB_WORDS, then one parking area per wavefront, then
+                 // n * S2K_PTAB_WORDS for the caller's fallback: a wavefront whose step returns 0 (an exceptional addition) takes the general
+                 // form on the same point, as k_rp_rings_shared -> k_rp_rings does.
         __shared__ u32 s_dig[S2K_RING_DIG_WORDS * 256];
         ge p; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32); fe_norm_weak(p.x); fe_norm_weak(p.y);
         gej A, T, R; gej_set_ge(A, p);
@@ -138,11 +140,17 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
         u32* const scratch = (u32*)flag + n;
         u32* rtab = scratch + (size_t)i * S2K_RTAB_WORDS;
         u32* raw = scratch + (size_t)n * S2K_RTAB_WORDS + (size_t)(i >> 6) * S2K_RRAW_WAVE_WORDS + (i & 63);
+        u32* ptab = scratch + (size_t)n * S2K_RTAB_WORDS + (size_t)((n + 63) >> 6) * S2K_RRAW_WAVE_WORDS + (size_t)i * S2K_PTAB_WORDS;
         ecmult_ring_tables(rtab, raw, A, T);
         const int done = S2K_WAVE_ALL(ecmult_ring_step(R, rtab, e, sg, f, 1, gtab, gtab, S2K_LANE_DIG(s_dig)));
+        if (!done) {
+            scalar sf; sc_add(sf, sg, f);
+            const lane_mem lm{ptab, S2K_LANE_DIG(s_dig)};
+            ecmult_lane(R, A, e, sf, 1, gtab, lm);
+        } else R.inf = 0;
         ge r; fe_set_zero(r.x); fe_set_zero(r.y);
-        if (done) ge_set_gej(r, R);
-        flag[i] = 2 * done;
+        if (!R.inf) ge_set_gej(r, R);
+        flag[i] = 2 * done + (R.inf ? 1 : 0);
         fe_normalize(r.x); fe_normalize(r.y); fe_get_b32(out + 64 * i, r.x); fe_get_b32(out + 64 * i + 32, r.y);
     } break;
     case 37: {   // lean point operations (group.h) against the general ones: double, then add b, from an affine start

@@ -204,7 +204,7 @@ static int emu_rp_shared_k(rp_rec& rec, std::vector<u32>& bases, std::vector<u32
             const rp_shared_mem M{rtab.data(), rraw.data(), park.data(), dig};
             did = rp_rings_shared<K>(rec, pub0.data() + 28 * r0, ring_out, ring_ok, proof, r0, 1, gtab_host(), g_htab.data(), g_xmul.data(), M);
         }
-        if (did) { fast += (int)((rec.rings - r0 < (u32)K) ? rec.rings - r0 : (u32)K); continue; }
+        if (did == RP_SHARED_SERVED) { fast += (int)((rec.rings - r0 < (u32)K) ? rec.rings - r0 : (u32)K); continue; }
         for (u32 i = r0; i < r0 + K; i++)
             rp_ring(rec, bases.data() + 28 * i, pub0.data() + 28 * i, ring_out + 33 * i, ring_ok + i, proof, i, i < rec.rings, gtab_host(), g_lm, nullptr,
                     dbases.data() + 28 * i, tcur.data() + 28 * i);

@@ -84,7 +84,7 @@ def test_cache_on_off_and_capacity(eng2, ref):
 
 
 def test_automatic_tables(eng2, ref):
-    """a generator that keeps coming gets a table by itself: host-buffer calls decide before the launch, `_dev` calls one call later"""
+    """a generator that keeps coming ON VALID PROOFS gets a table by itself: the final kernel reports, the next call counts and builds"""
     import torch
     from secp256k1_zkp_amd import Engine
     rng = np.random.default_rng(902)
@@ -93,9 +93,11 @@ def test_automatic_tables(eng2, ref):
     ga, gb = _gen(ref, rng), _gen(ref, rng)
     c, p, g, _ = ref.make_rangeproofs(6, rng, min_bits=20, gens64=np.tile(ga, (6, 1)))
     _same(eng2, ref, c, p, g)
-    assert not eng2.generator_cached(ga)                           # 6 < 10
+    assert not eng2.generator_cached(ga)
     _same(eng2, ref, c, p, g)
-    assert eng2.generator_cached(ga)                               # 12 seen: built before the second launch
+    assert not eng2.generator_cached(ga)                           # the second call has read the first one's report: 6 < 10
+    _same(eng2, ref, c, p, g)
+    assert eng2.generator_cached(ga)                               # 12 valid proofs seen: built at the start of the third call
     # `_dev`: the header kernel reports generators without a table; the host reads that report at the next call
     c, p, g, _ = ref.make_rangeproofs(12, rng, min_bits=20, gens64=np.tile(gb, (12, 1)))
     q = bytearray(p[3]); q[40] ^= 4; p[3] = bytes(q)
@@ -111,6 +113,40 @@ def test_automatic_tables(eng2, ref):
         eng2.sync()
         assert np.array_equal(d_res.cpu().numpy(), e_res) and np.array_equal(d_mx.cpu().numpy().view(np.uint64), e_mx)
         assert eng2.generator_cached(gb) == (k >= 1)               # reported by call 0, built at the start of call 1
+    eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 16)
+
+
+def test_junk_proofs_cannot_buy_a_table(eng2, ref):
+    """only proofs that VERIFIED count towards an automatic table, and an automatic table never takes the slot of secp256k1_generator_h or
+    of a generator the application cached itself: junk proofs that merely name a generator (not even a curve point) cost the engine
+    nothing, and valid proofs over ever new generators cannot push H out"""
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(903)
+    eng2.set_option(Engine.OPT_GEN_CACHE_SLOTS, 2)
+    eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 4)
+    H = np.frombuffer(GENERATOR_H, np.uint8)
+    eng2.cache_generator(GENERATOR_H)
+    c, p, g, _ = ref.make_rangeproofs(4, rng, min_bits=8)
+    _same(eng2, ref, c, p, g)
+    assert eng2.generator_cached(GENERATOR_H)
+    junk_gen = rng.integers(0, 256, 64, dtype=np.uint8)
+    jc = rng.integers(0, 256, (64, 33), dtype=np.uint8); jc[:, 0] = 8
+    jp = [bytes([0x40, 1]) + bytes(rng.integers(0, 256, 160, dtype=np.uint8)) for _ in range(64)]      # parses as a 1-ring proof, cannot verify
+    for _ in range(3):
+        res = _same(eng2, ref, jc, jp, np.tile(junk_gen, (64, 1)))
+        assert not res.any()
+    assert not eng2.generator_cached(junk_gen) and eng2.generator_cached(GENERATOR_H)
+    ga = _gen(ref, rng)
+    eng2.cache_generator(ga)                                        # slots: H or ga (explicit requests may evict anything)
+    eng2.cache_generator(GENERATOR_H)
+    assert eng2.generator_cached(ga) and eng2.generator_cached(GENERATOR_H)
+    for t in range(3):                                              # valid proofs over new generators: both slots are pinned, nothing is built
+        gx = _gen(ref, rng)
+        c, p, g, _ = ref.make_rangeproofs(6, rng, min_bits=8, gens64=np.tile(gx, (6, 1)))
+        for _ in range(2):
+            assert _same(eng2, ref, c, p, g).all()
+        assert not eng2.generator_cached(gx)
+    assert eng2.generator_cached(ga) and eng2.generator_cached(GENERATOR_H)
     eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 16)
 
 

@@ -1,0 +1,262 @@
+"""GPU parity on inputs only an adversary produces (tests/adversarial.py), through the real kernel chain
+k_rp_header -> k_rp_sum -> k_rp_rings_shared -> k_rp_rings -> k_rp_final, against the reference compiled here (oracle/_ref):
+
+* ring keys at infinity (the reference rejects them, src/modules/rangeproof/borromean_impl.h:78): forged proofs that satisfy every
+  other verification equation -- a verifier that missed the rejection would ACCEPT them; the shared-generator form of the rings
+  kernel has to recognise the ring as suspect (x-table of the ring-base multiples) and hand its wavefront to the general form;
+* a result at infinity (borromean_impl.h:84-86) and a VALID proof whose fixed-base part adds a point to itself: the exceptional
+  addition inside a step, the second hand-back;
+* all of it with the generator's table cached, without one, with per-proof generators, mixed into wavefronts with valid proofs
+  (the hand-back moves live neighbours: they must still verify), at 1, 63, 64, 65 items and at 2^14;
+* the same exceptional additions chosen digit by digit for the two double-multiplication forms on the device (prims 38 / 40);
+* surjection proofs with an input tag equal to the output tag (key at infinity) and with a result at infinity.
+`s2k_engine_rp_handback` shows that the hand-backs really happened."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.adversarial import Crafter, SurjectionCrafter
+from tests.refapi import GENERATOR_H, G_XY, N
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GH = np.frombuffer(GENERATOR_H, np.uint8)
+
+
+def _b(v):
+    return int(v % N).to_bytes(32, "big")
+
+
+def _fixture():
+    fx = json.load(open(os.path.join(HERE, "golden", "rangeproof_exceptional.json")))
+    return bytes.fromhex(fx["commit33"]), bytes.fromhex(fx["proof"])
+
+
+def _crafted(ref, rng, gen64=GENERATOR_H, with_fixture=True):
+    """list of (kind, commit33, proof): kind 'inf' = a key at infinity, 'x' = suspect x only, 'rinf' = result at infinity, 'dbl' = valid,
+    exceptional doubling"""
+    cr = Crafter(ref, gen64)
+    items = []
+    for rings, js in ((1, [1]), (1, [2]), (1, [3]), (2, [1, 3]), (2, [3, 3]), (3, [2, 1, 3]), (4, None), (8, None), (32, [1] * 32), (32, [2] * 32), (32, [3] * 32), (32, None)):
+        items.append(("inf",) + cr.forge_infinity_keys(rng, rings, js))
+    for rings in (1, 3, 32):
+        items.append(("x",) + cr.forge_infinity_keys(rng, rings, neg=True))
+    for rings, ring in ((2, 0), (3, 1), (32, 17)):
+        items.append(("rinf",) + cr.forge_r_infinity(rng, rings, ring))
+    if with_fixture and bytes(gen64) == GENERATOR_H:
+        items.append(("dbl",) + _fixture())
+    return items
+
+
+def _single_ring_edits(ref, rng, proofs, commits):
+    """a VALID 64-bit proof with ONE ring commitment replaced by x(j * 4^i * H), both lifts: (the key of position j is then infinity for one
+    of the two signs; all other rings stay honest).  Header 2 bytes, 4 sign bytes, then 31 x coordinates."""
+    out = []
+    cr = Crafter(ref)
+    for t, (ring, j) in enumerate(((0, 1), (0, 3), (1, 2), (7, 1), (15, 3), (16, 2), (30, 1), (30, 3))):
+        pt = cr.lin(j * 4**ring, 0)
+        for sign in (0, 1):
+            q = bytearray(proofs[t % len(proofs)])
+            q[6 + 32 * ring:6 + 32 * ring + 32] = pt[:32]
+            q[2 + (ring >> 3)] = (q[2 + (ring >> 3)] & ~(1 << (ring & 7))) | (sign << (ring & 7))
+            out.append(("edit", commits[t % len(proofs)].tobytes(), bytes(q)))
+    return out
+
+
+def _run(engine, ref, C, P, G):
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(C, P, G, threads=8)
+    res, mn, mx = engine.rangeproof_verify_batch(C, P, G)
+    assert np.array_equal(res, e_res), np.nonzero(res != e_res)
+    assert np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
+    return e_res
+
+
+def _assemble(items, valid, n, rng, gen_rows=None):
+    """n items: the crafted ones at random positions, valid proofs everywhere else"""
+    vc, vp, vg = valid
+    C = np.zeros((n, 33), np.uint8); P = [None] * n; G = np.zeros((n, 64), np.uint8); kinds = [None] * n
+    pos = rng.permutation(n)[:min(len(items), n)]
+    for t, i in enumerate(pos):
+        kinds[i], c, p = items[t]
+        C[i] = np.frombuffer(c, np.uint8); P[i] = p; G[i] = GH if gen_rows is None else gen_rows[t]
+    k = 0
+    for i in range(n):
+        if P[i] is None:
+            C[i] = vc[k % len(vp)]; P[i] = vp[k % len(vp)]; G[i] = vg[k % len(vp)]; k += 1
+    return C, P, G, kinds
+
+
+@pytest.fixture(scope="module")
+def valid_h(ref):
+    rng = np.random.default_rng(700)
+    c1, p1, g1, _ = ref.make_rangeproofs(24, rng, min_bits=64)
+    c2, p2, g2, _ = ref.make_rangeproofs(24, rng, min_bits=7)
+    c3, p3, g3, _ = ref.make_rangeproofs(16, rng, min_bits=52)
+    return np.concatenate([c1, c2, c3]), p1 + p2 + p3, np.concatenate([g1, g2, g3])
+
+
+def test_crafted_proofs_with_cached_generator(engine, ref, valid_h):
+    """H has its table (shared-generator form): suspect rings and exceptional additions must be handed back -- with their wavefronts"""
+    rng = np.random.default_rng(701)
+    engine.cache_generator(GENERATOR_H)
+    items = _crafted(ref, rng) + _single_ring_edits(ref, rng, valid_h[1][:8], valid_h[0][:8])
+    # every crafted proof alone (n = 1), then mixes around the wavefront size
+    for kind, c, p in items:
+        e_res = _run(engine, ref, np.frombuffer(c, np.uint8).reshape(1, 33), [p], GH.reshape(1, 64))
+        assert e_res[0] == (1 if kind == "dbl" else 0), kind
+        hb = engine.rp_handback()
+        if kind in ("inf", "x"):
+            assert hb[2] > 0 and hb[0] > 0, (kind, hb)               # suspect rings went back
+        if kind in ("rinf", "dbl"):
+            assert hb[3] > 0, (kind, hb)                             # an exceptional addition inside a step
+        if kind == "edit":
+            assert hb[2] + hb[3] > 0, (kind, hb)
+    suspects = exceptional = 0
+    for n in (63, 64, 65, 257):
+        for rep in range(2):
+            C, P, G, kinds = _assemble([items[i] for i in rng.permutation(len(items))[:max(3, n // 8)]], valid_h, n, rng)
+            e_res = _run(engine, ref, C, P, G)
+            hb = engine.rp_handback()
+            assert all(e_res[i] == 1 for i in range(n) if kinds[i] in (None, "dbl"))          # live neighbours survive the hand-back
+            assert not any(e_res[i] for i in range(n) if kinds[i] not in (None, "dbl"))
+            suspects += hb[2]; exceptional += hb[3]
+    assert suspects > 0 and exceptional > 0
+
+
+def test_crafted_proofs_general_form(ref, valid_h):
+    """no table at all (general form only), and per-proof generators: a key at infinity is met by rp_ring itself"""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(702)
+    eng = Engine(0)
+    try:
+        eng.set_option(Engine.OPT_GEN_CACHE_SLOTS, 0)
+        items = _crafted(ref, rng) + _single_ring_edits(ref, rng, valid_h[1][:8], valid_h[0][:8])
+        C, P, G, kinds = _assemble(items, valid_h, 130, rng)
+        e_res = _run(eng, ref, C, P, G)
+        assert eng.rp_handback()[0] == 0 and e_res.sum() == sum(k in (None, "dbl") for k in kinds)
+        # every crafted proof over a generator of its own
+        its, rows = [], []
+        for t in range(6):
+            g = ref.rand_point(rng)
+            for it in _crafted(ref, np.random.default_rng(800 + t), g, with_fixture=False)[t::6]:
+                its.append(it); rows.append(np.frombuffer(g, np.uint8))
+        C, P, G, kinds = _assemble(its, valid_h, 96, rng, gen_rows=rows)
+        e_res = _run(eng, ref, C, P, G)
+        assert not any(e_res[i] for i in range(96) if kinds[i] is not None)
+        # and with that generator's table built: shared form + hand-back for another generator than H
+        eng.set_option(Engine.OPT_GEN_CACHE_SLOTS, 2)
+        g = ref.rand_point(rng); ga = np.frombuffer(g, np.uint8)
+        eng.cache_generator(g)
+        its = _crafted(ref, rng, g, with_fixture=False)
+        gv = np.tile(ga, (12, 1))
+        vc, vp, vg, _ = ref.make_rangeproofs(12, rng, min_bits=20, gens64=gv)
+        C, P, G, kinds = _assemble(its, (vc, vp, vg), 64, rng, gen_rows=[ga] * len(its))
+        e_res = _run(eng, ref, C, P, G)
+        hb = eng.rp_handback()
+        assert hb[0] > 0 and hb[2] > 0 and e_res.sum() == sum(k is None for k in kinds)
+    finally:
+        eng.close()
+
+
+def test_full_size_with_crafted_proofs(engine, ref):
+    """BASELINE config 3's batch (2^14 64-bit proofs, H cached) with crafted proofs spread through it"""
+    rng = np.random.default_rng(703)
+    n = 1 << 14
+    commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, threads=16)
+    items = []
+    for t in range(4):
+        items += _crafted(ref, np.random.default_rng(900 + t))
+    items += _single_ring_edits(ref, rng, proofs[:8], commits[:8])
+    pos = rng.permutation(n)[:len(items)]
+    for (kind, c, p), i in zip(items, pos):
+        commits[i] = np.frombuffer(c, np.uint8); proofs[i] = p
+    engine.cache_generator(GENERATOR_H)
+    e_res = _run(engine, ref, commits, proofs, gens)
+    hb = engine.rp_handback()
+    n_valid = n - len(items) + sum(k == "dbl" for k, _, _ in items)
+    assert e_res.sum() == n_valid and hb[2] > 0 and hb[3] > 0
+    assert hb[1] <= 192 * len(items)                                  # only the affected wavefronts left the shared form (a proof's rings span at most two)
+
+
+def test_exceptional_additions_in_the_double_multiplication_forms(engine, ref):
+    """prims 38 (ecmult_lane_split + the caller's ecmult_lane) and 40 (ecmult_ring_step + the caller's fallback): digits chosen so that the
+    accumulator meets its own operand -- P + P and P - P -- at a generator window (first, a middle one, the last) and, for the ring
+    form, at a window of the second fixed-base table; one such lane per wavefront, the others random.  Results equal secp256k1_ecmult."""
+    import torch
+    lib = ctypes.CDLL(os.path.join(HERE, "gpu_prims", "libs2k_gpuprims.so"))
+    gsz = ctypes.c_size_t(0)
+    gtab = engine._lib.s2k_engine_gtable(engine._h, ctypes.byref(gsz))
+
+    def run(op, n, a, b, c, scratch_words):
+        dev = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x, np.uint8).reshape(-1)).cuda()
+        ta, tb, tc = dev(a), dev(b), dev(c)
+        out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda"); flag = torch.zeros(n + scratch_words, dtype=torch.int32, device="cuda")
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        torch.cuda.synchronize()
+        assert lib.s2k_test_prim(op, ptr(out), ptr(flag), ptr(ta), ptr(tb), ptr(tc), ctypes.c_void_p(gtab), n) == 1
+        return out.cpu().numpy().reshape(n, 64), flag.cpu().numpy()[:n]
+
+    rng = np.random.default_rng(704)
+    Gpt = np.frombuffer(G_XY, np.uint8)
+    ri = lambda: int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "big") % (N - 1) + 1
+    cases = [(phase, g, sign) for phase in (0, 1) for g in (0, 1, 5, 10) for sign in (1, -1)]
+    waves = len(cases) + 2                                            # + two wavefronts without a crafted lane
+    n = 64 * waves
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8); base[:, 0] &= 0x7F
+    e = rng.integers(0, 256, (n, 32), dtype=np.uint8); e[:, 0] &= 0x7F
+    s = rng.integers(0, 256, (n, 32), dtype=np.uint8); s[:, 0] &= 0x3F
+    f = rng.integers(0, 256, (n, 32), dtype=np.uint8); f[:, 0] &= 0x3F
+    for w, (phase, g, sign) in enumerate(cases):
+        i = 64 * w + int(rng.integers(0, 64))
+        ei, si, fi = (int.from_bytes(x[i].tobytes(), "big") for x in (e, s, f))
+        src = fi if phase else si                                     # the scalar whose window g is met
+        wg = (src >> (24 * g)) & 0xFFFFFF
+        assert wg != 0
+        lo = (src & ((1 << (24 * g)) - 1)) + (si if phase else 0)      # what the accumulator has received from the tables before that window
+        k = ((sign * (wg << (24 * g)) - lo) * pow(ei, -1, N)) % N      # e*k*G + lo*G == +-(window entry)
+        base[i] = np.frombuffer(_b(k), np.uint8)
+    A, ainf = ref.ecmult_batch(np.tile(Gpt, (n, 1)), base)
+    assert not ainf.any()
+    z = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    # ring form: e*A + s*G + f*G
+    sf = np.stack([np.frombuffer(_b(int.from_bytes(s[i].tobytes(), "big") + int.from_bytes(f[i].tobytes(), "big")), np.uint8) for i in range(n)])
+    want, winf = ref.ecmult_batch(A, e, ng=sf)
+    got, flag = run(40, n, A, np.concatenate([e, s, f], axis=1), None, n * 528 + waves * (2 * 16 * 27 * 64) + n * 544 + 64)
+    done = (flag >> 1).reshape(waves, 64)
+    assert not done[:len(cases)].any() and done[len(cases):].all()   # every crafted wavefront handed back, the others completed
+    assert ((flag & 1) == winf).all() and (got[winf == 0] == want[winf == 0]).all()
+    # two-piece form: e*A + (s + f)*G with the same points: the phase-1 cases collide at a window of (s + f) only by accident, so craft anew
+    for w, (phase, g, sign) in enumerate(cases):
+        i = 64 * w + int(rng.integers(0, 64))
+        ei = int.from_bytes(e[i].tobytes(), "big"); si = int.from_bytes(sf[i].tobytes(), "big")
+        wg = (si >> (24 * g)) & 0xFFFFFF
+        assert wg != 0
+        k = ((sign * (wg << (24 * g)) - (si & ((1 << (24 * g)) - 1))) * pow(ei, -1, N)) % N
+        base[i] = np.frombuffer(_b(k), np.uint8)
+    A, ainf = ref.ecmult_batch(np.tile(Gpt, (n, 1)), base)
+    want, winf = ref.ecmult_batch(A, e, ng=sf)
+    got, flag = run(38, n, A, np.concatenate([e, sf], axis=1), z, n * 544 + 64)
+    took = (flag >> 1).reshape(waves, 64)
+    assert not took[:len(cases)].any() and took[len(cases):].all()
+    assert ((flag & 1) == winf).all() and (got[winf == 0] == want[winf == 0]).all()
+
+
+def test_surjection_keys_at_infinity(engine, ref):
+    rng = np.random.default_rng(705)
+    sc = SurjectionCrafter(ref)
+    proofs, tags, outs, want = [], [], [], []
+    shapes = ((3, [0, 2], 0), (3, [0, 2], 1), (8, [1, 4, 7], 1), (8, [1, 4, 7], 2), (1, [0], 0), (5, [0, 1, 2], 0))
+    for k in range(40):
+        if k % 2 == 0:
+            n_in = int(rng.integers(1, 9))
+            p, t, o = ref.make_surjection(rng, n_in, min(n_in, 1 + k % 3))
+        else:
+            a = shapes[(k // 2) % 6]
+            p, t, o = sc.forge_infinity(rng, *a) if k % 4 == 1 else sc.forge_r_infinity(rng, a[0], a[1])
+        proofs.append(p); tags.append(t); outs.append(o); want.append(ref.surjection_verify(p, t, o))
+    res = engine.surjectionproof_verify_batch(proofs, tags, np.stack(outs))
+    assert list(res) == want and sum(want) == 20 and not any(want[1::2])
