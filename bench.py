@@ -26,6 +26,8 @@ BATCH = 1 << 14                    # proofs per GPU per step
 PROOF_BYTES_ALGO = 5223            # 5126 B proof + 33 B commitment + 64 B generator
 MAC64_PER_PROOF = 6.6e6            # reference schedule, 64x64->128 MACs per 64-bit proof
 MAC64_PER_MSM_TERM = 6.3e3         # reference schedule at n >= 16384 (20 bucket additions per term)
+MAC64_PER_MSM_TERM_SMALL = 10.6e3  # reference schedule at n = 1 024 (32 bucket additions per term)
+MAC64_PER_SCHNORR = 45e3 + 267 * 21 + 267 * 21      # ~45 k MAC64 for the double multiplication + one inversion + the key's square root (~267 field operations of ~21 MAC64 each)
 MSM_BYTES_PER_TERM = 96            # 32 B scalar + 64 B affine point
 # integer-MAC peak of the chip: v_mad_u64_u32 lane-ops/s.  Measured with >= 10 ms launches at 8 waves/SIMD
 # (tools/ubench/issue_model.hip -> profiles/r02a_issue_model.txt: 3.73e13 = 4.22 cycles per wave64 instruction at the nominal
@@ -227,6 +229,93 @@ def measure_dropin(eng, commits, proofs, gens, steps):
     return out
 
 
+def measure_secondary(eng, ref, dev, steps, with_cpu=True):
+    """BASELINE configs 2 and 4 and the GPU side of config 1, each with an in-run check of the verdicts / the result against the reference
+    and a VALU roofline from SURVEY 8d's per-unit work (Schnorr: ~45 k MAC64 + one inversion and one square root per signature; norm
+    argument: a (g_len + h_len) + 13-point multi-scalar multiplication per proof at ~10.6 k MAC64 per term; MSM of 1 024 terms: 10.6 k)."""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    from tests.refapi import G_XY
+    out = {}
+    rng = np.random.default_rng(777)
+
+    def loop(fn):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def roof(mac64_per_unit, units, sec, what):
+        rate = 4 * mac64_per_unit * units / sec
+        return {"bound": "valu", "achieved": rate / 1e12, "peak": MAD32_PEAK / 1e12, "unit": "T lane-MAC/s (v_mad_u64_u32)", "frac": rate / MAD32_PEAK,
+                "frac_of_architectural_peak": rate / MAD32_PEAK_ARCH, "note": what + " x 4 v_mad_u64_u32 x units / wall time of the whole call (K calls queued, waited for once)"}
+
+    # ---- config 2: 2^16 BIP-340 signatures, some of them broken
+    n = 1 << 16
+    sigs, msgs, pks = ref.make_schnorr(n, rng, threads=usable_cores())
+    sigs[::251, 40] ^= 1; pks[100::509, 7] ^= 4
+    chk = np.arange(0, n, 61)                                                   # a sample of the batch through the reference (all of it would take ~3 s more)
+    want = ref.schnorr_verify_many(sigs[chk], msgs[chk], pks[chk])
+    d = [torch.tensor(x).to(dev) for x in (sigs, msgs, pks)]; res = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    sec = loop(lambda: eng.schnorrsig_verify_batch_dev(res, d[0], d[1], d[2]))
+    got = res.cpu().numpy()
+    assert np.array_equal(got[chk], want), "BIP-340 verdicts differ from the reference"
+    bad = np.zeros(n, bool); bad[::251] = True; bad[100::509] = True
+    assert not got[bad].any() and got[~bad].all()
+    out["bip340_2p16"] = {"metric": "BIP-340 signature verifies/sec (BASELINE config 2)", "value": n / sec, "unit": "verifies/s", "ms": sec * 1e3, "batch": n,
+                          "verified": True, "result_check": "every verdict as constructed (%d broken signatures / keys rejected), %d items compared with the reference's secp256k1_schnorrsig_verify" % (int(bad.sum()), chk.size),
+                          "roofline": roof(MAC64_PER_SCHNORR, n, sec, "algorithmic %.1fe3 MAC64 per signature (SURVEY 8d: ~45 k for the double multiplication + one inversion + the key's square root)" % (MAC64_PER_SCHNORR / 1e3)),
+                          "hbm_roofline": {"achieved": 160.0 * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * n / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_signature": 160}}
+    del d, res
+    # ---- config 4: 2^12 BP++ norm arguments (g_len 64, h_len 8): 64 distinct proofs by the reference's prover, tiled; three of the 64 broken
+    nb = 1 << 12
+    base = ref.make_bppp(64, rng, 64, 8)
+    pr = base[0].copy(); pr[5, 10] ^= 1; pr[21, 70] ^= 0x80; cm = base[6].copy(); cm[40, 12] ^= 2
+    want = ref.bppp_verify_many(pr, base[1], base[2], base[3], base[4], base[5], cm)
+    assert want.sum() == 61
+    reps = nb // 64
+    tile = lambda a: torch.tensor(np.ascontiguousarray(np.concatenate([a] * reps))).to(dev)
+    d_pr, d_tr, d_rho, d_cv, d_cm = tile(pr), tile(base[1]), tile(base[2]), tile(base[5]), tile(cm)
+    gens = np.ascontiguousarray(base[3]); d_gens = torch.tensor(gens).to(dev)
+    res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    call = lambda: eng.bppp_norm_product_verify_batch_dev(res, d_pr, pr.shape[1], d_tr, d_rho, d_gens, gens, base[4], d_cv, base[5].shape[1], d_cm, nb)
+    sec = loop(call)
+    got = res.cpu().numpy()
+    assert np.array_equal(got, np.tile(want, reps)), "BP++ verdicts differ from the reference"
+    terms = 64 + 8 + 13
+    out["bppp_2p12"] = {"metric": "BP++ norm-argument verifies/sec (BASELINE config 4: the norm argument is the measurable unit, SURVEY 8d)", "value": nb / sec, "unit": "verifies/s",
+                        "ms": sec * 1e3, "batch": nb, "g_len": 64, "h_len": 8, "verified": True,
+                        "result_check": "== secp256k1_bppp_rangeproof_norm_product_verify of the reference on the 64 distinct proofs (61 valid, 3 broken), tiled %d times" % reps,
+                        "roofline": roof(MAC64_PER_MSM_TERM_SMALL * terms, nb, sec, "algorithmic %d terms x 10.6e3 MAC64 per term per proof (SURVEY 8d, the 1 024-term schedule)" % terms)}
+    if with_cpu:
+        k = 256
+        idx = np.arange(k) % 64
+        t0 = time.time(); r = ref.bppp_verify_many(pr[idx], base[1][idx], base[2][idx], base[3], base[4], base[5][idx], cm[idx]); t = time.time() - t0
+        assert np.array_equal(r, want[idx])
+        out["bppp_2p12"]["cpu_baseline"] = {"value": k / t, "unit": "verifies/s", "cores": 1, "kind": "reference",
+                                            "sample": "secp256k1_bppp_rangeproof_norm_product_verify through oracle/ref_shim.c (src/bench_bppp.c is an empty stub), %d proofs on one thread in %.2f s" % (k, t)}
+    del d_pr, d_tr, d_rho, d_cv, d_cm, res
+    # ---- config 1 on the GPU: the 1 024 (scalar, point) pairs of bench_ecmult as ONE call (latency, not throughput: the CPU row is the baseline's)
+    nm = 1024
+    ks = rng.integers(0, 256, (nm, 32), dtype=np.uint8); scs = rng.integers(0, 256, (nm, 32), dtype=np.uint8); gsc = rng.integers(0, 256, 32, dtype=np.uint8)
+    pts, pinf = ref.ecmult_batch(np.tile(np.frombuffer(G_XY, np.uint8), (nm, 1)), ks)
+    d_s, d_p, d_g = torch.tensor(scs).to(dev), torch.tensor(pts).to(dev), torch.tensor(gsc).to(dev)
+    r_xy = torch.zeros(64, dtype=torch.uint8, device=dev); r_inf = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    sec = loop(lambda: eng.ecmult_multi_dev(r_xy, r_inf, d_s, d_p, g_sc=d_g))
+    exp_xy, exp_inf = ref.ecmult_multi(scs, pts, gsc.tobytes())
+    assert bytes(r_xy.cpu().numpy()) == exp_xy.tobytes() and int(r_inf.item()) == exp_inf, "1 024-term MSM differs from the reference's ecmult_multi_var"
+    out["bench_ecmult_1023p_g"] = {"metric": "one 1 024-term multi-scalar multiplication incl. G (BASELINE config 1's input shape)", "value": nm / sec / 1e6, "unit": "Mpoint-scalar/s",
+                                   "ms": sec * 1e3, "terms": nm, "verified": True, "result_check": "== secp256k1_ecmult_multi_var of the reference on the same inputs",
+                                   "roofline": roof(MAC64_PER_MSM_TERM_SMALL, nm, sec, "algorithmic 10.6e3 MAC64 per term (SURVEY 8d, n = 1 024)"),
+                                   "note": "a single small MSM is latency bound on a GPU (DESIGN 4.3); config 1 is the CPU reference's row, kept beside it"}
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -297,6 +386,9 @@ def cpu_baseline_ref_benches():
     big = ec.get("ecmult_multi_32767p_g")
     if big:
         out["bench_ecmult_pippenger_32767p_g"] = {"us_per_point_min_avg_max": big, "mpoint_scalar_per_s": 1.0 / big[1]}
+    k1 = ec.get("ecmult_multi_1023p_g")                                        # BASELINE config 1: 1024 (scalar, point) pairs, Pippenger, CPU only
+    if k1:
+        out["bench_ecmult_pippenger_1023p_g"] = {"us_per_point_min_avg_max": k1, "mpoint_scalar_per_s": 1.0 / k1[1]}
     return out
 
 
@@ -328,6 +420,7 @@ def main():
     ap.add_argument("--no-msm-big", action="store_true", help="skip the 2^24-term strong-scaling MSM entry")
     ap.add_argument("--no-distinct", action="store_true", help="skip the second timed loop (every proof its own generator)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 1, 2 and 4 (bench_ecmult 1024 pairs, BIP-340 2^16, BP++ norm argument 2^12)")
     args = ap.parse_args()
 
     import torch
@@ -562,6 +655,13 @@ def main():
             msm["strong_2p24"] = big
             del scs, pts
 
+    # BASELINE configs 2 and 4 (and config 1's GPU side): same conventions as the headline -- inputs made by the reference, resident in HBM,
+    # K stream-ordered `_dev` calls queued back to back and waited for once, every verdict checked in-run against the reference's.
+    secondary = None
+    if rank == 0 and not args.no_secondary and ref is not None:
+        torch.cuda.synchronize(); time.sleep(1.0)
+        secondary = measure_secondary(eng, ref, dev, max(3, args.steps), with_cpu=not args.no_cpu_baseline)
+
     if rank == 0:
         value = world * n * args.steps / dt
         kms = float(np.mean(kern_ms))
@@ -633,6 +733,8 @@ def main():
             out["msm"] = msm
         if dropin:
             out["dropin"] = dropin
+        if secondary:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline:
             # (1) the reference's own bench programs (src/bench_rangeproof.c with min_bits = 64, src/bench_ecmult.c; timer of src/bench.h),
             #     one process and one taskset-pinned process per usable core; (2) the same functions through the oracle/_ref shim with
@@ -652,6 +754,15 @@ def main():
                                        "bench_programs": rb, "shim_cross_check": shim}
                 if msm and "bench_ecmult_pippenger_32767p_g" in rb:
                     msm.setdefault("cpu_baseline", {})["bench_ecmult"] = rb["bench_ecmult_pippenger_32767p_g"]
+                if secondary:
+                    if "bench_schnorrsig_verify" in rb:
+                        sv = rb["bench_schnorrsig_verify"]
+                        secondary["bip340_2p16"]["cpu_baseline"] = {"value": sv["verifies_per_s_one_process"], "unit": "verifies/s", "cores": 1, "kind": "reference",
+                                                                    "sample": "the reference's src/bench.c schnorrsig_verify, SECP256K1_BENCH_ITERS=4000 x 10 repetitions, avg column: %.1f us per verification" % sv["us_per_verify_min_avg_max"][1]}
+                    if "bench_ecmult_pippenger_1023p_g" in rb:
+                        k1 = rb["bench_ecmult_pippenger_1023p_g"]
+                        secondary["bench_ecmult_1023p_g"]["cpu_baseline"] = {"value": k1["mpoint_scalar_per_s"], "unit": "Mpoint-scalar/s", "cores": 1, "kind": "reference",
+                                                                             "sample": "the reference's bench_ecmult pippenger_wnaf, row ecmult_multi_1023p_g (src/bench_ecmult.c:278-307): %.2f us per point" % k1["us_per_point_min_avg_max"][1]}
             elif shim:
                 if ref is None:
                     shim["kind"] = "port"

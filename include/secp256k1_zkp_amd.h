@@ -42,6 +42,7 @@ S2K_API const char* s2k_last_error(void);
 #define S2K_STATUS_OK 0
 #define S2K_STATUS_ENGINE_FAILURE 1   /* no device, HIP error, out of memory */
 #define S2K_STATUS_ILLEGAL_ARGUMENT 2 /* what the reference's ARG_CHECK would have rejected */
+#define S2K_STATUS_BUSY 3             /* both staging sets of the host-buffer rangeproof calls are held by asynchronous tickets */
 S2K_API int s2k_last_status(void);
 S2K_API void s2k_clear_status(void);
 /* Engine options.
@@ -171,13 +172,14 @@ S2K_API int secp256k1_rangeproof_verify_batch_ptrs(s2k_engine* e, int32_t* resul
 /* Asynchronous pair over the two host-buffer forms, for callers with a stream of batches (the blocks of a chain sync, the transactions of a
  * mempool): `_submit` gathers the inputs, queues the copies and the kernels and returns a ticket; `_wait(ticket)` blocks until that batch is
  * done and only then fills results / min_value / max_value (which must stay valid until then; `results` holds zeros in between).  The
- * INPUT arrays may be reused as soon as `_submit` returns.  At most TWO submissions may be in flight -- a third `_submit` fails (argument
- * error) until the older ticket has been waited for -- and tickets may be waited for in any order, from any thread.  With
+ * INPUT arrays may be reused as soon as `_submit` returns.  At most TWO submissions may be in flight -- a third `_submit` fails
+ * (S2K_STATUS_BUSY) until the older ticket has been waited for -- and tickets may be waited for in any order, from any thread.  With
  *     submit(k+1); wait(k); submit(k+2); wait(k+1); ...
  * the gathering and the PCIe copies of batch k+1 run underneath the kernels of batch k and the GPU never idles: the throughput of the
  * host-buffer path becomes that of the device-resident one (bench.py: dropin.two_in_flight).  The synchronous forms above are
  * submit + wait on one of the same two staging sets: concurrent synchronous callers (verifier threads sharing an engine) queue for a
- * set -- two of them overlap, none is turned away -- unless both sets are held by tickets nobody waits for (error after 60 s).
+ * set -- two of them overlap, none is turned away -- unless both sets are held by asynchronous tickets, which only the application can
+ * free: the synchronous call then returns 0 at once with S2K_STATUS_BUSY.
  * A ticket is never 0. */
 S2K_API int secp256k1_rangeproof_verify_batch_submit(s2k_engine* e, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                                      const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
@@ -289,6 +291,39 @@ S2K_API int secp256k1_bppp_commit_batch(s2k_engine* e, unsigned char* commits33,
 S2K_API int secp256k1_bppp_commit_batch_dev(s2k_engine* e, void* stream, unsigned char* commits33, int32_t* results, const unsigned char* gens33_dev,
                                             const unsigned char* gens33_host, size_t n_gens, size_t g_len, const unsigned char* n_vec,
                                             const unsigned char* l_vec, const unsigned char* c_vec, size_t h_len, const unsigned char* mu, size_t n);
+
+/* ---- engine groups: the GPUs of one node behind one handle ------------------------------------------------------------------------
+ * A group holds one engine per entry of `devices` (HIP device ordinals; an ordinal may appear more than once -- engines on one device
+ * share that device's tables) and one host thread per engine.  Independent items are replica work ("batches of independent
+ * proofs: replicas only"): `_group` batch calls cut the batch into contiguous index ranges, one per engine, and run them concurrently
+ * through the engines' host-buffer entry points; arguments, per-item results and error conventions are those of the single-engine
+ * calls (a failing engine fails the call and zeroes `results`).  One LARGE multi-scalar multiplication is sharded by terms
+ * (BASELINE config 5): every engine sums its slice to a 112-byte Jacobian partial, the partials are copied to the first engine's
+ * device (hipMemcpyPeerAsync; devices that can reach each other over xGMI are made peers) and summed there.  s2k_ecmult_multi_group
+ * takes host arrays (each engine uploads its slice); s2k_ecmult_multi_group_dev takes, per engine i, device pointers to a slice that
+ * is already resident on engine i's GPU (n_per_engine[i] terms; pt_inf_dev may be NULL; g_sc_dev0: 32 bytes on engine 0's GPU or
+ * NULL) -- the result comes back to the host in both.  One group call runs at a time; the engines of a group may also be used directly
+ * (s2k_group_engine), e.g. to cache a generator on every device.
+ * A group handle fits the reference-side hook's `engine` slot (integration/secp256k1_amd_hook.h): the `_group` functions have the
+ * single-engine prototypes with the handle type changed. */
+typedef struct s2k_group s2k_group;
+S2K_API s2k_group* s2k_group_create(const int* devices, int n);
+S2K_API void s2k_group_destroy(s2k_group* g);
+S2K_API int s2k_group_size(const s2k_group* g);
+S2K_API s2k_engine* s2k_group_engine(s2k_group* g, int i);
+S2K_API int secp256k1_rangeproof_verify_batch_group(s2k_group* g, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                    const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,
+                                                    const unsigned char* extra, const uint64_t* extra_off, const unsigned char* gens64, size_t n);
+S2K_API int secp256k1_rangeproof_verify_batch_ptrs_group(s2k_group* g, int32_t* results, uint64_t* min_value, uint64_t* max_value,
+                                                         const void* const* commit_objs, const unsigned char* const* proofs, const size_t* plens,
+                                                         const unsigned char* const* extra, const size_t* elens, const void* const* gen_objs, size_t n);
+S2K_API int secp256k1_schnorrsig_verify_batch_group(s2k_group* g, int32_t* results, const unsigned char* sigs, const unsigned char* msgs,
+                                                    size_t msglen, const unsigned char* pubkeys, int pk_format, size_t n);
+S2K_API int s2k_ecmult_multi_group(s2k_group* g, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc, const unsigned char* sc,
+                                   const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
+S2K_API int s2k_ecmult_multi_group_dev(s2k_group* g, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc_dev0,
+                                       const unsigned char* const* sc_dev, const unsigned char* const* pt_xy_dev,
+                                       const unsigned char* const* pt_inf_dev, const size_t* n_per_engine);
 
 #ifdef __cplusplus
 }

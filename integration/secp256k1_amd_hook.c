@@ -18,7 +18,16 @@
  * leave a verification's duration between two installs. */
 static secp256k1_amd_backend secp256k1_amd_slots[2];        /* all-NULL: CPU library */
 static const secp256k1_amd_backend *secp256k1_amd_cur = &secp256k1_amd_slots[0];
+/* Statistics, updated by concurrent verifier threads: atomic increments (GCC/Clang builtins, which the reference's supported compilers
+ * provide -- cf. its own use of __builtin_* in src/util.h; a compiler without them gets plain increments: the counters are diagnostics). */
 static size_t secp256k1_amd_served = 0, secp256k1_amd_fell_back = 0;
+#if defined(__GNUC__) || defined(__clang__)
+#define SECP256K1_AMD_COUNT(x) ((void)__atomic_fetch_add(&(x), 1, __ATOMIC_RELAXED))
+#define SECP256K1_AMD_READ(x) __atomic_load_n(&(x), __ATOMIC_RELAXED)
+#else
+#define SECP256K1_AMD_COUNT(x) ((void)(x)++)
+#define SECP256K1_AMD_READ(x) (x)
+#endif
 /* MSMs shorter than this stay on the CPU: one engine round trip costs ~0.65 ms whatever the size (profiles/r03*_msm_sweep.txt), the
  * reference's Strauss / Pippenger ~3-6 us per term on one core, so the crossover sits near 200 terms */
 #define SECP256K1_AMD_MSM_MIN_TERMS_DEFAULT 256
@@ -48,8 +57,8 @@ void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend) {
     SECP256K1_AMD_STORE_BE(next);
 }
 void secp256k1_amd_stats(size_t *served, size_t *fell_back) {
-    if (served != NULL) *served = secp256k1_amd_served;
-    if (fell_back != NULL) *fell_back = secp256k1_amd_fell_back;
+    if (served != NULL) *served = SECP256K1_AMD_READ(secp256k1_amd_served);
+    if (fell_back != NULL) *fell_back = SECP256K1_AMD_READ(secp256k1_amd_fell_back);
 }
 void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n; }
 
@@ -91,9 +100,9 @@ int secp256k1_amd_rangeproof_verify_batch_submit(const secp256k1_context *ctx, u
     if (n == 0) return 1;
     if (be->rangeproof_verify_batch_ptrs_submit != NULL && be->rangeproof_verify_batch_wait != NULL) {
         if (be->rangeproof_verify_batch_ptrs_submit(be->engine, ticket, (int32_t*)results, min_value, max_value, (const void *const *)commits, proofs, plens,
-                                                    extra_commits, extra_commit_lens, (const void *const *)gens, n)) { secp256k1_amd_served++; return 1; }
+                                                    extra_commits, extra_commit_lens, (const void *const *)gens, n)) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
         *ticket = 0;
-        secp256k1_amd_fell_back++;
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) {
         results[i] = secp256k1_rangeproof_verify(ctx, &min_value[i], &max_value[i], commits[i], proofs[i], plens[i],
@@ -140,8 +149,8 @@ int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *res
             if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
         }
         free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     } else if (be->rangeproof_verify_batch != NULL) {
         size_t pbytes = 0, ebytes = 0, po = 0, eo = 0;
         unsigned char *c33, *pbuf, *ebuf, *g64;
@@ -174,8 +183,8 @@ int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *res
             if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
         }
         free(c33); free(g64); free(pbuf); free(ebuf); free(poff); free(eoff); free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;              /* engine-level failure: the whole batch takes the library's own path */
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);              /* engine-level failure: the whole batch takes the library's own path */
     }
     for (i = 0; i < n; i++) {
         results[i] = secp256k1_rangeproof_verify(ctx, &min_value[i], &max_value[i], commits[i], proofs[i], plens[i],
@@ -271,8 +280,8 @@ int secp256k1_amd_rangeproof_rewind_batch(const secp256k1_context *ctx, int *res
         }
         if (nn != NULL) memset(nn, 0, 32 * n);                      /* nonces are secrets */
         free(c33); free(g64); free(nn); free(pbuf); free(ebuf); free(poff); free(eoff); free(res32); free(msg); free(olen);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) {
         size_t ol = message_out != NULL ? outlen[i] : 0;
@@ -319,7 +328,7 @@ static int secp256k1_ecmult_multi_var_amd(const secp256k1_callback *error_callba
         }
         free(sc); free(pt); free(inf);
         if (ok) {
-            secp256k1_amd_served++;
+            SECP256K1_AMD_COUNT(secp256k1_amd_served);
             if (rinf) secp256k1_gej_set_infinity(r);
             else {
                 secp256k1_ge a; secp256k1_fe x, y;
@@ -329,7 +338,7 @@ static int secp256k1_ecmult_multi_var_amd(const secp256k1_callback *error_callba
             }
             return 1;
         }
-        secp256k1_amd_fell_back++;
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     return secp256k1_ecmult_multi_var(error_callback, scratch, r, inp_g_sc, cb, cbdata, n);
 }
@@ -379,8 +388,8 @@ static int secp256k1_ecmult_batch_amd(const secp256k1_callback *error_callback, 
             }
         }
         free(axy); free(ainf); free(sna); free(sng); free(rxy); free(rinf);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) secp256k1_ecmult(&r[i], &a[i], &na[i], ng != NULL ? &ng[i] : NULL);
     return 1;
@@ -423,8 +432,8 @@ static int secp256k1_amd_bppp_norm_product_verify_batch(const secp256k1_context 
             if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
         }
         free(pr); free(tr); free(rh); free(gs); free(cv); free(cm); free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) {
         /* the reference's verify modifies its generator set, c_vec and transcript: give it copies */
@@ -477,8 +486,8 @@ int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *res
             if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
         }
         free(s); free(m); free(pk); free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) results[i] = secp256k1_schnorrsig_verify(ctx, sigs64[i], msglen != 0 ? msgs[i] : NULL, msglen, pubkeys[i]);
     return 1;
@@ -502,10 +511,10 @@ int secp256k1_amd_schnorrsig_aggverify(const secp256k1_context *ctx, const secp2
     if (be->schnorrsig_aggverify != NULL && n != 0) {
         int32_t verdict = 0;
         if (be->schnorrsig_aggverify(be->engine, &verdict, (const unsigned char*)pubkeys, 1, msgs32, n, aggsig, aggsig_len)) {
-            secp256k1_amd_served++;
+            SECP256K1_AMD_COUNT(secp256k1_amd_served);
             return verdict != 0;
         }
-        secp256k1_amd_fell_back++;
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     return secp256k1_schnorrsig_aggverify(ctx, pubkeys, msgs32, n, aggsig, aggsig_len);
 }
@@ -558,8 +567,8 @@ int secp256k1_amd_surjectionproof_verify_batch(const secp256k1_context *ctx, int
             if (ok) for (i = 0; i < n; i++) results[i] = res32[i] != 0;
         }
         free(pbuf); free(tags); free(outs); free(poff); free(toff); free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (i = 0; i < n; i++) results[i] = secp256k1_surjectionproof_verify(ctx, proofs[i], input_tags[i], n_input_tags[i], output_tags[i]);
     return 1;
@@ -607,8 +616,8 @@ int secp256k1_amd_pedersen_verify_tally_batch(const secp256k1_context *ctx, int 
             if (ok) for (t = 0; t < n_tallies; t++) results[t] = res32[t] != 0;
         }
         free(c33); free(off); free(npos); free(res32);
-        if (ok) { secp256k1_amd_served++; return 1; }
-        secp256k1_amd_fell_back++;
+        if (ok) { SECP256K1_AMD_COUNT(secp256k1_amd_served); return 1; }
+        SECP256K1_AMD_COUNT(secp256k1_amd_fell_back);
     }
     for (t = 0; t < n_tallies; t++) results[t] = secp256k1_pedersen_verify_tally(ctx, pos[t], pcnt[t], neg[t], ncnt[t]);
     return 1;

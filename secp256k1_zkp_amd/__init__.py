@@ -3,4 +3,4 @@
 Python here is plumbing only (ctypes over the C ABI in ``include/secp256k1_zkp_amd.h``, torch for HBM buffers and
 ``torch.distributed``); all arithmetic runs in the hand-written HIP kernels under ``csrc/``.
 """
-from .api import Engine, S2KError  # noqa: F401
+from .api import Engine, Group, S2KError  # noqa: F401

@@ -60,6 +60,15 @@ SIGNATURES = {
     "secp256k1_bppp_commit_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _sz]),
     "secp256k1_bppp_commit_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _sz]),
     "secp256k1_bppp_norm_product_verify_batch": (_c.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),
+    "s2k_group_create": (_vp, [_vp, _c.c_int]),
+    "s2k_group_destroy": (None, [_vp]),
+    "s2k_group_size": (_c.c_int, [_vp]),
+    "s2k_group_engine": (_vp, [_vp, _c.c_int]),
+    "secp256k1_rangeproof_verify_batch_group": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_rangeproof_verify_batch_ptrs_group": (_c.c_int, [_vp] + [_vp] * 9 + [_sz]),
+    "secp256k1_schnorrsig_verify_batch_group": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),
+    "s2k_ecmult_multi_group": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
+    "s2k_ecmult_multi_group_dev": (_c.c_int, [_vp] + [_vp] * 7),
 }
 
 _lib = None

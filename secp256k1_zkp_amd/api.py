@@ -167,6 +167,14 @@ class Engine:
         self._check(self._lib.secp256k1_schnorrsig_verify_batch_dev(self._h, stream, _dp(results), _dp(sigs), _dp(msgs), msglen, _dp(pubkeys),
                                                                     pk_format, n), "secp256k1_schnorrsig_verify_batch_dev")
 
+    def bppp_norm_product_verify_batch_dev(self, results, proofs, proof_len, transcripts, rho, gens33_dev, gens33_host, g_len, c_vec, c_vec_len, commits33, n,
+                                           stream=None):
+        """every array in HBM (torch uint8 tensors); gens33_host: the same generator set as a numpy array (cache key of the fixed-base table)"""
+        gh = _u8(gens33_host)
+        self._check(self._lib.secp256k1_bppp_norm_product_verify_batch_dev(self._h, stream, _dp(results), _dp(proofs), proof_len, _dp(transcripts), _dp(rho), _dp(gens33_dev),
+                                                                            _p(gh), gh.size // 33, g_len, _dp(c_vec), c_vec_len, _dp(commits33), n),
+                    "secp256k1_bppp_norm_product_verify_batch_dev")
+
     # ---- secp256k1_bppp_commit (modules/bppp/bppp_norm_product_impl.h:105-151), batched on the fixed-base tables -----
     def bppp_commit_batch(self, gens33, g_len, n_vec, l_vec, c_vec, mu):
         """gens33 (n_gens,33); n_vec (n,g_len,32); l_vec, c_vec (n,h_len,32); mu (n,32) -> (commits (n,33), set_ok (n,))"""
@@ -324,3 +332,88 @@ class Engine:
                                                                         _p(gens33), n_gens, g_len, _p(c_vec), c_len, _p(_u8(commits33)), n),
                     "secp256k1_bppp_norm_product_verify_batch")
         return res
+
+
+class Group:
+    """The GPUs of one node behind one handle (s2k_group, include/secp256k1_zkp_amd.h): one engine and one host thread per entry of
+    `devices`; batches of independent items are cut into contiguous ranges, one large multi-scalar multiplication is sharded by terms."""
+
+    def __init__(self, devices):
+        self._lib = _native.load()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = self._lib.s2k_group_create(devs, len(devices))
+        if not self._h:
+            raise S2KError("s2k_group_create failed: " + _native.last_error())
+        self.devices = [int(d) for d in devices]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.s2k_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.s2k_group_size(self._h))
+
+    def _check(self, ok, what):
+        if not ok:
+            raise S2KError(f"{what} failed: {_native.last_error()}")
+
+    def engine(self, i):
+        """a non-owning Engine view of member i (options, generator cache)"""
+        h = self._lib.s2k_group_engine(self._h, int(i))
+        if not h:
+            raise IndexError(i)
+        e = Engine.__new__(Engine)
+        e._lib = self._lib; e._h = h; e.device = self.devices[i]
+        e.close = lambda: None                   # the group owns it
+        return e
+
+    def rangeproof_verify_batch(self, commits33, proofs, gens64, extra=None):
+        data, off = proofs if isinstance(proofs, tuple) else Engine.pack(list(proofs))
+        n = off.size - 1
+        commits33 = _u8(commits33); gens64 = _u8(gens64)
+        edata = eoff = None
+        if extra is not None:
+            edata, eoff = extra if isinstance(extra, tuple) else Engine.pack(list(extra))
+        Engine._check_rp_shapes("rangeproof_verify_batch_group", n, commits33, gens64, data, off, edata, eoff)
+        res = np.zeros(n, np.int32); mn = np.zeros(n, np.uint64); mx = np.zeros(n, np.uint64)
+        self._check(self._lib.secp256k1_rangeproof_verify_batch_group(self._h, _p(res), _p(mn), _p(mx), _p(commits33), _p(data), _p(off), _p(edata), _p(eoff),
+                                                                       _p(gens64), n), "secp256k1_rangeproof_verify_batch_group")
+        return res, mn, mx
+
+    def schnorrsig_verify_batch(self, sigs, msgs, pubkeys, msglen=32, pk_format=0):
+        sigs = _u8(sigs); msgs = _u8(msgs); pubkeys = _u8(pubkeys); n = sigs.size // 64
+        _need("schnorrsig_verify_batch_group sigs", sigs, 64 * n); _need("schnorrsig_verify_batch_group msgs", msgs, msglen * n)
+        _need("schnorrsig_verify_batch_group pubkeys", pubkeys, (64 if pk_format else 32) * n)
+        res = np.zeros(n, np.int32)
+        self._check(self._lib.secp256k1_schnorrsig_verify_batch_group(self._h, _p(res), _p(sigs), _p(msgs), msglen, _p(pubkeys), pk_format, n),
+                    "secp256k1_schnorrsig_verify_batch_group")
+        return res
+
+    def ecmult_multi(self, sc, pt_xy, g_sc=None, pt_inf=None):
+        sc = _u8(sc); pt_xy = _u8(pt_xy); n = sc.size // 32
+        g_sc = None if g_sc is None else _u8(g_sc); pt_inf = None if pt_inf is None else _u8(pt_inf)
+        _need("ecmult_multi_group sc", sc, 32 * n); _need("ecmult_multi_group pt_xy", pt_xy, 64 * n)
+        if g_sc is not None: _need("ecmult_multi_group g_sc", g_sc, 32)
+        if pt_inf is not None: _need("ecmult_multi_group pt_inf", pt_inf, n)
+        r = np.zeros(64, np.uint8); inf = np.zeros(1, np.int32)
+        self._check(self._lib.s2k_ecmult_multi_group(self._h, _p(r), _p(inf), _p(g_sc), _p(sc), _p(pt_xy), _p(pt_inf), n), "s2k_ecmult_multi_group")
+        return r, int(inf[0])
+
+    def ecmult_multi_dev(self, sc_list, pt_list, g_sc_dev0=None, inf_list=None):
+        """per engine: torch uint8 tensors resident on that engine's GPU (sc (n_i,32), pt (n_i,64)); returns (xy bytes, inf)"""
+        k = len(self)
+        assert len(sc_list) == k and len(pt_list) == k
+        vp = ctypes.c_void_p * k
+        a = vp(*[t.data_ptr() for t in sc_list]); b = vp(*[t.data_ptr() for t in pt_list])
+        c = None if inf_list is None else vp(*[t.data_ptr() for t in inf_list])
+        cnt = (ctypes.c_size_t * k)(*[t.numel() // 32 for t in sc_list])
+        r = np.zeros(64, np.uint8); inf = np.zeros(1, np.int32)
+        self._check(self._lib.s2k_ecmult_multi_group_dev(self._h, _p(r), _p(inf), _dp(g_sc_dev0), a, b, c, cnt), "s2k_ecmult_multi_group_dev")
+        return r, int(inf[0])

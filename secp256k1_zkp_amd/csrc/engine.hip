@@ -14,6 +14,7 @@
 #include "surjection.h"
 #include "halfagg.h"
 #include "pedersen.h"
+#include "host_sha256.h"
 #include "../../include/secp256k1_zkp_amd.h"
 
 #include <hip/hip_runtime.h>
@@ -40,6 +41,11 @@ static int s2k_fail(const char* what, const char* detail) {
     g_last_status = S2K_STATUS_ENGINE_FAILURE;
     return 0;
 }
+static int s2k_fail_busy(const char* what, const char* detail) {
+    g_last_error = std::string(what) + ": " + (detail ? detail : "");
+    g_last_status = S2K_STATUS_BUSY;
+    return 0;
+}
 static int s2k_fail_arg(const char* what, const char* detail) {
     g_last_error = std::string(what) + ": " + (detail ? detail : "");
     g_last_status = S2K_STATUS_ILLEGAL_ARGUMENT;
@@ -55,10 +61,11 @@ extern "C" void s2k_clear_status(void) { g_last_status = S2K_STATUS_OK; g_last_e
 // ------------------------------------------------------------------------------------------------------------
 // engine object
 // ------------------------------------------------------------------------------------------------------------
+struct s2k_dev_pool;
 struct s2k_engine {
     int device;
     hipStream_t stream;
-    u32* gtab;                 // generator table (S2K_GTAB_WORDS words)
+    u32* gtab;                 // the device pool's generator table (S2K_GTAB_WORDS words) once a call of this engine has needed it (engine_gtab)
     unsigned char* ws;         // growable HBM workspace
     size_t ws_bytes;
     u32* ptab;                 // per-lane odd-multiples tables (S2K_PTAB_WORDS words per lane), grown on demand
@@ -87,19 +94,12 @@ struct s2k_engine {
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
     u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
     int bp_gens_ok;            // every generator of the cached set parsed (what k_bp_gens found when the table was built)
-    // Fixed-base tables of rangeproof generators (rangeproof.h, shared-generator form of the rings kernel): a small cache keyed by the 64
-    // generator bytes.  Slot tables have the layout of gtab (S2K_GTAB_WORDS words, allocated when a slot is first used and then reused by
-    // whatever generator takes the slot); xmul is the x-table of the ring-base multiples (RP_XMUL_WORDS).  gen_keys (device) is what
-    // k_rp_header matches a proof's generator against; gen_seen counts the VERIFIED proofs met per uncached generator (reported by
-    // k_rp_final through the device mailbox gen_mbox / its pinned copy, read at the next call) and a generator is built once it reaches
-    // gen_min.  `pinned`: secp256k1_generator_h and generators cached explicitly -- an automatic build never evicts those.
-    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; int pinned; } gen[RP_GEN_SLOTS];
-    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h; int gen_dirty;
-    unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
+    // The generator table and the cache of rangeproof generator tables live in the device's pool (below); per engine: the mailbox through
+    // which k_rp_final reports which tables served verified proofs and which uncached generators keep coming.
+    struct s2k_dev_pool* pool;
     rp_gen_mbox* gen_mbox;     // device
     rp_gen_mbox* gen_mbox_host;   // pinned copy taken at the end of the previous rangeproof call
     hipEvent_t ev_mbox; int mbox_pending;
-    std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;
     // pinned staging of the host-buffer rangeproof entry points (rp_host_submit): inputs are packed into it by a few host threads, chunk by
     // chunk, and every finished chunk goes to HBM at once (true DMA from pinned memory: the copies overlap the packing of the next chunks)
     // Two such sets (pinned in / pinned out / their device images), so that a second batch can be gathered and copied while the first one
@@ -108,12 +108,14 @@ struct s2k_engine {
         unsigned char* in; size_t in_bytes; unsigned char* out; size_t out_bytes; unsigned char* dev; size_t dev_bytes;
         hipEvent_t ev_h2d, ev_out; int used;
         uint64_t ticket;                                  // 0: free; otherwise the submission that owns the set until it is waited for
+        int sync_owned;                                   // the owner is a synchronous call (it hands the set back by itself)
         int32_t* results; uint64_t* min_value; uint64_t* max_value; size_t n, o_res, o_min, o_max;
     } stage[2];
     uint64_t next_ticket;
     std::condition_variable_any stage_cv;                 // a staging set was handed back (synchronous callers queue for one)
     hipStream_t stream_copy;
     int stage_threads;
+    u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
     std::recursive_mutex mu;
 };
 
@@ -261,42 +263,154 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// generator-table cache (rangeproof.h, shared-generator form): host side
+// per-device table pool + generator-table cache (rangeproof.h, shared-generator form): host side
 // ------------------------------------------------------------------------------------------------------------
+// The big tables belong to the DEVICE, not to an engine: the 11.8 GB fixed-base table of G and the cache of rangeproof generator tables
+// (11.8 GB each) are held once per HIP device in a reference-counted pool that every engine on that device shares.  A second engine on
+// a device -- the documented way to give every verifier thread its own stream, scratch and lock -- costs a few streams and events,
+// no table memory and no table build.  Tables are built lazily, by the first call that needs one (s2k_engine_reserve warms them up).
+// Ordering between engines: a build is stream-ordered on the building engine's stream and publishes an event; every other stream
+// that is about to read the table waits for that event until it is known to have completed.  The pool's mutex is held while an engine
+// takes its view of the cache AND enqueues the kernels that use it, and a slot's memory is only ever rewritten (eviction, fewer slots)
+// after a device-wide synchronisation under that mutex, so no kernel in flight can read a table that is being replaced.
+// Lock order: engine mutex, then pool mutex.
 // secp256k1_generator_h (src/modules/generator/main_impl.h:30-35): the generator of bench_rangeproof and of every non-asset caller
 static const unsigned char k_generator_h[64] = {
     0x50, 0x92, 0x9b, 0x74, 0xc1, 0xa0, 0x49, 0x54, 0xb7, 0x8b, 0x4b, 0x60, 0x35, 0xe9, 0x7a, 0x5e, 0x07, 0x8a, 0x5a, 0x0f, 0x28, 0xec, 0x96, 0xd5, 0x47, 0xbf, 0xee, 0x9a, 0xce, 0x80, 0x3a, 0xc0,
     0x31, 0xd3, 0xc6, 0x86, 0x39, 0x73, 0x92, 0x6e, 0x04, 0x9e, 0x63, 0x7c, 0xb1, 0xb5, 0xf4, 0x0a, 0x36, 0xda, 0xc2, 0x8a, 0xf1, 0x76, 0x69, 0x68, 0xc3, 0x0c, 0x23, 0x13, 0xf3, 0xa3, 0x89, 0x04};
-static rp_gen_dev gen_dev_view(const s2k_engine* e) {
-    rp_gen_dev gc; gc.keys = e->gen_keys; gc.valid = 0; gc.any = 0;
+struct s2k_dev_pool {
+    int device; int refs;
+    std::recursive_mutex mu;
+    u32* gtab; hipEvent_t ev_gtab; int gtab_state;           // 0: not built, 1: build queued (ev_gtab behind it), 2: known to be complete
+    // Fixed-base tables of rangeproof generators: a small cache keyed by the 64 generator bytes.  Slot tables have the layout of gtab
+    // (allocated when a slot is first used and then reused by whatever generator takes the slot); xmul is the x-table of the ring-base
+    // multiples (RP_XMUL_WORDS).  gen_keys (device) is what k_rp_header matches a proof's generator against; gen_seen counts the VERIFIED
+    // proofs met per uncached generator (k_rp_final reports them through each engine's device mailbox, read at that engine's next call)
+    // and a generator is built once it reaches gen_min.  pinned: secp256k1_generator_h and generators cached explicitly -- an automatic
+    // build never evicts those.
+    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; int pinned; hipEvent_t ev_ready; int done; } gen[RP_GEN_SLOTS];
+    int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h;
+    unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
+    std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;
+};
+static std::mutex g_pools_mu;
+static std::vector<s2k_dev_pool*> g_pools;
+static void pool_free_tables(s2k_dev_pool* p) {
+    if (p->gtab) hipFree(p->gtab);
+    p->gtab = nullptr; p->gtab_state = 0;
     for (int i = 0; i < RP_GEN_SLOTS; i++) {
-        const int v = i < e->gen_slots && e->gen[i].valid;
-        gc.tab[i] = v ? e->gen[i].tab : nullptr; gc.xmul[i] = v ? e->gen[i].xmul : nullptr;
+        if (p->gen[i].tab) hipFree(p->gen[i].tab);
+        if (p->gen[i].xmul) hipFree(p->gen[i].xmul);
+        p->gen[i].tab = nullptr; p->gen[i].xmul = nullptr; p->gen[i].valid = 0;
+    }
+}
+// (the caller has made `device` current)
+static s2k_dev_pool* pool_acquire(int device) {
+    std::lock_guard<std::mutex> g(g_pools_mu);
+    for (auto* p : g_pools) if (p->device == device) { p->refs++; return p; }
+    s2k_dev_pool* p = new s2k_dev_pool();
+    p->device = device; p->refs = 1; p->gtab = nullptr; p->ev_gtab = nullptr; p->gtab_state = 0; p->gen_keys = nullptr;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) { auto& g2 = p->gen[i]; g2.tab = nullptr; g2.xmul = nullptr; g2.valid = 0; g2.stamp = 0; g2.pinned = 0; g2.ev_ready = nullptr; g2.done = 0; }
+    p->gen_slots = 2; p->gen_clock = 0; p->gen_min = size_t(1) << 16; p->gen_h = 1;
+    if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); p->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
+    if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) p->gen_min = (size_t)strtoull(gm, nullptr, 10);
+    if (const char* gh = getenv("S2K_GEN_CACHE_H")) p->gen_h = atoi(gh) != 0;
+    int ok = hipEventCreateWithFlags(&p->ev_gtab, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < RP_GEN_SLOTS; i++) ok = hipEventCreateWithFlags(&p->gen[i].ev_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&p->gen_keys, 64 * RP_GEN_SLOTS) == hipSuccess && hipMemset(p->gen_keys, 0, 64 * RP_GEN_SLOTS) == hipSuccess;
+    if (!ok) {
+        s2k_fail("s2k_engine_create", "cannot create the device's table pool");
+        (void)hipGetLastError();
+        if (p->ev_gtab) hipEventDestroy(p->ev_gtab);
+        for (int i = 0; i < RP_GEN_SLOTS; i++) if (p->gen[i].ev_ready) hipEventDestroy(p->gen[i].ev_ready);
+        if (p->gen_keys) hipFree(p->gen_keys);
+        delete p; return nullptr;
+    }
+    g_pools.push_back(p);
+    return p;
+}
+// (the caller has made the device current and has synchronised it: nothing of the leaving engine is in flight)
+static void pool_release(s2k_dev_pool* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_pools_mu);
+    if (--p->refs > 0) return;
+    g_pools.erase(std::remove(g_pools.begin(), g_pools.end(), p), g_pools.end());
+    pool_free_tables(p);
+    if (p->gen_keys) hipFree(p->gen_keys);
+    if (p->ev_gtab) hipEventDestroy(p->ev_gtab);
+    for (int i = 0; i < RP_GEN_SLOTS; i++) if (p->gen[i].ev_ready) hipEventDestroy(p->gen[i].ev_ready);
+    delete p;
+}
+// The table of G, built by the first call on this device that needs it (stream-ordered on that call's stream); every later user's
+// stream waits for the build's event until it is known to be over.  Returns the table or nullptr (no memory: s2k_fail was called).
+static const u32* engine_gtab(s2k_engine* e, hipStream_t st) {
+    s2k_dev_pool* p = e->pool;
+    std::lock_guard<std::recursive_mutex> lock(p->mu);
+    if (p->gtab_state == 2) return p->gtab;
+    if (p->gtab_state == 0) {
+        if (hipMalloc((void**)&p->gtab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); p->gtab = nullptr; s2k_fail("engine_gtab", "no memory for the generator table (11.8 GB of HBM)"); return nullptr; }
+        int ok = hipMemsetAsync(p->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, st) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, p->gtab);
+            hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, p->gtab);
+            ok = hipGetLastError() == hipSuccess && hipEventRecord(p->ev_gtab, st) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); hipFree(p->gtab); p->gtab = nullptr; s2k_fail("engine_gtab", "generator table build failed"); return nullptr; }
+        p->gtab_state = 1;
+        return p->gtab;
+    }
+    if (hipEventQuery(p->ev_gtab) == hipSuccess) { p->gtab_state = 2; return p->gtab; }
+    (void)hipGetLastError();
+    if (hipStreamWaitEvent(st, p->ev_gtab, 0) != hipSuccess) { (void)hipGetLastError(); s2k_fail("engine_gtab", "hipStreamWaitEvent failed"); return nullptr; }
+    return p->gtab;
+}
+#define ENGINE_GTAB(e, st) do { if (!((e)->gtab = const_cast<u32*>(engine_gtab((e), (st))))) return 0; } while (0)
+// The cache as the kernels of one launch see it; `st` / `sp`: the streams that will read the tables (made to wait for builds still in flight)
+static rp_gen_dev gen_dev_view(s2k_engine* e, hipStream_t st, hipStream_t sp) {
+    s2k_dev_pool* p = e->pool;
+    rp_gen_dev gc; gc.keys = p->gen_keys; gc.valid = 0; gc.any = 0;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) {
+        auto& g = p->gen[i];
+        int v = i < p->gen_slots && g.valid;
+        if (v && !g.done) {
+            if (hipEventQuery(g.ev_ready) == hipSuccess) g.done = 1;
+            else {
+                (void)hipGetLastError();
+                if (hipStreamWaitEvent(st, g.ev_ready, 0) != hipSuccess || (sp && hipStreamWaitEvent(sp, g.ev_ready, 0) != hipSuccess)) { (void)hipGetLastError(); v = 0; }      // cannot order: do without this table
+            }
+        }
+        gc.tab[i] = v ? g.tab : nullptr; gc.xmul[i] = v ? g.xmul : nullptr;
         if (v) { gc.valid |= 1u << i; gc.any = (u32)i; }
     }
     return gc;
 }
-static int gen_cache_find(s2k_engine* e, const unsigned char* key) {
-    for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, key, 64)) { e->gen[i].stamp = ++e->gen_clock; return i; }
+static int gen_cache_find(s2k_dev_pool* p, const unsigned char* key) {
+    for (int i = 0; i < p->gen_slots; i++) if (p->gen[i].valid && !memcmp(p->gen[i].key, key, 64)) { p->gen[i].stamp = ++p->gen_clock; return i; }
     return -1;
 }
 // Builds (stream-ordered on `st`) the tables of `key` into a free slot or the least recently used one; -1 when there is no memory for a
-// table (the proofs then simply keep the general form).  Everything that may still read the slot's old content was queued on `st`
-// before (stream_guard) or waits for gen_dirty (rp_launch).  pinned = 0 is an AUTOMATIC build (a generator that kept coming on valid
+// table (the proofs then simply keep the general form).  pinned = 0 is an AUTOMATIC build (a generator that kept coming on valid
 // proofs): it only takes a free slot or the slot of another automatically built table -- never the table of secp256k1_generator_h or
-// one the application asked for -- and returns -1 when there is none.
+// one the application asked for -- and returns -1 when there is none.  (Pool mutex held by the caller.)
 static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key, int pinned) {
-    int slot = gen_cache_find(e, key);
-    if (slot >= 0) { if (pinned) e->gen[slot].pinned = 1; return slot; }
-    if (e->gen_slots <= 0) return -1;
+    s2k_dev_pool* p = e->pool;
+    int slot = gen_cache_find(p, key);
+    if (slot >= 0) { if (pinned) p->gen[slot].pinned = 1; return slot; }
+    if (p->gen_slots <= 0) return -1;
     slot = -1;
-    for (int i = 0; i < e->gen_slots; i++) {
-        if (!e->gen[i].valid) { slot = i; break; }
-        if (!pinned && e->gen[i].pinned) continue;
-        if (slot < 0 || e->gen[i].stamp < e->gen[slot].stamp) slot = i;
+    for (int i = 0; i < p->gen_slots; i++) {
+        if (!p->gen[i].valid) { slot = i; break; }
+        if (!pinned && p->gen[i].pinned) continue;
+        if (slot < 0 || p->gen[i].stamp < p->gen[slot].stamp) slot = i;
     }
     if (slot < 0) return -1;
-    s2k_engine::gen_slot& g = e->gen[slot];
+    s2k_dev_pool::gen_slot& g = p->gen[slot];
+    const u32* gtab = engine_gtab(e, st);
+    if (!gtab) return -1;
+    e->gtab = const_cast<u32*>(gtab);
+    // a slot whose memory may still be read -- by this engine's side streams or by another engine's kernels -- is rewritten only once the
+    // device is idle (an eviction is a 0.3 s table build anyway)
+    if (g.tab && hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
     if (!g.tab) {
         if (hipMalloc((void**)&g.tab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }
         if (hipMalloc((void**)&g.xmul, sizeof(u32) * RP_XMUL_WORDS) != hipSuccess) { (void)hipGetLastError(); hipFree(g.tab); g.tab = nullptr; g.xmul = nullptr; return -1; }
@@ -304,53 +418,54 @@ static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* k
     if (!engine_ptab(e, 2048)) return -1;
     g.valid = 0;
     memcpy(g.key, key, 64);
-    if (hipMemcpyAsync(e->gen_keys + 64 * slot, g.key, 64, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, e->gen_keys + 64 * slot);
+    if (hipMemcpyAsync(p->gen_keys + 64 * slot, g.key, 64, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, p->gen_keys + 64 * slot);
     hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, g.tab);
-    hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, e->gen_keys + 64 * slot, e->gtab, e->ptab);
-    if (hipGetLastError() != hipSuccess) return -1;
-    g.valid = 1; g.pinned = pinned; g.stamp = ++e->gen_clock;
-    e->gen_dirty = 1;
+    hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, p->gen_keys + 64 * slot, gtab, e->ptab);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(g.ev_ready, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    g.valid = 1; g.done = 0; g.pinned = pinned; g.stamp = ++p->gen_clock;
     return slot;
 }
-// `count` more proofs were seen with this (uncached) generator; returns 1 when it has now been seen often enough to deserve a table
-static int gen_note_seen(s2k_engine* e, const unsigned char* key, size_t count) {
-    for (auto& it : e->gen_seen) if (!memcmp(it.first.data(), key, 64)) { it.second += count; return it.second >= e->gen_min; }
-    if (e->gen_seen.size() >= 64) {                         // bounded: forget the least seen
-        size_t lo = 0; for (size_t i = 1; i < e->gen_seen.size(); i++) if (e->gen_seen[i].second < e->gen_seen[lo].second) lo = i;
-        e->gen_seen.erase(e->gen_seen.begin() + lo);
+// `count` more verified proofs were seen with this (uncached) generator; returns 1 when it has now been seen often enough to deserve a table
+static int gen_note_seen(s2k_dev_pool* p, const unsigned char* key, size_t count) {
+    for (auto& it : p->gen_seen) if (!memcmp(it.first.data(), key, 64)) { it.second += count; return it.second >= p->gen_min; }
+    if (p->gen_seen.size() >= 64) {                         // bounded: forget the least seen
+        size_t lo = 0; for (size_t i = 1; i < p->gen_seen.size(); i++) if (p->gen_seen[i].second < p->gen_seen[lo].second) lo = i;
+        p->gen_seen.erase(p->gen_seen.begin() + lo);
     }
     std::array<unsigned char, 64> k; memcpy(k.data(), key, 64);
-    e->gen_seen.emplace_back(k, count);
-    return count >= e->gen_min;
+    p->gen_seen.emplace_back(k, count);
+    return count >= p->gen_min;
 }
-static void gen_forget_seen(s2k_engine* e, const unsigned char* key) {
-    for (size_t i = 0; i < e->gen_seen.size(); i++) if (!memcmp(e->gen_seen[i].first.data(), key, 64)) { e->gen_seen.erase(e->gen_seen.begin() + i); return; }
+static void gen_forget_seen(s2k_dev_pool* p, const unsigned char* key) {
+    for (size_t i = 0; i < p->gen_seen.size(); i++) if (!memcmp(p->gen_seen[i].first.data(), key, 64)) { p->gen_seen.erase(p->gen_seen.begin() + i); return; }
 }
-// Start of a rangeproof call: (1) secp256k1_generator_h gets its table once, (2) what the final kernels of the call before reported
-// through the mailbox (its pinned copy is only read once the copy has completed): tables that served valid proofs get a fresh
-// least-recently-used stamp, uncached generators are counted by their VALID proofs and at most one that is due is built per call.
+// Start of a rangeproof call (pool mutex held): (1) secp256k1_generator_h gets its table once, (2) what the final kernels of this engine's
+// call before reported through the mailbox (its pinned copy is only read once the copy has completed): tables that served valid proofs
+// get a fresh least-recently-used stamp, uncached generators are counted by their VALID proofs and at most one that is due is built per call.
 static void gen_cache_service(s2k_engine* e, hipStream_t st) {
-    if (e->gen_slots <= 0) return;
-    if (e->gen_h == 1) { e->gen_h = 2; (void)gen_cache_build(e, st, k_generator_h, 1); }
+    s2k_dev_pool* p = e->pool;
+    if (p->gen_slots <= 0) return;
+    if (p->gen_h == 1) { p->gen_h = 2; (void)gen_cache_build(e, st, k_generator_h, 1); }
     if (e->mbox_pending && hipEventQuery(e->ev_mbox) == hipSuccess) {
         e->mbox_pending = 0;
-        for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && e->gen_mbox_host->hits[i]) e->gen[i].stamp = ++e->gen_clock;
+        // (slot indices in the report are those of the view the reporting call took; a slot replaced since then just gets a fresh stamp early)
+        for (int i = 0; i < p->gen_slots; i++) if (p->gen[i].valid && e->gen_mbox_host->hits[i]) p->gen[i].stamp = ++p->gen_clock;
         int built = 0;
         for (int m = 0; m < RP_GEN_MBOX; m++) {
             if (!e->gen_mbox_host->tag[m] || !e->gen_mbox_host->count[m]) continue;
             const unsigned char* key = e->gen_mbox_host->key[m];
             if (rp_gen_tag(key) != e->gen_mbox_host->tag[m]) continue;          // (key bytes of a slot whose claimant never wrote them)
             int cached = 0;
-            for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, key, 64)) cached = 1;
+            for (int i = 0; i < p->gen_slots; i++) if (p->gen[i].valid && !memcmp(p->gen[i].key, key, 64)) cached = 1;
             if (cached) continue;
-            if (gen_note_seen(e, key, e->gen_mbox_host->count[m]) && !built && gen_cache_build(e, st, key, 0) >= 0) { gen_forget_seen(e, key); built = 1; }
+            if (gen_note_seen(p, key, e->gen_mbox_host->count[m]) && !built && gen_cache_build(e, st, key, 0) >= 0) { gen_forget_seen(p, key); built = 1; }
         }
     } else if (e->mbox_pending) (void)hipGetLastError();
 }
 // End of a rangeproof call: copy the mailbox out and clear it (both on `st`, behind the call's kernels)
 static void gen_cache_collect(s2k_engine* e, hipStream_t st) {
-    if (e->gen_slots <= 0 || e->mbox_pending) return;
+    if (e->pool->gen_slots <= 0 || e->mbox_pending) return;
     if (hipMemcpyAsync(e->gen_mbox_host, e->gen_mbox, sizeof(rp_gen_mbox), hipMemcpyDeviceToHost, st) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipMemsetAsync(e->gen_mbox, 0, sizeof(rp_gen_mbox), st) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipEventRecord(e->ev_mbox, st) == hipSuccess) e->mbox_pending = 1; else (void)hipGetLastError();
@@ -373,22 +488,19 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->ev_rp_draws = nullptr; e->ev_rp_rewound = nullptr; e->rp_rewound_valid = 0;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     e->rp_last_plan[0] = e->rp_last_plan[1] = nullptr;
+    e->ha_pin = nullptr; e->ha_pin_words = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
-    for (int i = 0; i < 2; i++) { auto& S = e->stage[i]; S.in = S.out = S.dev = nullptr; S.in_bytes = S.out_bytes = S.dev_bytes = 0; S.ev_h2d = S.ev_out = nullptr; S.used = 0; S.ticket = 0; }
+    for (int i = 0; i < 2; i++) { auto& S = e->stage[i]; S.in = S.out = S.dev = nullptr; S.in_bytes = S.out_bytes = S.dev_bytes = 0; S.ev_h2d = S.ev_out = nullptr; S.used = 0; S.ticket = 0; S.sync_owned = 0; }
     e->next_ticket = 1; e->stream_copy = nullptr;
     { unsigned hc = std::thread::hardware_concurrency(); e->stage_threads = (int)std::min(8u, std::max(1u, hc / 2)); }
     if (const char* th = getenv("S2K_STAGE_THREADS")) { const int v = atoi(th); if (v >= 1 && v <= 64) e->stage_threads = v; }
 #ifdef S2K_DIAG          /* diagnostic builds only (tools/rings_parts.py builds its own library with -DS2K_DIAG): a verifier's verdicts never depend on the environment */
     if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
 #endif
-    for (int i = 0; i < RP_GEN_SLOTS; i++) { e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0; e->gen[i].stamp = 0; e->gen[i].pinned = 0; }
-    e->gen_slots = 2; e->gen_clock = 0; e->gen_min = size_t(1) << 16; e->gen_h = 1; e->gen_dirty = 0;
-    e->gen_keys = nullptr; e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
-    if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); e->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
-    if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) e->gen_min = (size_t)strtoull(gm, nullptr, 10);
-    if (const char* gh = getenv("S2K_GEN_CACHE_H")) e->gen_h = atoi(gh) != 0;
+    e->pool = nullptr;
+    e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
 #define S2K_CREATE_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { s2k_fail(#call, hipGetErrorString(_e)); s2k_engine_destroy(e); return nullptr; } } while (0)
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
@@ -424,18 +536,12 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->host_flags, 64, hipHostMallocDefault));
     S2K_CREATE_CHK(hipMalloc((void**)&e->dev_flags, 64));
     S2K_CREATE_CHK(hipMemset(e->dev_flags, 0, 64));
-    S2K_CREATE_CHK(hipMalloc((void**)&e->gen_keys, 64 * RP_GEN_SLOTS));
-    S2K_CREATE_CHK(hipMemset(e->gen_keys, 0, 64 * RP_GEN_SLOTS));
     S2K_CREATE_CHK(hipMalloc((void**)&e->gen_mbox, sizeof(rp_gen_mbox)));
     S2K_CREATE_CHK(hipMemset(e->gen_mbox, 0, sizeof(rp_gen_mbox)));
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->gen_mbox_host, sizeof(rp_gen_mbox), hipHostMallocDefault));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_mbox, hipEventDisableTiming));
-    S2K_CREATE_CHK(hipMalloc((void**)&e->gtab, sizeof(u32) * S2K_GTAB_WORDS));
-    S2K_CREATE_CHK(hipMemsetAsync(e->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, e->stream));
-    hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, e->stream, e->gtab);
-    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, e->stream, e->gtab);
-    S2K_CREATE_CHK(hipGetLastError());
-    S2K_CREATE_CHK(hipStreamSynchronize(e->stream));
+    e->pool = pool_acquire(device);            // the device's tables: shared with every other engine on it, built on first use
+    if (!e->pool) { s2k_engine_destroy(e); return nullptr; }
 #undef S2K_CREATE_CHK
     return e;
 }
@@ -445,9 +551,9 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     hipDeviceSynchronize();            // `_dev` calls may have been issued on caller streams: nothing of this engine may still be in flight
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
-    if (e->gtab) hipFree(e->gtab);
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
+    if (e->ha_pin) hipHostFree(e->ha_pin);
     for (int i = 0; i < 2; i++) {
         auto& S = e->stage[i];
         if (S.in) hipHostFree(S.in);
@@ -458,8 +564,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     }
     if (e->stream_copy) hipStreamDestroy(e->stream_copy);
     if (e->dev_flags) hipFree(e->dev_flags);
-    for (int i = 0; i < RP_GEN_SLOTS; i++) { if (e->gen[i].tab) hipFree(e->gen[i].tab); if (e->gen[i].xmul) hipFree(e->gen[i].xmul); }
-    if (e->gen_keys) hipFree(e->gen_keys);
+    pool_release(e->pool);
     if (e->gen_mbox) hipFree(e->gen_mbox);
     if (e->gen_mbox_host) hipHostFree(e->gen_mbox_host);
     if (e->ev_mbox) hipEventDestroy(e->ev_mbox);
@@ -493,7 +598,13 @@ extern "C" int s2k_engine_sync(s2k_engine* e) {
 }
 extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
     if (bytes) *bytes = sizeof(u32) * S2K_GTAB_WORDS;
-    return e ? e->gtab : nullptr;
+    if (!e) return nullptr;
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    const u32* t = engine_gtab(e, e->stream);                  // (built now if no call has needed it yet)
+    if (!t || hipStreamSynchronize(e->stream) != hipSuccess) return nullptr;
+    e->gtab = const_cast<u32*>(t);
+    return t;
 }
 extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) {
     if (!e) return 0;
@@ -564,6 +675,7 @@ extern "C" int s2k_ecmult_batch_dev(s2k_engine* e, void* stream, unsigned char* 
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
+    ENGINE_GTAB(e, st);
     HIPCHK(hipEventRecord(e->ev[0], st));
     HIPCHK(hipEventRecord(e->ev[2], st));
     for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {
@@ -844,15 +956,17 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     const size_t nw = std::min(n, RP_CHUNK);
     if (!engine_rp_slots(e, nw)) return 0;
     if (!engine_rtab(e, nw * RP_MAX_RINGS)) return 0;
+    // the device's tables: held from the moment this call takes its view of the generator-table cache until its last kernel is queued
+    std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu);
+    ENGINE_GTAB(e, st);
+    const hipStream_t sp = e->stream_pre;
     gen_cache_service(e, st);
-    const rp_gen_dev gc = gen_dev_view(e);
+    const rp_gen_dev gc = gen_dev_view(e, st, sp);           // (streams that will read a table still being built wait for its event)
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st));
-    const hipStream_t sp = e->stream_pre;
-    // (a table built or replaced since the last call was queued on `st`: the side stream must see it, too)
     // (inputs_ev: the inputs arrive on another stream, which recorded this event behind them -- the host-buffer entry points' copy stream)
     if (inputs_ev) HIPCHK(hipStreamWaitEvent(sp, inputs_ev, 0));
-    if (inputs_on_stream || (!inputs_ev && !e->rp_inputs_ready) || e->gen_dirty) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); e->gen_dirty = 0; }
+    if (inputs_on_stream || (!inputs_ev && !e->rp_inputs_ready)) { HIPCHK(hipEventRecord(e->ev_rp_in, st)); HIPCHK(hipStreamWaitEvent(sp, e->ev_rp_in, 0)); }
     for (size_t p0 = 0; p0 < n; p0 += RP_CHUNK) {
         const size_t m = std::min(n - p0, RP_CHUNK);
         const unsigned b64 = (unsigned)((m + 63) / 64), b256 = (unsigned)((m * 32 + 255) / 256);
@@ -891,7 +1005,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
         hipLaunchKernelGGL(k_rp_rings, dim3(b256), dim3(256), 0, st, w, proofs, proof_off + p0, e->gtab, e->ptab, rewind ? rewind->ev : (u32*)nullptr, e->rp_split);
         if (p0 == 0) { HIPCHK(hipEventRecord(e->ev[3], st)); HIPCHK(hipEventRecord(e->ev_ring[rq][1], st)); e->ring_seq++; }
         hipLaunchKernelGGL(k_rp_final, dim3(b64), dim3(64), 0, st, w, results + p0, proofs, proof_off + p0, gens64 + 64 * p0,
-                           e->gen_slots > 0 ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
+                           e->pool->gen_slots > 0 ? e->gen_mbox : (rp_gen_mbox*)nullptr, m);
         if (rewind) {
             rp_rewind_args ra = *rewind;                      // scratch is per chunk, the caller's arrays are per batch
             ra.blind_out += 32 * p0; ra.value_out += p0; ra.nonces += 32 * p0;
@@ -917,15 +1031,16 @@ extern "C" int s2k_engine_cache_generator(s2k_engine* e, const unsigned char* ge
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     stream_guard sg(e, e->stream);
-    if (e->gen_h == 1 && !memcmp(gen64, k_generator_h, 64)) e->gen_h = 2;
+    std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu);
+    if (e->pool->gen_h == 1 && !memcmp(gen64, k_generator_h, 64)) e->pool->gen_h = 2;
     if (gen_cache_build(e, e->stream, gen64, 1) < 0) return s2k_fail("s2k_engine_cache_generator", "no slot or no memory for a generator table (S2K_GEN_CACHE)");
     return 1;
 }
 // 1 when `gen64` currently has a table
 extern "C" int s2k_engine_generator_cached(s2k_engine* e, const unsigned char* gen64) {
     if (!e || !gen64) return 0;
-    std::lock_guard<std::recursive_mutex> lock(e->mu);
-    for (int i = 0; i < e->gen_slots; i++) if (e->gen[i].valid && !memcmp(e->gen[i].key, gen64, 64)) return 1;
+    std::lock_guard<std::recursive_mutex> lock(e->pool->mu);
+    for (int i = 0; i < e->pool->gen_slots; i++) if (e->pool->gen[i].valid && !memcmp(e->pool->gen[i].key, gen64, 64)) return 1;
     return 0;
 }
 extern "C" int secp256k1_rangeproof_verify_batch_dev(s2k_engine* e, void* stream, int32_t* results, uint64_t* min_value, uint64_t* max_value,
@@ -982,8 +1097,19 @@ static int engine_stage(s2k_engine* e, s2k_engine::stage_set& S, size_t in_bytes
 // the one before it computes has its inputs in HBM -- and its header / prologue stage done -- by the time the rings kernel is free.
 // `queue`: the caller's lock on the engine when it is a SYNCHRONOUS entry point -- such a call waits its turn for a staging set (several
 // verifier threads on one engine take turns, two of them overlapping) where the asynchronous `_submit` reports "two in flight".
+struct thread_joiner { std::vector<std::thread>& w; ~thread_joiner() { for (auto& t : w) if (t.joinable()) t.join(); } };
+static int rp_host_submit_impl(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n,
+                               std::unique_lock<std::recursive_mutex>* queue);
+// (these functions sit right behind extern "C" entry points: nothing may leave them as a C++ exception -- a failed allocation or thread
+// start is an engine failure like any other, and the packing threads are joined on every path)
 static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n,
                           std::unique_lock<std::recursive_mutex>* queue = nullptr) {
+    try { return rp_host_submit_impl(e, who, ticket, results, min_value, max_value, src, n, queue); }
+    catch (const std::exception& ex) { (void)hipStreamSynchronize(e->stream_copy); return s2k_fail(who, ex.what()); }
+    catch (...) { (void)hipStreamSynchronize(e->stream_copy); return s2k_fail(who, "unexpected exception"); }
+}
+static int rp_host_submit_impl(s2k_engine* e, const char* who, uint64_t* ticket, int32_t* results, uint64_t* min_value, uint64_t* max_value, const rp_host_src& src, size_t n,
+                               std::unique_lock<std::recursive_mutex>* queue) {
     const int ptrs = src.commit_objs != nullptr;
     const int has_extra = ptrs ? (src.extra_ptrs != nullptr) : (src.extra != nullptr && src.extra_off != nullptr);
     int si = -1;
@@ -991,9 +1117,11 @@ static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int3
         const int pref = (int)(e->next_ticket & 1u);
         si = !e->stage[pref].ticket ? pref : (!e->stage[pref ^ 1].ticket ? (pref ^ 1) : -1);
         if (si >= 0) break;
-        if (!queue) return s2k_fail_arg(who, "two batches in flight already: wait for a ticket first");
-        if (e->stage_cv.wait_for(*queue, std::chrono::seconds(60)) == std::cv_status::timeout && e->stage[0].ticket && e->stage[1].ticket)
-            return s2k_fail_arg(who, "both staging sets are held by tickets nobody waits for");
+        if (!queue) return s2k_fail_busy(who, "two batches in flight already: wait for a ticket first");
+        // a synchronous caller queues behind other synchronous callers (they hand their sets back by themselves); when both sets belong to
+        // asynchronous tickets only the application can free one, so the call reports "busy" at once instead of stalling
+        if (!e->stage[0].sync_owned && !e->stage[1].sync_owned) return s2k_fail_busy(who, "both staging sets are held by asynchronous tickets: wait for one first");
+        e->stage_cv.wait_for(*queue, std::chrono::seconds(1));
     }
     s2k_engine::stage_set& S = e->stage[si];
     // sizes and offsets
@@ -1062,9 +1190,14 @@ static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int3
         if (pbytes && hipMemcpyAsync(ds + o_pr, hs + o_pr, pbytes, hipMemcpyHostToDevice, cp) != hipSuccess) ok = 0;
     } else {
         std::vector<std::thread> workers;
-        for (int t = 1; t < nt; t++) workers.emplace_back(pack, t);
-        for (int c = 0; c < nchunk; c += nt) { pack_piece(c); queue_ready(false); }      // this thread packs its share and queues whatever is ready, in order
-        for (auto& w : workers) w.join();
+        {
+            thread_joiner joiner{workers};
+            int started = 1;
+            try { workers.reserve(nt); for (int t = 1; t < nt; t++) { workers.emplace_back(pack, t); started++; } }
+            catch (...) { }                                                              // fewer workers than planned: this thread packs the rest
+            for (int c = 0; c < nchunk; c += nt) { pack_piece(c); queue_ready(false); }      // this thread packs its share and queues whatever is ready, in order
+            for (int t = started; t < nt; t++) pack(t);
+        }
         queue_ready(true);
     }
     if (!ok) { (void)hipGetLastError(); (void)hipStreamSynchronize(cp); return s2k_fail(who, "host to device copy failed"); }
@@ -1077,7 +1210,7 @@ static int rp_host_submit(s2k_engine* e, const char* who, uint64_t* ticket, int3
                    ds + o_gen, n, nullptr, 0, S.ev_h2d)) { (void)hipStreamSynchronize(cp); return 0; }
     HIPCHK(hipMemcpyAsync(S.out, dout, out_bytes - 256, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(S.ev_out, st));
-    S.used = 1; S.ticket = e->next_ticket++; S.results = results; S.min_value = min_value; S.max_value = max_value; S.n = n; S.o_res = o_res; S.o_min = o_min; S.o_max = o_max;
+    S.used = 1; S.ticket = e->next_ticket++; S.sync_owned = queue != nullptr; S.results = results; S.min_value = min_value; S.max_value = max_value; S.n = n; S.o_res = o_res; S.o_min = o_min; S.o_max = o_max;
     *ticket = S.ticket;
     if (tlog) fprintf(stderr, "[s2k stage] n=%zu threads=%d: small arrays %.2f ms, proofs packed+queued %.2f ms, H2D drained +%.2f ms, launch %.2f ms\n",
                       n, nt, ms(t_begin, t_small), ms(t_small, t_packed), ms(t_packed, t_h2d), ms(t_h2d, now()));
@@ -1097,9 +1230,9 @@ static int rp_host_wait(s2k_engine* e, const char* who, uint64_t ticket) {
     const hipError_t err = hipEventSynchronize(ev);
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     if (S->ticket != ticket) return s2k_fail_arg(who, "unknown ticket (waited for by another thread meanwhile)");
-    if (err != hipSuccess) { S->ticket = 0; e->stage_cv.notify_all(); (void)hipGetLastError(); return s2k_fail(who, hipGetErrorString(err)); }      // (the arrays keep the zeros of submission time)
+    if (err != hipSuccess) { S->ticket = 0; S->sync_owned = 0; e->stage_cv.notify_all(); (void)hipGetLastError(); return s2k_fail(who, hipGetErrorString(err)); }      // (the arrays keep the zeros of submission time)
     memcpy(S->results, S->out + S->o_res, 4 * S->n); memcpy(S->min_value, S->out + S->o_min, 8 * S->n); memcpy(S->max_value, S->out + S->o_max, 8 * S->n);
-    S->ticket = 0;
+    S->ticket = 0; S->sync_owned = 0;
     e->stage_cv.notify_all();
     return 1;
 }
@@ -1379,6 +1512,7 @@ extern "C" int secp256k1_schnorrsig_verify_batch_dev(s2k_engine* e, void* stream
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
+    ENGINE_GTAB(e, st);
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
     for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {
@@ -2037,6 +2171,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
                       const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1) {
     const size_t nt = n + (g_sc ? 1 : 0);
     if (parts == 0 || part >= parts) return s2k_fail_arg("s2k_ecmult_multi", "window share out of range");
+    ENGINE_GTAB(e, st);                                        // (the bucket-free exact path multiplies by G through the table)
     msm_plan pl = msm_make_plan(nt ? nt : 1);
     // term references are packed as (u32)(term << 2 | half << 1 | sign): refuse what those cannot index instead of wrapping silently
     if (nt >= (size_t(1) << 30) || nt * 2 * pl.windows >= (size_t(1) << 32))
@@ -2360,6 +2495,7 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
     // not an illegal argument that would read as a rejected proof)
     if (sh.log_g > BP_MAX_LOG_G) return s2k_fail("secp256k1_bppp_norm_product_verify_batch", "g_len above 256 is not supported by this engine");
     if (!engine_ptab(e, ((nt + 255) / 256) * 256)) return 0;
+    ENGINE_GTAB(e, st);
     HIPCHK(hipMemsetAsync(d_res, 0, sizeof(int32_t) * n, st));
     HIPCHK(hipEventRecord(e->ev[0], st));
     int fixed = 0;
@@ -2500,6 +2636,7 @@ k_bpc_final(unsigned char* commits33, int32_t* results, const u32* sums28, const
 static int bpc_launch(s2k_engine* e, hipStream_t st, ws_carver& c, unsigned char* d_out33, int32_t* d_res, const unsigned char* d_g33, const unsigned char* gens33_host,
                       size_t n_gens, size_t g_len, size_t h_len, const unsigned char* d_nv, const unsigned char* d_lv, const unsigned char* d_cv, const unsigned char* d_mu, size_t n) {
     const size_t T = n_gens + 1;
+    ENGINE_GTAB(e, st);
     u32* gens18 = c.take<u32>(n_gens * 18); int* gens_ok = c.take<int>(16); u32* v8 = c.take<u32>(8 * n);
     u32* out28 = c.take<u32>(n * T * 28); u32* bufA = c.take<u32>((n * (T / 1024 + 1) + 64) * 28); u32* bufB = c.take<u32>((n * (T / 1024 + 1) + 64) * 28);
     hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, (u32*)gens_ok, 1u);
@@ -2600,6 +2737,7 @@ extern "C" int secp256k1_surjectionproof_verify_batch_dev(s2k_engine* e, void* s
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     if (!engine_ptab(e, ((std::min(n, e->max_lanes) + 255) / 256) * 256)) return 0;
+    ENGINE_GTAB(e, st);
     HIPCHK(hipMemsetAsync(results, 0, sizeof(int32_t) * n, st));          // a batch that does not complete never shows an item as valid
     HIPCHK(hipEventRecord(e->ev[0], st)); HIPCHK(hipEventRecord(e->ev[2], st));
     for (size_t i0 = 0; i0 < n; i0 += e->max_lanes) {     // offsets are absolute, so a sub-range only shifts the per-item arrays
@@ -2690,19 +2828,54 @@ static size_t ha_ws_bytes(size_t n) {
     const size_t nblocks = (3 * n) >> 1, nt = 2 * n + 1;
     return ws_need({128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16}) + msm_ws_bytes(nt + 1, msm_make_plan(nt));
 }
-// device pointers in, verdict to d_res[0]; aggsig_len already checked to be 32 (n + 1)
+// The randomizer hash's chain on the host (host_sha256.h): state after every full 64-byte block of r_0|x(P_0)|m_0|r_1|..., into pinned
+// memory.  pk_format 0: the serialised key IS x(P_i) (a key that does not parse makes the verdict 0 whatever is hashed); 1: the object's
+// first 32 bytes are x, least significant byte first.
+struct ha_host_src { const unsigned char* aggsig; const unsigned char* pks; int pk_format; const unsigned char* msgs32; };
+static void ha_host_chain(u32* states, const ha_host_src& h, size_t nblocks) {
+    uint32_t st[8]; ha_tag_midstate(st);
+    const size_t pkb = h.pk_format ? 64 : 32;
+    unsigned char blk[64];
+    for (size_t j = 0; j < nblocks; j++) {
+        for (int half = 0; half < 2; half++) {
+            const size_t u = 2 * j + half, i = u / 3; const unsigned part = (unsigned)(u % 3);
+            unsigned char* o = blk + 32 * half;
+            if (part == 0) memcpy(o, h.aggsig + 32 * i, 32);
+            else if (part == 2) memcpy(o, h.msgs32 + 32 * i, 32);
+            else if (!h.pk_format) memcpy(o, h.pks + pkb * i, 32);
+            else { for (int k = 0; k < 32; k++) o[k] = h.pks[pkb * i + 31 - k]; }
+        }
+        host_sha256_compress(st, blk);
+        for (int k = 0; k < 8; k++) states[8 * j + k] = st[k];
+    }
+}
+// device pointers in, verdict to d_res[0]; aggsig_len already checked to be 32 (n + 1).  host: the same inputs in host memory -- the
+// hash chain is then walked on the host underneath the point-lifting kernel and its states uploaded (the device chain is 2.4 us per
+// block on one wavefront: 118 ms for 2^15 signatures against ~2.6 ms here); nullptr: the device chain.
 static int ha_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res, const unsigned char* d_pk, int pk_format, const unsigned char* d_msg, size_t n,
-                     const unsigned char* d_agg) {
+                     const unsigned char* d_agg, const ha_host_src* host = nullptr) {
     const size_t nblocks = (3 * n) >> 1;
     unsigned char* d_pts = c.take<unsigned char>(128 * n + 64);
     unsigned char* d_pkx = c.take<unsigned char>(32 * n + 64); u32* d_wk = c.take<u32>(nblocks * 64 + 16); u32* d_states = c.take<u32>(nblocks * 8 + 16);
     unsigned char* d_sc = c.take<unsigned char>(64 * n + 64); unsigned char* d_g = c.take<unsigned char>(64); u32* d_flags = c.take<u32>(16);
+    if (host && nblocks * 8 > e->ha_pin_words) {
+        HIPCHK(hipStreamSynchronize(st));                       // (an earlier call's upload may still read the old buffer)
+        if (e->ha_pin) HIPCHK(hipHostFree(e->ha_pin));
+        e->ha_pin = nullptr; e->ha_pin_words = 0;
+        const size_t words = (nblocks * 8 + 4095) & ~size_t(4095);
+        HIPCHK(hipHostMalloc((void**)&e->ha_pin, words * sizeof(u32), hipHostMallocDefault));
+        e->ha_pin_words = words;
+    }
     HIPCHK(hipMemsetAsync(d_res, 0, 4, st));
     HIPCHK(hipMemsetAsync(d_flags, 0, 64, st));
     HIPCHK(hipEventRecord(e->ev[0], st));
     const unsigned bn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_ha_points, dim3(bn), dim3(256), 0, st, d_pts, d_pkx, d_flags, d_agg, d_pk, pk_format, n);
-    if (nblocks) {
+    if (nblocks && host) {
+        HIPCHK(hipGetLastError());
+        ha_host_chain(e->ha_pin, *host, nblocks);              // the GPU lifts the points meanwhile
+        HIPCHK(hipMemcpyAsync(d_states, e->ha_pin, nblocks * 8 * sizeof(u32), hipMemcpyHostToDevice, st));
+    } else if (nblocks) {
         hipLaunchKernelGGL(k_ha_schedule, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, d_wk, d_agg, d_pkx, d_msg, nblocks);
         hipLaunchKernelGGL(k_ha_chain, dim3(1), dim3(64), 0, st, d_states, d_wk, nblocks);
     }
@@ -2752,7 +2925,9 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     }
     HIPCHK(hipMemcpyAsync(d_agg, aggsig, 32 * (n + 1), hipMemcpyHostToDevice, st));
     ws_carver c{e->ws, 0};
-    if (!ha_launch(e, st, c, d_res, d_pk, pk_format, d_msg, n, d_agg)) return 0;
+    static const int host_chain = [] { const char* v = getenv("S2K_HALFAGG_HOST_CHAIN"); return v ? atoi(v) != 0 : 1; }();      // 0: the device chain (same verdicts; tests)
+    const ha_host_src hsrc{aggsig, pubkeys, pk_format, msgs32};
+    if (!ha_launch(e, st, c, d_res, d_pk, pk_format, d_msg, n, d_agg, host_chain ? &hsrc : nullptr)) return 0;
     HIPCHK(hipMemcpyAsync(result, d_res, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 1;
@@ -2856,20 +3031,22 @@ extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
     switch (option) {
     case S2K_OPT_RP_INPUTS_READY: e->rp_inputs_ready = value != 0; return 1;
     case S2K_OPT_RP_SPLIT: e->rp_split = value != 0; return 1;
-    case S2K_OPT_GEN_CACHE_SLOTS: {
+    case S2K_OPT_GEN_CACHE_SLOTS: {                             // (the cache belongs to the device: every engine on it sees the change)
+        s2k_dev_pool* p = e->pool;
+        std::lock_guard<std::recursive_mutex> pool_lock(p->mu);
         const int v = value < 0 ? 0 : (value > RP_GEN_SLOTS ? RP_GEN_SLOTS : (int)value);
-        if (v < e->gen_slots) {                            // slots that go away give their tables back once nothing can still read them
+        if (v < p->gen_slots) {                            // slots that go away give their tables back once nothing can still read them
             if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return s2k_fail("s2k_engine_set_option", "device synchronisation failed");
-            for (int i = v; i < e->gen_slots; i++) {
-                if (e->gen[i].valid && !memcmp(e->gen[i].key, k_generator_h, 64) && e->gen_h == 2) e->gen_h = 1;
-                if (e->gen[i].tab) hipFree(e->gen[i].tab);
-                if (e->gen[i].xmul) hipFree(e->gen[i].xmul);
-                e->gen[i].tab = nullptr; e->gen[i].xmul = nullptr; e->gen[i].valid = 0;
+            for (int i = v; i < p->gen_slots; i++) {
+                if (p->gen[i].valid && !memcmp(p->gen[i].key, k_generator_h, 64) && p->gen_h == 2) p->gen_h = 1;
+                if (p->gen[i].tab) hipFree(p->gen[i].tab);
+                if (p->gen[i].xmul) hipFree(p->gen[i].xmul);
+                p->gen[i].tab = nullptr; p->gen[i].xmul = nullptr; p->gen[i].valid = 0; p->gen[i].pinned = 0;
             }
         }
-        e->gen_slots = v; return 1;
+        p->gen_slots = v; return 1;
     }
-    case S2K_OPT_GEN_CACHE_MIN: e->gen_min = value < 1 ? 1 : (size_t)value; return 1;
+    case S2K_OPT_GEN_CACHE_MIN: { std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu); e->pool->gen_min = value < 1 ? 1 : (size_t)value; return 1; }
     default: return s2k_fail_arg("s2k_engine_set_option", "unknown option");
     }
 }
@@ -2879,5 +3056,267 @@ extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) {
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t nw = std::min(n_items, RP_CHUNK);
-    return engine_workspace(e, n_items * 5400) && engine_rp_slots(e, nw) && engine_ptab(e, nw * RP_MAX_RINGS);
+    if (!(engine_workspace(e, n_items * 5400) && engine_rp_slots(e, nw) && engine_ptab(e, nw * RP_MAX_RINGS))) return 0;
+    // warm-up: the device's tables (the table of G; secp256k1_generator_h's when the generator-table cache is on) are built now rather than by
+    // the first call that needs them
+    stream_guard sg(e, e->stream);
+    ENGINE_GTAB(e, e->stream);
+    {
+        std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu);
+        if (e->pool->gen_slots > 0 && e->pool->gen_h == 1) { e->pool->gen_h = 2; (void)gen_cache_build(e, e->stream, k_generator_h, 1); }
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 1;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI: engine groups -- the GPUs of one node behind one handle (include/secp256k1_zkp_amd.h, "engine groups")
+// ------------------------------------------------------------------------------------------------------------
+// One engine per entry of `devices` and one host thread per engine (its device stays current on that thread).  Independent items
+// (rangeproofs, signatures) are REPLICA work: a batch is cut into contiguous index ranges, every engine runs its range through its own
+// host-buffer entry point -- pinned staging, copies, kernels and results all proceed in parallel on the node's GPUs, no data crosses
+// between them.  One large multi-scalar multiplication is sharded by TERMS: every engine sums its slice to a 112-byte Jacobian partial
+// (s2k_ecmult_multi_partial_dev), the partials are copied to the first engine's device (hipMemcpyPeerAsync: xGMI when the devices are
+// peers) and summed there (s2k_gej_sum_dev) -- EC addition is not a reduction operator of a collective library, and 112 bytes per
+// device do not need one.
+#include <functional>
+struct s2k_group {
+    std::vector<s2k_engine*> eng;
+    struct worker { std::thread th; std::mutex mu; std::condition_variable cv; std::function<int()> job; int has_job = 0, done = 0, quit = 0, ok = 0, status = 0; std::string err; };
+    std::vector<worker*> wk;
+    std::mutex call_mu;                    // one group call at a time
+    u32* gather = nullptr;                 // on eng[0]'s device: [n][28] Jacobian partials
+    u32** partial = nullptr;               // partial[i] on eng[i]'s device: 28 words
+    unsigned char* res_xy = nullptr; int32_t* res_inf = nullptr;      // on eng[0]'s device
+    hipEvent_t* ev = nullptr;              // ev[i] on eng[i]'s device: partial i has arrived in `gather`
+};
+static void group_worker_main(s2k_group::worker* w, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = 0;
+        lk.unlock();
+        int ok = 0;
+        g_last_status = S2K_STATUS_OK; g_last_error.clear();
+        try { ok = job(); } catch (const std::exception& ex) { ok = s2k_fail("s2k_group", ex.what()); } catch (...) { ok = s2k_fail("s2k_group", "unexpected exception"); }
+        lk.lock();
+        w->ok = ok; w->status = g_last_status; w->err = g_last_error; w->done = 1;
+        w->cv.notify_all();
+    }
+}
+// runs jobs[i] on worker i (all of them concurrently); 1 when every job returned 1, otherwise the first failure's status and message
+static int group_run(s2k_group* g, std::vector<std::function<int()>>& jobs) {
+    for (size_t i = 0; i < jobs.size(); i++) {
+        auto* w = g->wk[i];
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->job = std::move(jobs[i]); w->has_job = 1; w->done = 0;
+        w->cv.notify_all();
+    }
+    int ok = 1;
+    for (size_t i = 0; i < jobs.size(); i++) {
+        auto* w = g->wk[i];
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done != 0; });
+        if (!w->ok && ok) { ok = 0; g_last_status = w->status ? w->status : S2K_STATUS_ENGINE_FAILURE; g_last_error = w->err; }
+    }
+    return ok;
+}
+extern "C" void s2k_group_destroy(s2k_group* g) {
+    if (!g) return;
+    for (auto* w : g->wk) {
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = 1; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    if (!g->eng.empty() && g->eng[0]) {
+        (void)hipSetDevice(g->eng[0]->device);
+        if (g->gather) hipFree(g->gather);
+        if (g->res_xy) hipFree(g->res_xy);
+        if (g->res_inf) hipFree(g->res_inf);
+    }
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        if (!g->eng[i]) continue;
+        (void)hipSetDevice(g->eng[i]->device);
+        if (g->partial && g->partial[i]) hipFree(g->partial[i]);
+        if (g->ev && g->ev[i]) hipEventDestroy(g->ev[i]);
+        s2k_engine_destroy(g->eng[i]);
+    }
+    delete[] g->partial; delete[] g->ev;
+    delete g;
+}
+extern "C" s2k_group* s2k_group_create(const int* devices, int n) {
+    if (!devices || n <= 0 || n > 64) { s2k_fail_arg("s2k_group_create", "illegal argument"); return nullptr; }
+    s2k_group* g = new s2k_group();
+    g->partial = new u32*[n](); g->ev = new hipEvent_t[n]();
+    for (int i = 0; i < n; i++) {
+        s2k_engine* e = s2k_engine_create(devices[i]);
+        if (!e) { s2k_group_destroy(g); return nullptr; }
+        g->eng.push_back(e);
+        if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc((void**)&g->partial[i], 28 * sizeof(u32)) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) { s2k_fail("s2k_group_create", "device allocation failed"); (void)hipGetLastError(); s2k_group_destroy(g); return nullptr; }
+    }
+    if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc((void**)&g->gather, (size_t)n * 28 * sizeof(u32)) != hipSuccess ||
+        hipMalloc((void**)&g->res_xy, 64) != hipSuccess || hipMalloc((void**)&g->res_inf, 16) != hipSuccess) { s2k_fail("s2k_group_create", "device allocation failed"); (void)hipGetLastError(); s2k_group_destroy(g); return nullptr; }
+    // devices that can reach each other directly (xGMI) are made peers, so that the 112-byte partials do not bounce through the host
+    for (int i = 1; i < n; i++) {
+        int can = 0;
+        if (devices[i] != devices[0] && hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+            if (hipSetDevice(devices[i]) == hipSuccess) { const hipError_t er = hipDeviceEnablePeerAccess(devices[0], 0); if (er != hipSuccess) (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
+    try {
+        for (int i = 0; i < n; i++) { auto* w = new s2k_group::worker(); g->wk.push_back(w); w->th = std::thread(group_worker_main, w, devices[i]); }
+    } catch (...) { s2k_fail("s2k_group_create", "cannot start worker threads"); s2k_group_destroy(g); return nullptr; }
+    return g;
+}
+extern "C" int s2k_group_size(const s2k_group* g) { return g ? (int)g->eng.size() : 0; }
+extern "C" s2k_engine* s2k_group_engine(s2k_group* g, int i) { return (g && i >= 0 && (size_t)i < g->eng.size()) ? g->eng[i] : nullptr; }
+// share i of n items over k engines: [lo, hi)
+static inline void group_share(size_t n, size_t k, size_t i, size_t& lo, size_t& hi) { lo = n * i / k; hi = n * (i + 1) / k; }
+
+extern "C" int secp256k1_rangeproof_verify_batch_group(s2k_group* g, int32_t* results, uint64_t* min_value, uint64_t* max_value, const unsigned char* commits33,
+                                                       const unsigned char* proofs, const uint64_t* proof_off, const unsigned char* extra, const uint64_t* extra_off,
+                                                       const unsigned char* gens64, size_t n) {
+    const char* who = "secp256k1_rangeproof_verify_batch_group";
+    if (!g || g->eng.empty()) return s2k_fail(who, "null group");
+    if (n == 0) return 1;
+    if (!results || !min_value || !max_value || !commits33 || !proofs || !proof_off || !gens64) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::mutex> call(g->call_mu);
+    memset(results, 0, sizeof(int32_t) * n);
+    const size_t k = g->eng.size();
+    std::vector<std::function<int()>> jobs(k);
+    for (size_t i = 0; i < k; i++) {
+        size_t lo, hi; group_share(n, k, i, lo, hi);
+        s2k_engine* e = g->eng[i];
+        jobs[i] = [=]() -> int {
+            if (hi == lo) return 1;
+            const size_t m = hi - lo;
+            std::vector<uint64_t> po(m + 1), eo;
+            for (size_t t = 0; t <= m; t++) po[t] = proof_off[lo + t] - proof_off[lo];
+            const int has_extra = extra && extra_off;
+            if (has_extra) { eo.resize(m + 1); for (size_t t = 0; t <= m; t++) eo[t] = extra_off[lo + t] - extra_off[lo]; }
+            return secp256k1_rangeproof_verify_batch(e, results + lo, min_value + lo, max_value + lo, commits33 + 33 * lo, proofs + proof_off[lo], po.data(),
+                                                     has_extra ? extra + extra_off[lo] : nullptr, has_extra ? eo.data() : nullptr, gens64 + 64 * lo, m);
+        };
+    }
+    const int ok = group_run(g, jobs);
+    if (!ok) memset(results, 0, sizeof(int32_t) * n);                  // an engine failure never leaves part of a batch marked valid
+    return ok;
+}
+extern "C" int secp256k1_rangeproof_verify_batch_ptrs_group(s2k_group* g, int32_t* results, uint64_t* min_value, uint64_t* max_value, const void* const* commit_objs,
+                                                            const unsigned char* const* proofs, const size_t* plens, const unsigned char* const* extra, const size_t* elens,
+                                                            const void* const* gen_objs, size_t n) {
+    const char* who = "secp256k1_rangeproof_verify_batch_ptrs_group";
+    if (!g || g->eng.empty()) return s2k_fail(who, "null group");
+    if (n == 0) return 1;
+    if (!rp_ptrs_check(who, results, min_value, max_value, commit_objs, proofs, plens, extra, elens, gen_objs, n)) return 0;
+    std::lock_guard<std::mutex> call(g->call_mu);
+    memset(results, 0, sizeof(int32_t) * n);
+    const size_t k = g->eng.size();
+    std::vector<std::function<int()>> jobs(k);
+    for (size_t i = 0; i < k; i++) {
+        size_t lo, hi; group_share(n, k, i, lo, hi);
+        s2k_engine* e = g->eng[i];
+        jobs[i] = [=]() -> int {
+            if (hi == lo) return 1;
+            return secp256k1_rangeproof_verify_batch_ptrs(e, results + lo, min_value + lo, max_value + lo, commit_objs + lo, proofs + lo, plens + lo, extra ? extra + lo : nullptr,
+                                                          extra ? elens + lo : nullptr, gen_objs + lo, hi - lo);
+        };
+    }
+    const int ok = group_run(g, jobs);
+    if (!ok) memset(results, 0, sizeof(int32_t) * n);
+    return ok;
+}
+extern "C" int secp256k1_schnorrsig_verify_batch_group(s2k_group* g, int32_t* results, const unsigned char* sigs, const unsigned char* msgs, size_t msglen,
+                                                       const unsigned char* pubkeys, int pk_format, size_t n) {
+    const char* who = "secp256k1_schnorrsig_verify_batch_group";
+    if (!g || g->eng.empty()) return s2k_fail(who, "null group");
+    if (n == 0) return 1;
+    if (!results || !sigs || (!msgs && msglen) || !pubkeys) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::mutex> call(g->call_mu);
+    memset(results, 0, sizeof(int32_t) * n);
+    const size_t k = g->eng.size(), pkb = pk_format ? 64 : 32;
+    std::vector<std::function<int()>> jobs(k);
+    for (size_t i = 0; i < k; i++) {
+        size_t lo, hi; group_share(n, k, i, lo, hi);
+        s2k_engine* e = g->eng[i];
+        jobs[i] = [=]() -> int {
+            if (hi == lo) return 1;
+            return secp256k1_schnorrsig_verify_batch(e, results + lo, sigs + 64 * lo, msgs ? msgs + msglen * lo : nullptr, msglen, pubkeys + pkb * lo, pk_format, hi - lo);
+        };
+    }
+    const int ok = group_run(g, jobs);
+    if (!ok) memset(results, 0, sizeof(int32_t) * n);
+    return ok;
+}
+// One sum over the group.  Per engine i: its slice's scalars / points (device memory of engine i's GPU when `resident`, host memory
+// otherwise); the generator term goes with slice 0.  The result comes back to the host (r_xy 64 bytes, *r_inf).
+static int group_msm(s2k_group* g, const char* who, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc, const unsigned char* const* sc,
+                     const unsigned char* const* pt, const unsigned char* const* pt_inf, const size_t* cnt, int resident) {
+    const size_t k = g->eng.size();
+    std::lock_guard<std::mutex> call(g->call_mu);
+    std::vector<std::function<int()>> jobs(k);
+    const int dev0 = g->eng[0]->device;
+    for (size_t i = 0; i < k; i++) {
+        s2k_engine* e = g->eng[i];
+        u32* part = g->partial[i]; u32* dst = g->gather + 28 * i; hipEvent_t ev = g->ev[i];
+        const unsigned char* sci = sc[i]; const unsigned char* pti = pt[i]; const unsigned char* infi = pt_inf ? pt_inf[i] : nullptr; const size_t m = cnt[i];
+        const unsigned char* gs = i == 0 ? g_sc : nullptr;
+        jobs[i] = [=]() -> int {
+            std::lock_guard<std::recursive_mutex> lock(e->mu);
+            HIPCHK(hipSetDevice(e->device));
+            hipStream_t st = e->stream;
+            const unsigned char *d_sc = sci, *d_pt = pti, *d_inf = infi, *d_g = gs;
+            if (!resident) {
+                // slice to HBM: behind the MSM's own workspace need (s2k_ecmult_multi_partial_dev carves from the start)
+                const size_t nt = m + (gs ? 1 : 0);
+                const size_t base = ws_need({28 * 4}) + msm_ws_bytes(nt + 1, msm_make_plan(nt ? nt : 1));
+                if (!engine_workspace(e, base + ws_need({32 * m + 64, 64 * m + 64, m + 64, 64}))) return 0;
+                ws_carver c{e->ws, base};
+                unsigned char* a = c.take<unsigned char>(32 * m + 64); unsigned char* b = c.take<unsigned char>(64 * m + 64); unsigned char* ci = c.take<unsigned char>(m + 64);
+                unsigned char* dg = c.take<unsigned char>(64);
+                stream_guard sg(e, st);
+                if (m) { HIPCHK(hipMemcpyAsync(a, sci, 32 * m, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(b, pti, 64 * m, hipMemcpyHostToDevice, st)); }
+                if (m && infi) HIPCHK(hipMemcpyAsync(ci, infi, m, hipMemcpyHostToDevice, st));
+                if (gs) HIPCHK(hipMemcpyAsync(dg, gs, 32, hipMemcpyHostToDevice, st));
+                d_sc = a; d_pt = b; d_inf = infi ? ci : nullptr; d_g = gs ? dg : nullptr;
+            }
+            if (!s2k_ecmult_multi_partial_dev(e, nullptr, part, d_g, d_sc, d_pt, d_inf, m)) return 0;
+            HIPCHK(hipMemcpyPeerAsync(dst, dev0, part, e->device, 28 * sizeof(u32), st));
+            HIPCHK(hipEventRecord(ev, st));
+            return 1;
+        };
+    }
+    if (!group_run(g, jobs)) return 0;
+    (void)who;
+    s2k_engine* e0 = g->eng[0];
+    std::lock_guard<std::recursive_mutex> lock(e0->mu);
+    HIPCHK(hipSetDevice(e0->device));
+    for (size_t i = 0; i < k; i++) HIPCHK(hipStreamWaitEvent(e0->stream, g->ev[i], 0));
+    if (!s2k_gej_sum_dev(e0, nullptr, g->res_xy, g->res_inf, g->gather, k)) return 0;
+    HIPCHK(hipMemcpyAsync(r_xy, g->res_xy, 64, hipMemcpyDeviceToHost, e0->stream));
+    HIPCHK(hipMemcpyAsync(r_inf, g->res_inf, 4, hipMemcpyDeviceToHost, e0->stream));
+    HIPCHK(hipStreamSynchronize(e0->stream));
+    return 1;
+}
+extern "C" int s2k_ecmult_multi_group(s2k_group* g, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc, const unsigned char* sc,
+                                      const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    const char* who = "s2k_ecmult_multi_group";
+    if (!g || g->eng.empty()) return s2k_fail(who, "null group");
+    if (!r_xy || !r_inf || (n && (!sc || !pt_xy))) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    const size_t k = g->eng.size();
+    std::vector<const unsigned char*> a(k), b(k), c(k); std::vector<size_t> cnt(k);
+    for (size_t i = 0; i < k; i++) { size_t lo, hi; group_share(n, k, i, lo, hi); a[i] = sc + 32 * lo; b[i] = pt_xy + 64 * lo; c[i] = pt_inf ? pt_inf + lo : nullptr; cnt[i] = hi - lo; }
+    return group_msm(g, who, r_xy, r_inf, g_sc, a.data(), b.data(), pt_inf ? c.data() : nullptr, cnt.data(), 0);
+}
+extern "C" int s2k_ecmult_multi_group_dev(s2k_group* g, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc_dev0, const unsigned char* const* sc_dev,
+                                          const unsigned char* const* pt_xy_dev, const unsigned char* const* pt_inf_dev, const size_t* n_per_engine) {
+    const char* who = "s2k_ecmult_multi_group_dev";
+    if (!g || g->eng.empty()) return s2k_fail(who, "null group");
+    if (!r_xy || !r_inf || !sc_dev || !pt_xy_dev || !n_per_engine) return s2k_fail_arg(who, "illegal argument (ARG_CHECK)");
+    return group_msm(g, who, r_xy, r_inf, g_sc_dev0, sc_dev, pt_xy_dev, pt_inf_dev, n_per_engine, 1);
 }

@@ -130,7 +130,7 @@ def test_junk_proofs_cannot_buy_a_table(eng2, ref):
     _same(eng2, ref, c, p, g)
     assert eng2.generator_cached(GENERATOR_H)
     junk_gen = rng.integers(0, 256, 64, dtype=np.uint8)
-    jc = rng.integers(0, 256, (64, 33), dtype=np.uint8); jc[:, 0] = 8
+    jc = np.tile(c, (16, 1))                                         # (commitments must parse: the reference's API only ever sees parsed objects)
     jp = [bytes([0x40, 1]) + bytes(rng.integers(0, 256, 160, dtype=np.uint8)) for _ in range(64)]      # parses as a 1-ring proof, cannot verify
     for _ in range(3):
         res = _same(eng2, ref, jc, jp, np.tile(junk_gen, (64, 1)))
