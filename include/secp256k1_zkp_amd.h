@@ -51,7 +51,10 @@ S2K_API void s2k_clear_status(void);
  *   that stage still waits for everything queued on the caller's stream before the call, because the inputs may be produced there.
  *   Setting the option to 1 is the caller's promise that the input arrays of a `_dev` call are complete when the call is made (and
  *   stay untouched until its results are consumed); min_value/max_value may then be written before the stream reaches the call.
- *   Results are unaffected; host-buffer entry points ignore the option.
+ *   Results are unaffected; host-buffer entry points ignore the option.  The same promise lets s2k_ecmult_multi_dev and
+ *   s2k_ecmult_multi_partial_dev keep TWO calls in flight for small sums (up to 2^13 terms, where one call is a chain of latency-bound
+ *   launches): calls alternate between two internal stream / workspace sets and the caller's stream only waits for each call's result
+ *   (give calls that may overlap different output buffers).  Larger sums fill the machine by themselves and run one after the other.
  * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results).
  * S2K_OPT_GEN_CACHE_SLOTS (default 2, 0..8; $S2K_GEN_CACHE): how many rangeproof generators may have a fixed-base table at a time
  *   (11.8 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.

@@ -46,7 +46,7 @@ static int secp256k1_amd_layout_ok(void) {
     return sizeof(secp256k1_ge_storage) == 64 && sizeof(((secp256k1_xonly_pubkey*)0)->data) == 64 && *(const unsigned char*)&one == 1;
 }
 
-void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend) {
+SECP256K1_AMD_API void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend) {
     const secp256k1_amd_backend *cur = SECP256K1_AMD_LOAD_BE();
     secp256k1_amd_backend *next = (cur == &secp256k1_amd_slots[0]) ? &secp256k1_amd_slots[1] : &secp256k1_amd_slots[0];
     if (backend == NULL) memset(next, 0, sizeof(*next));
@@ -56,11 +56,11 @@ void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend) {
     }
     SECP256K1_AMD_STORE_BE(next);
 }
-void secp256k1_amd_stats(size_t *served, size_t *fell_back) {
+SECP256K1_AMD_API void secp256k1_amd_stats(size_t *served, size_t *fell_back) {
     if (served != NULL) *served = SECP256K1_AMD_READ(secp256k1_amd_served);
     if (fell_back != NULL) *fell_back = SECP256K1_AMD_READ(secp256k1_amd_fell_back);
 }
-void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n; }
+SECP256K1_AMD_API void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n; }
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Batch form of secp256k1_rangeproof_verify (reference include/secp256k1_rangeproof.h:70-80).
@@ -75,7 +75,7 @@ void secp256k1_amd_set_msm_min_terms(size_t n) { secp256k1_amd_msm_min_terms = n
 #if INT_MAX != 0x7fffffff
 #error "the asynchronous adapters hand `int *results` to the engine as int32_t"
 #endif
-int secp256k1_amd_rangeproof_verify_batch_submit(const secp256k1_context *ctx, uint64_t *ticket, int *results, uint64_t *min_value, uint64_t *max_value,
+SECP256K1_AMD_API int secp256k1_amd_rangeproof_verify_batch_submit(const secp256k1_context *ctx, uint64_t *ticket, int *results, uint64_t *min_value, uint64_t *max_value,
         const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
         const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
@@ -110,14 +110,14 @@ int secp256k1_amd_rangeproof_verify_batch_submit(const secp256k1_context *ctx, u
     }
     return 1;
 }
-int secp256k1_amd_rangeproof_verify_batch_wait(const secp256k1_context *ctx, uint64_t ticket) {
+SECP256K1_AMD_API int secp256k1_amd_rangeproof_verify_batch_wait(const secp256k1_context *ctx, uint64_t ticket) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
     VERIFY_CHECK(ctx != NULL);
     if (ticket == 0) return 1;
     ARG_CHECK(be->rangeproof_verify_batch_wait != NULL);
     return be->rangeproof_verify_batch_wait(be->engine, ticket);
 }
-int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *results, uint64_t *min_value, uint64_t *max_value,
+SECP256K1_AMD_API int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *results, uint64_t *min_value, uint64_t *max_value,
         const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
         const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
@@ -200,7 +200,7 @@ int secp256k1_amd_rangeproof_verify_batch(const secp256k1_context *ctx, int *res
  * writes (outlen[i] in: capacity of message_out[i], out: bytes recovered).  For results[i] == 0 the reference leaves its
  * outputs unspecified; this form zeroes blind_out / value_out and sets outlen[i] = 0 on both paths.
  * --------------------------------------------------------------------------------------------------------------- */
-int secp256k1_amd_rangeproof_rewind_batch(const secp256k1_context *ctx, int *results, unsigned char *blind_out, uint64_t *value_out,
+SECP256K1_AMD_API int secp256k1_amd_rangeproof_rewind_batch(const secp256k1_context *ctx, int *results, unsigned char *blind_out, uint64_t *value_out,
         unsigned char *const *message_out, size_t *outlen, const unsigned char *const *nonces, uint64_t *min_value, uint64_t *max_value,
         const secp256k1_pedersen_commitment *const *commits, const unsigned char *const *proofs, const size_t *plens,
         const unsigned char *const *extra_commits, const size_t *extra_commit_lens, const secp256k1_generator *const *gens, size_t n) {
@@ -458,7 +458,7 @@ static int secp256k1_amd_bppp_norm_product_verify_batch(const secp256k1_context 
  * Batch form of secp256k1_schnorrsig_verify (reference include/secp256k1_schnorrsig.h:178); all messages msglen long.
  * --------------------------------------------------------------------------------------------------------------- */
 #ifdef ENABLE_MODULE_SCHNORRSIG
-int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *results, const unsigned char *const *sigs64,
+SECP256K1_AMD_API int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *results, const unsigned char *const *sigs64,
         const unsigned char *const *msgs, size_t msglen, const secp256k1_xonly_pubkey *const *pubkeys, size_t n) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
     size_t i;
@@ -501,7 +501,7 @@ int secp256k1_amd_schnorrsig_verify_batch(const secp256k1_context *ctx, int *res
  * Returns the verdict; an engine that cannot give one leaves the call to the CPU.
  * --------------------------------------------------------------------------------------------------------------- */
 #ifdef ENABLE_MODULE_SCHNORRSIG_HALFAGG
-int secp256k1_amd_schnorrsig_aggverify(const secp256k1_context *ctx, const secp256k1_xonly_pubkey *pubkeys, const unsigned char *msgs32, size_t n,
+SECP256K1_AMD_API int secp256k1_amd_schnorrsig_aggverify(const secp256k1_context *ctx, const secp256k1_xonly_pubkey *pubkeys, const unsigned char *msgs32, size_t n,
         const unsigned char *aggsig, size_t aggsig_len) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
     VERIFY_CHECK(ctx != NULL);
@@ -525,7 +525,7 @@ int secp256k1_amd_schnorrsig_aggverify(const secp256k1_context *ctx, const secp2
  * Item i: proofs[i], input_tags[i][0 .. n_input_tags[i]), output_tags[i].
  * --------------------------------------------------------------------------------------------------------------- */
 #ifdef ENABLE_MODULE_SURJECTIONPROOF
-int secp256k1_amd_surjectionproof_verify_batch(const secp256k1_context *ctx, int *results, const secp256k1_surjectionproof *const *proofs,
+SECP256K1_AMD_API int secp256k1_amd_surjectionproof_verify_batch(const secp256k1_context *ctx, int *results, const secp256k1_surjectionproof *const *proofs,
         const secp256k1_generator *const *input_tags, const size_t *n_input_tags, const secp256k1_generator *const *output_tags, size_t n) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();
     size_t i;
@@ -580,7 +580,7 @@ int secp256k1_amd_surjectionproof_verify_batch(const secp256k1_context *ctx, int
  * sum(pos[t][0..pcnt[t])) - sum(neg[t][0..ncnt[t])) == 0.
  * --------------------------------------------------------------------------------------------------------------- */
 #ifdef ENABLE_MODULE_GENERATOR
-int secp256k1_amd_pedersen_verify_tally_batch(const secp256k1_context *ctx, int *results,
+SECP256K1_AMD_API int secp256k1_amd_pedersen_verify_tally_batch(const secp256k1_context *ctx, int *results,
         const secp256k1_pedersen_commitment *const *const *pos, const size_t *pcnt,
         const secp256k1_pedersen_commitment *const *const *neg, const size_t *ncnt, size_t n_tallies) {
     const secp256k1_amd_backend *be = SECP256K1_AMD_LOAD_BE();

@@ -35,6 +35,15 @@
 extern "C" {
 #endif
 
+/* exported like the library's own API (the library is built with hidden visibility: include/secp256k1.h defines SECP256K1_API) */
+#ifndef SECP256K1_AMD_API
+# ifdef SECP256K1_API
+#  define SECP256K1_AMD_API SECP256K1_API
+# else
+#  define SECP256K1_AMD_API
+# endif
+#endif
+
 /* ABI of the engine entry points (include/secp256k1_zkp_amd.h); `engine` is the s2k_engine*. */
 typedef int (*secp256k1_amd_rangeproof_verify_batch_fn)(void *engine, int32_t *results, uint64_t *min_value, uint64_t *max_value,
         const unsigned char *commits33, const unsigned char *proofs, const uint64_t *proof_off,
@@ -91,12 +100,12 @@ typedef struct secp256k1_amd_backend {
  * secp256k1_context_set_sha256_compression; two installs must be a verification's duration apart (two table slots).
  * Thread safety of the engine behind the table: one s2k_engine serialises its callers (a mutex per engine; their launches share its stream
  * and scratch), so concurrent verifier threads are safe and take turns; give every thread its own engine for parallel submission. */
-void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend);
+SECP256K1_AMD_API void secp256k1_amd_set_backend(const secp256k1_amd_backend *backend);
 /* secp256k1_ecmult_multi_var calls with fewer terms than this stay on the CPU (default 256: an engine round trip costs ~0.45-0.6 ms whatever
  * the size, the CPU ~3-6 us per term); 0 sends everything to the engine. */
-void secp256k1_amd_set_msm_min_terms(size_t n);
+SECP256K1_AMD_API void secp256k1_amd_set_msm_min_terms(size_t n);
 /* Counters for tests / monitoring: batches served by the backend, batches that fell back to the CPU after a backend failure. */
-void secp256k1_amd_stats(size_t *served, size_t *fell_back);
+SECP256K1_AMD_API void secp256k1_amd_stats(size_t *served, size_t *fell_back);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,13 @@ struct s2k_engine {
     std::condition_variable_any stage_cv;                 // a staging set was handed back (synchronous callers queue for one)
     hipStream_t stream_copy;
     int stage_threads;
+    // Two MSM calls in flight (s2k_ecmult_multi_dev / _partial_dev with S2K_OPT_RP_INPUTS_READY): each slot has its own streams, events and
+    // workspace, calls alternate between the slots, and the caller's stream only waits for a call's result -- the latency-bound tail of
+    // call k (Horner, tree sums, bucket weights: ~25 small launches during which most CUs idle) runs underneath the binning and
+    // partial-sum rounds of call k+1.
+    struct msm_slot { hipStream_t s, s2; hipEvent_t fork, join, done, in; unsigned char* ws; size_t ws_bytes; } msm_slot[2];
+    unsigned msm_seq;
+    int cur_pipe, prev_pipe;   // the current / the previous entry-point call was a pipelined MSM (stream_guard, msm_pipelined)
     u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
     std::recursive_mutex mu;
 };
@@ -124,6 +131,7 @@ struct s2k_engine {
 struct stream_guard {
     s2k_engine* e; hipStream_t st;
     stream_guard(s2k_engine* e_, hipStream_t st_) : e(e_), st(st_) {
+        e->prev_pipe = e->cur_pipe; e->cur_pipe = 0;
         if (e->last_stream_valid && e->last_stream != st) { if (hipStreamWaitEvent(st, e->ev_last, 0) != hipSuccess) (void)hipGetLastError(); }
     }
     ~stream_guard() {
@@ -489,6 +497,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     e->rp_last_plan[0] = e->rp_last_plan[1] = nullptr;
     e->ha_pin = nullptr; e->ha_pin_words = 0;
+    for (int i = 0; i < 2; i++) { auto& m = e->msm_slot[i]; m.s = m.s2 = nullptr; m.fork = m.join = m.done = m.in = nullptr; m.ws = nullptr; m.ws_bytes = 0; }
+    e->msm_seq = 0; e->cur_pipe = e->prev_pipe = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
@@ -521,6 +531,12 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_join, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        auto& m = e->msm_slot[i];
+        S2K_CREATE_CHK(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking)); S2K_CREATE_CHK(hipStreamCreateWithFlags(&m.s2, hipStreamNonBlocking));
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming)); S2K_CREATE_CHK(hipEventCreateWithFlags(&m.join, hipEventDisableTiming));
+        S2K_CREATE_CHK(hipEventCreateWithFlags(&m.done, hipEventDisableTiming)); S2K_CREATE_CHK(hipEventCreateWithFlags(&m.in, hipEventDisableTiming));
+    }
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_copy, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) { S2K_CREATE_CHK(hipEventCreateWithFlags(&e->stage[i].ev_h2d, hipEventDisableTiming)); S2K_CREATE_CHK(hipEventCreateWithFlags(&e->stage[i].ev_out, hipEventDisableTiming)); }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_rp_in, hipEventDisableTiming));
@@ -554,6 +570,12 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (e->bp_tab) hipFree(e->bp_tab);
     if (e->host_flags) hipHostFree(e->host_flags);
     if (e->ha_pin) hipHostFree(e->ha_pin);
+    for (int i = 0; i < 2; i++) {
+        auto& m = e->msm_slot[i];
+        if (m.ws) hipFree(m.ws);
+        if (m.fork) hipEventDestroy(m.fork); if (m.join) hipEventDestroy(m.join); if (m.done) hipEventDestroy(m.done); if (m.in) hipEventDestroy(m.in);
+        if (m.s) hipStreamDestroy(m.s); if (m.s2) hipStreamDestroy(m.s2);
+    }
     for (int i = 0; i < 2; i++) {
         auto& S = e->stage[i];
         if (S.in) hipHostFree(S.in);
@@ -2167,8 +2189,13 @@ static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const
 // result instead.  (part, parts): the share of the digit windows this launch owns (msm_plan_share) -- (0, 1) = all of them.
 __global__ void k_set_word(u32* p, u32 v) { *p = v; }
 __global__ void k_msm_flag_copy(u32* persist, const u32* flags) { persist[0] = flags[0]; }
+// side: where the gated exact path runs (with its fork / join events); arena: which MSM_DIRECT_LANES-sized region of the engine's table
+// arena its lanes use (0: the engine's own calls; 1, 2: the two pipelined slots)
+struct msm_ctx { hipStream_t side; hipEvent_t fork, join; unsigned arena; };
 static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
-                      const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1) {
+                      const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1, const msm_ctx* ctx = nullptr) {
+    const msm_ctx dflt{e->stream2, e->ev_msm_fork, e->ev_msm_join, 0u};
+    const msm_ctx& X = ctx ? *ctx : dflt;
     const size_t nt = n + (g_sc ? 1 : 0);
     if (parts == 0 || part >= parts) return s2k_fail_arg("s2k_ecmult_multi", "window share out of range");
     ENGINE_GTAB(e, st);                                        // (the bucket-free exact path multiplies by G through the table)
@@ -2191,9 +2218,10 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     }
     if (nt < MSM_SMALL_N) {
         const unsigned dl = (unsigned)(((nt + 255) / 256) * 256);
-        if (!engine_ptab(e, dl)) return 0;
+        if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
         HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_msm_direct, dim3(dl / 256), dim3(256), 0, st, lanes, (const u32*)nullptr, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
+        hipLaunchKernelGGL(k_msm_direct, dim3(dl / 256), dim3(256), 0, st, lanes, (const u32*)nullptr, g_sc, sc, pt, pt_inf, e->gtab,
+                           e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS, n, nt, pl);
         HIPCHK(hipEventRecord(e->ev[3], st));
         const u32* r = launch_gej_reduce(st, lanes, dbufA, dbufB, 1, dl);
         HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
@@ -2201,7 +2229,8 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
         HIPCHK(hipGetLastError());
         return 1;
     }
-    if (!engine_ptab(e, MSM_DIRECT_LANES)) return 0;
+    if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
+    u32* const direct_ptab = e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS;
     const u32 nk = pl.wn * pl.nb;
     const size_t E = nt * 2 * pl.wn;                           // upper bound on this share's bucket references
     const msm_layout L = msm_make_layout(nt, pl);
@@ -2237,17 +2266,17 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
     // exact path, un-gated only by the overflow flag the binning pass may have raised: on the side stream, so that its (normally
     // empty) launches do not sit behind the Horner tail of every call
-    HIPCHK(hipEventRecord(e->ev_msm_fork, st));
-    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_msm_fork, 0));
-    hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, e->stream2, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, e->ptab, n, nt, pl);
-    const u32* ex = launch_gej_reduce(e->stream2, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
-    HIPCHK(hipEventRecord(e->ev_msm_join, e->stream2));
+    HIPCHK(hipEventRecord(X.fork, st));
+    HIPCHK(hipStreamWaitEvent(X.side, X.fork, 0));
+    hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, X.side, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, direct_ptab, n, nt, pl);
+    const u32* ex = launch_gej_reduce(X.side, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
+    HIPCHK(hipEventRecord(X.join, X.side));
     if (msm_max_cap(full, L) <= MSM_ONE_ROUND_CAP && !getenv("S2K_MSM_NO_SMALL")) {
         const u32 nchunks = (pl.nb - 1 + 255) / 256;
         hipLaunchKernelGGL(k_msm_small_windows, dim3(nchunks, pl.wn), dim3(256), 0, st, partA, refs_cap, gcnt, term, pl, L, nchunks);
         const u32* wsum = launch_gej_reduce(st, partA, bufA, bufB, pl.wn, nchunks);
         hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
-        HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
+        HIPCHK(hipStreamWaitEvent(st, X.join, 0));
         hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
         HIPCHK(hipGetLastError());
         return 1;
@@ -2276,9 +2305,48 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl, L);
     const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
-    HIPCHK(hipStreamWaitEvent(st, e->ev_msm_join, 0));
+    HIPCHK(hipStreamWaitEvent(st, X.join, 0));
     hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
     HIPCHK(hipGetLastError());
+    return 1;
+}
+// Two calls in flight (see s2k_engine::msm_slot): used when the caller has promised that its input arrays are complete at call time
+// (S2K_OPT_RP_INPUTS_READY) and the sum is SMALL (<= 2^13 terms): there a call is a chain of latency-bound launches that leaves most of
+// the machine idle, and two chains side by side finish in little more than the time of one (measured, 1 024 terms: 0.49 -> 0.35 ms per
+// call; profiles/r04e_msm_bare*.txt).  From ~2^14 terms on the partial-sum rounds fill the SIMDs, the other call's tail kernels only take
+// issue slots from them, and two calls in flight are SLOWER than one after the other (2^20 terms: 2.31 against 2.04 ms) -- those sizes keep
+// the plain path.  `finish`: 0 = the Jacobian partial to
+// out28, 1 = affine result to r_xy / r_inf.  Everything runs on the slot's streams; the caller's stream waits for the result.
+#define MSM_PIPE_MAX_TERMS (size_t(1) << 13)
+static int msm_pipelined(s2k_engine* e, hipStream_t st, int finish, uint32_t* out28, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
+                         const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    const size_t nt = n + (g_sc ? 1 : 0);
+    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    const size_t need = msm_ws_bytes(nt + 1, pl);
+    const unsigned si = e->msm_seq++ & 1u;
+    auto& S = e->msm_slot[si];
+    if (need > S.ws_bytes) {
+        HIPCHK(hipStreamSynchronize(S.s)); HIPCHK(hipStreamSynchronize(S.s2));
+        if (S.ws) HIPCHK(hipFree(S.ws));
+        S.ws = nullptr; S.ws_bytes = 0;
+        const size_t bytes = (need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+        HIPCHK(hipMalloc((void**)&S.ws, bytes));
+        S.ws_bytes = bytes;
+    }
+    // the slot's streams are not the caller's: work of an earlier call of another kind (it may share the engine's table arena with this
+    // call's exact path) must be over first; consecutive pipelined MSM calls do not wait for each other -- that is the point
+    if (!e->prev_pipe && e->last_stream_valid) HIPCHK(hipStreamWaitEvent(S.s, e->ev_last, 0));
+    e->cur_pipe = 1;
+    const msm_ctx ctx{S.s2, S.fork, S.join, 1u + si};
+    ws_carver c{S.ws, 0}; u32* res = nullptr;
+    HIPCHK(hipEventRecord(e->ev[0], S.s));
+    if (!msm_launch(e, S.s, c, &res, g_sc, sc, pt_xy, pt_inf, n, 0, 1, &ctx)) return 0;
+    if (finish) hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, S.s, r_xy, r_inf, res);
+    else HIPCHK(hipMemcpyAsync(out28, res, 28 * 4, hipMemcpyDeviceToDevice, S.s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], S.s));
+    HIPCHK(hipEventRecord(S.done, S.s));
+    HIPCHK(hipStreamWaitEvent(st, S.done, 0));               // the result is stream-ordered for the caller
     return 1;
 }
 extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
@@ -2289,6 +2357,7 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
+    if (e->rp_inputs_ready && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
     const msm_plan pl = msm_make_plan(nt ? nt : 1);
     if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;
@@ -2323,6 +2392,7 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
+    if (e->rp_inputs_ready && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
     const msm_plan pl = msm_make_plan(nt ? nt : 1);
     if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;

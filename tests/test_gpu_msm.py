@@ -11,16 +11,33 @@ from tests.refapi import G_XY, N, P
 pytestmark = pytest.mark.gpu
 
 
+_POOL = {}
+
+
 def _points(engine, rng, n):
-    """n pseudo-random curve points k_i*G, produced by the engine's own (separately verified) batch multiplication."""
-    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-    g = np.frombuffer(G_XY * n, np.uint8).reshape(n, 64)
-    pts, inf = engine.ecmult_batch(g, np.zeros((n, 32), np.uint8), k)
+    """n pseudo-random curve points.  Up to 2^18 they come from a pool of k_i*G made by the REFERENCE's secp256k1_ecmult (oracle/_ref, once per
+    session, a different random slice per call), so that the engine is never checked on points it produced itself; beyond that (the
+    2^20-term test) the engine's own, separately verified, batch multiplication fills up."""
+    if "pts" not in _POOL:
+        from tests.refapi import Ref
+        prng = np.random.default_rng(424242)
+        m = 1 << 18
+        k = prng.integers(0, 256, (m, 32), dtype=np.uint8)
+        pts, inf = Ref().ecmult_batch(np.frombuffer(G_XY * m, np.uint8).reshape(m, 64), k)
+        assert not inf.any()
+        _POOL["pts"] = pts
+    pool = _POOL["pts"]
+    if n <= pool.shape[0]:
+        start = int(rng.integers(0, pool.shape[0] - n + 1))
+        return pool[start:start + n].copy()
+    k = rng.integers(0, 256, (n - pool.shape[0], 32), dtype=np.uint8)
+    g = np.frombuffer(G_XY * k.shape[0], np.uint8).reshape(-1, 64)
+    more, inf = engine.ecmult_batch(g, np.zeros((k.shape[0], 32), np.uint8), k)
     assert not inf.any()
-    return pts
+    return np.concatenate([pool, more])
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 50, 191, 192, 193, 1000, 5000, 8191, 8192, 16384, 40000, 65536, 262144])      # (window width and the fused small-input stage switch at 2^14, 2^16, 2^18 terms)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 50, 191, 192, 193, 1000, 5000, 8191, 8192, 8193, 16383, 16384, 32767, 32768, 40000, 65535, 65536, 131072, 262143, 262144])      # (window width and the fused small-input stage switch at 2^14, 2^16, 2^18 terms)
 def test_msm_sizes(engine, ref, n):
     rng = np.random.default_rng(1000 + n)
     pts = _points(engine, rng, max(n, 1))[:n]
@@ -183,3 +200,58 @@ def test_msm_on_reference_generated_points(engine, ref):
         got, ginf = engine.ecmult_multi(sc, pts, g)
         assert ginf == einf and np.array_equal(got, exp)
     assert not engine.last_msm_fallback()
+
+
+def test_two_calls_in_flight(ref):
+    """S2K_OPT_RP_INPUTS_READY lets s2k_ecmult_multi_dev keep two calls in flight (two stream / workspace sets, the caller's stream waits for
+    each result): a queue of different sums -- sizes around the plan switches, one with a skewed scalar set that takes the exact path --
+    interleaved with calls of another kind gives, output by output, the reference's results."""
+    import torch
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(2024)
+    eng = Engine(0)
+    try:
+        dev = torch.device("cuda", 0)
+        Gpt = np.frombuffer(G_XY, np.uint8)
+        nmax = 70000
+        ks = rng.integers(0, 256, (nmax, 32), dtype=np.uint8)
+        pts, _ = eng.ecmult_batch(np.tile(Gpt, (nmax, 1)), np.zeros((nmax, 32), np.uint8), ng=ks)
+        pts[::5] = np.frombuffer(ref.rand_point(rng), np.uint8)
+        jobs = []
+        for n in (40, 700, 5000, 20000, 33000, 70000, 300, 66000):
+            sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            if n == 33000:
+                sc[:] = sc[0]                                               # one scalar for every term: bucket regions overflow -> exact path
+            jobs.append((n, sc, ref.ecmult_multi(sc, pts[:n])))
+        d_pts = torch.tensor(pts).to(dev)
+        d_sc = [torch.tensor(j[1]).to(dev) for j in jobs]
+        outs = [(torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) for _ in jobs]
+        c, p, g, _ = ref.make_rangeproofs(8, rng, min_bits=16)
+        want_rp = ref.rangeproof_verify_many(c, p, g)
+        torch.cuda.synchronize()
+        eng.set_option(Engine.OPT_RP_INPUTS_READY, 1)
+        for rep in range(2):
+            for i, (n, _, _) in enumerate(jobs):
+                eng.ecmult_multi_dev(outs[i][0], outs[i][1], d_sc[i], d_pts[:n])
+                if i == 3 and rep == 1:
+                    assert np.array_equal(eng.rangeproof_verify_batch(c, p, g)[0], want_rp[0])      # another kind of call in between
+            eng.sync()
+            for i, (n, _, (wxy, winf)) in enumerate(jobs):
+                assert int(outs[i][1].item()) == winf and bytes(outs[i][0].cpu().numpy()) == wxy.tobytes(), (rep, n)
+        eng.set_option(Engine.OPT_RP_INPUTS_READY, 0)
+    finally:
+        eng.close()
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("S2K_TEST_LONG"), reason="2^24 terms through the reference take about a minute of one host core: S2K_TEST_LONG=1")
+def test_2p24_terms_against_ecmult_multi_var(engine, ref):
+    """the largest size bench.py times (c = 16, two-pass binning), against secp256k1_ecmult_multi_var itself rather than the (sum s_i k_i)*G identity"""
+    rng = np.random.default_rng(2424)
+    n = 1 << 24
+    base = _points(engine, rng, 1 << 18)
+    pts = np.tile(base, (n >> 18, 1))                                       # 64 copies of the pool, every copy with its own scalars
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    g = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    exp, einf = ref.ecmult_multi(sc, pts, g, None)
+    got, ginf = engine.ecmult_multi(sc, pts, g, None)
+    assert ginf == einf and np.array_equal(got, exp) and not engine.last_msm_fallback()

@@ -34,10 +34,11 @@ k_rp_rings_shared(rp_ws ws, const unsigned char* __restrict__ proofs, const uint
                           raw0 + (lanes >> 6) * S2K_RRAW_WAVE_WORDS + wave * (S2K_RP_K * RP_PARK_WORDS * 64) + lane, S2K_LANE_DIG(s_dig)};
     const int served = rp_rings_shared<S2K_RP_K>(rec, ws.pub0 + (p * RP_MAX_RINGS + g * S2K_RP_K) * RP_GEJ_WORDS, ws.ring_out + p * RP_RING_OUT_BYTES, ws.ring_ok + p * RP_MAX_RINGS,
                                                  proofs + proof_off[p], g * S2K_RP_K, live, gtab, gc.tab[sl], gc.xmul[sl], M, ev ? ev + p * (RP_MAX_RINGS * 32) : nullptr, dbg);
-    if (!served && live) {                          // (wavefront-uniform verdict) hand this lane's rings to the general form
+    if (served != RP_SHARED_SERVED && live) {       // (wavefront-uniform verdict) hand this lane's rings to the general form
         const u32 r0 = g * S2K_RP_K, cnt = rec.rings - r0 < S2K_RP_K ? rec.rings - r0 : S2K_RP_K;
         const u32 base = atomicAdd(&ws.plan[1], cnt);
         for (u32 i = 0; i < cnt; i++) ws.mapG[base + i] = (u32)p | ((r0 + i) << 20);
+        atomicAdd(&ws.plan[served == RP_SHARED_SUSPECT ? 2 : 3], cnt);      // diagnostics: s2k_engine_rp_handback
     }
 }
 __global__ void __launch_bounds__(256, S2K_RINGS_WAVES)
