@@ -333,6 +333,70 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     return out
 
 
+def measure_group(devices, commits, proofs, gens, ref, steps):
+    """The C-ABI engine group (s2k_group_*, include/secp256k1_zkp_amd.h) over `devices`, from ONE process: (i) replica dispatch -- `len(devices)`
+    times the headline batch handed over in HOST memory, cut into one contiguous range per engine, wall clock of the whole call; (ii) one
+    2^20-term multi-scalar multiplication sharded by terms, slices resident on their GPUs, 112-byte partials gathered on the first device
+    (hipMemcpyPeerAsync) and summed there.  Both checked in-run."""
+    import torch
+    from secp256k1_zkp_amd import Group
+    from tests.refapi import G_XY, N as ORDER
+    k = len(devices)
+    g = Group(devices)
+    out = {"devices": list(devices), "engines": k}
+    try:
+        n = len(proofs)
+        C = np.ascontiguousarray(np.tile(commits, (k, 1))); G = np.ascontiguousarray(np.tile(gens, (k, 1))); P = Group_pack(proofs * k)
+        for e in range(k):
+            g.engine(e).cache_generator(bytes(gens[0]))
+        res, mn, mx = g.rangeproof_verify_batch(C, P, G)                      # warm-up: staging buffers, tables
+        assert res.all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res, mn, mx = g.rangeproof_verify_batch(C, P, G)
+        dt = (time.perf_counter() - t0) / steps
+        assert res.all() and int(mx.min()) == 2**64 - 1
+        out["rangeproof_host_buffers"] = {"proofs_per_call": n * k, "ms_per_call": dt * 1e3, "verifies_per_s": n * k / dt,
+                                          "note": "secp256k1_rangeproof_verify_batch_group: packing into pinned staging, H2D, kernels, D2H on every device concurrently; synchronous calls"}
+        # ---- one 2^20-term sum, term-sharded
+        nm = 1 << 20
+        rng = np.random.default_rng(4242)
+        ks = rng.integers(0, 256, (nm, 32), dtype=np.uint8); sc = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+        e0 = g.engine(0); d0 = torch.device("cuda", devices[0])
+        gp = torch.tensor(np.frombuffer(G_XY, np.uint8).copy()).to(d0).repeat(nm, 1)
+        pts = torch.zeros(nm, 64, dtype=torch.uint8, device=d0); pinf = torch.zeros(nm, dtype=torch.int32, device=d0)
+        torch.cuda.synchronize(d0)
+        e0.ecmult_batch_dev(pts, pinf, gp, torch.zeros(nm, 32, dtype=torch.uint8, device=d0), torch.tensor(ks).to(d0)); e0.sync()
+        cut = [nm * i // k for i in range(k + 1)]
+        pts_h = pts.cpu()
+        scl = [torch.tensor(sc[cut[i]:cut[i + 1]]).to(torch.device("cuda", devices[i])) for i in range(k)]
+        ptl = [pts_h[cut[i]:cut[i + 1]].to(torch.device("cuda", devices[i])) for i in range(k)]
+        for d in set(devices):
+            torch.cuda.synchronize(torch.device("cuda", d))
+        xy, inf = g.ecmult_multi_dev(scl, ptl)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            xy, inf = g.ecmult_multi_dev(scl, ptl)
+        dtm = (time.perf_counter() - t0) / steps
+        tot = sum(int.from_bytes(ks[i].tobytes(), "big") * int.from_bytes(sc[i].tobytes(), "big") for i in range(nm)) % ORDER
+        verified = False
+        if ref is not None:
+            exp_xy, exp_inf = ref.ecmult_batch(np.frombuffer(G_XY, np.uint8), np.zeros(32, np.uint8), ng=np.frombuffer(tot.to_bytes(32, "big"), np.uint8), a_inf=np.ones(1, np.uint8))
+            assert inf == int(exp_inf[0]) and xy.tobytes() == exp_xy[0].tobytes(), "group MSM differs from (sum s_i k_i)*G"
+            verified = True
+        out["msm_2p20_term_sharded"] = {"terms": nm, "ms": dtm * 1e3, "mpoint_scalar_per_s": nm / dtm / 1e6, "verified": verified,
+                                        "frac": 4 * MAC64_PER_MSM_TERM * nm / dtm / (MAD32_PEAK * len(set(devices))),
+                                        "note": "s2k_ecmult_multi_group_dev: host call to host result (one partial per engine, peer copies to the first device, sum there)"}
+    finally:
+        g.close()
+    return out
+
+
+def Group_pack(items):
+    from secp256k1_zkp_amd import Engine
+    return Engine.pack(items)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -438,6 +502,7 @@ def main():
     ap.add_argument("--no-msm-big", action="store_true", help="skip the 2^24-term strong-scaling MSM entry")
     ap.add_argument("--no-distinct", action="store_true", help="skip the second timed loop (every proof its own generator)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
+    ap.add_argument("--no-group", action="store_true", help="skip the single-process C-ABI engine-group block (rank 0 over all the run's GPUs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 1, 2 and 4 (bench_ecmult 1024 pairs, BIP-340 2^16, BP++ norm argument 2^12)")
     args = ap.parse_args()
 
@@ -680,6 +745,23 @@ def main():
         torch.cuda.synchronize(); time.sleep(1.0)
         secondary = measure_secondary(eng, ref, dev, max(3, args.steps), with_cpu=not args.no_cpu_baseline)
 
+    # The C-ABI engine group, from rank 0 alone (the other ranks wait at the barrier below, their GPUs idle): one process drives every GPU of the
+    # run through s2k_group_* -- the path a C caller without torch.distributed takes.  With one GPU: two engines on it (they share the
+    # device's tables), which shows what a second submitting thread buys on a single device.
+    group = None
+    if not args.no_group:
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            ndev = torch.cuda.device_count()
+            devs = list(range(min(world, ndev))) if world > 1 else [local, local]
+            try:
+                group = measure_group(devs, commits, proofs, gens, ref, steps=max(2, min(args.steps, 4)))
+            except Exception as ex:      # noqa: BLE001  (the headline must not be lost to a failure of this extra block)
+                group = {"error": repr(ex)}
+        if world > 1:
+            dist.barrier()
+
     if rank == 0:
         value = world * n * args.steps / dt
         kms = float(np.mean(kern_ms))
@@ -757,6 +839,8 @@ def main():
             out["dropin"] = dropin
         if secondary:
             out["secondary"] = secondary
+        if group:
+            out["group"] = group
         if not args.no_cpu_baseline:
             # (1) the reference's own bench programs (src/bench_rangeproof.c with min_bits = 64, src/bench_ecmult.c; timer of src/bench.h),
             #     one process and one taskset-pinned process per usable core; (2) the same functions through the oracle/_ref shim with
