@@ -54,6 +54,27 @@ def main():
     print("rangeproof: %d items, %d accepted, %d unparseable commitments, mismatches: %d" % (len(P), int(e[0].sum()), int((~parses).sum()), len(bad)), bad[:10])
     for i in bad[:5]:
         print("   item", i, "ref", e[0][i], e[1][i], e[2][i], "gpu", r[0][i], r[1][i], r[2][i], "len", len(P[i]), "hdr", P[i][:11].hex())
+    # ---- crafted rangeproofs (tests/adversarial.py): forgeries with ring keys at infinity, results at infinity, suspect x coordinates -- as
+    #      they are and with the mutations above on top (a flipped bit in a forged proof moves it off the crafted case in every possible way)
+    from tests.adversarial import Crafter
+    from tests.refapi import GENERATOR_H
+    cr = Crafter(ref)
+    gh = np.frombuffer(GENERATOR_H, np.uint8)
+    CC, CP = [], []
+    for t in range(max(4, n // 128)):
+        rings = int(rng.choice([1, 2, 3, 4, 7, 16, 32]))
+        kind = t % 4
+        if kind == 0: c, p = cr.forge_infinity_keys(rng, rings)
+        elif kind == 1: c, p = cr.forge_infinity_keys(rng, rings, neg=True)
+        elif kind == 2: c, p = cr.forge_r_infinity(rng, max(rings, 2), int(rng.integers(0, max(rings, 2) - 1)))
+        else: c, p = cr.sign(rng, min(rings, 4), int(rng.integers(0, 4 ** min(rings, 4))))
+        for k in range(9):
+            CC.append(np.frombuffer(c, np.uint8)); CP.append(p if k == 0 else mutate(p, rng, int(rng.integers(0, 8))))
+    CC = np.stack(CC); CG = np.tile(gh, (len(CP), 1))
+    e = ref.rangeproof_verify_many(CC, CP, CG, threads=16)
+    r = eng.rangeproof_verify_batch(CC, CP, CG)
+    bad = np.nonzero((e[0] != r[0]) | (e[1] != r[1]) | (e[2] != r[2]))[0]
+    print("crafted rangeproofs: %d items, %d accepted, hand-backs %s, mismatches: %d" % (len(CP), int(e[0].sum()), eng.rp_handback()[2:], len(bad)), bad[:10])
     # ---- BIP-340
     sigs, msgs, pks = ref.make_schnorr(4 * n, rng, threads=16)
     for i in range(4 * n):
