@@ -57,7 +57,7 @@ S2K_API void s2k_clear_status(void);
  *   (give calls that may overlap different output buffers).  Larger sums fill the machine by themselves and run one after the other.
  * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results).
  * S2K_OPT_GEN_CACHE_SLOTS (default 2, 0..8; $S2K_GEN_CACHE): how many rangeproof generators may have a fixed-base table at a time
- *   (11.8 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.
+ *   (21.5 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.
  * S2K_OPT_GEN_CACHE_MIN (default 65536; $S2K_GEN_CACHE_MIN): an uncached generator gets a table automatically once this many proofs
  *   carrying it have VERIFIED (the last kernel of a call reports them through a device mailbox that the next call reads: junk proofs
  *   that merely name a generator never cost a table).  At most one automatic table is built per call, and it only takes a free slot

@@ -267,12 +267,15 @@ S2K_HD void bpc_v_scalar(u32 v8[8], const unsigned char* n_vec32, u32 g_len, con
 // k * G through the generator table (gtable.h): S2K_GTAB_WINDOWS additions, no doubling
 S2K_HD void bpc_gmul(gej& out, const u32* gtab, const u32* k8) {
     gej acc; gej_set_infinity(acc);
-    for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
-        const u32 b = w * S2K_GTAB_BITS, word = b >> 5;
-        const u64 pair = (u64)k8[word] | ((u64)(word + 1 < 8 ? k8[word + 1] : 0u) << 32);
-        const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
-        if (v) {
-            ge p; gtab_load(p, gtab, w, v);
+    u32 kr[S2K_GTAB_SWORDS]; gtab_recode(kr, k8);                    // signed fixed-base digits (ecmult.h)
+    for (int w = 0; w < (int)S2K_GTAB_WINDOWS; w++) {
+        const int word = (w * S2K_GTAB_BITS) >> 5;
+        const u32* rec = gtab; int neg = 0;
+        if (gtab_locate(rec, neg, gtab, w, kr[word], word + 1 < S2K_GTAB_SWORDS ? kr[word + 1] : 0u)) {
+            u32 raw[16];
+            for (int i = 0; i < 16; i++) raw[i] = rec[i];
+            ge p; fe_from_words(p.x, raw); fe_from_words(p.y, raw + 8);
+            if (neg) { fe_neg(p.y, p.y, 1); fe_norm_weak(p.y); }
             gej t; const int f = gej_add_ge(t, acc, p); acc = t;
             if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
         }

@@ -12,8 +12,8 @@
 //                    isomorphic-curve / global-Z trick (ecmult_impl.h:73-115, group_impl.h:289-320) -- and parked in a
 //                    per-lane 1152-byte slice of HBM (L2/MALL resident while the lane is alive); operands are gathered one
 //                    addition ahead so the ~1-2 us of latency hides under the previous ~4 us of arithmetic.
-//   generator:       no doublings at all: ng is cut into 11 windows of 24 bits (S2K_GTAB_BITS), each indexing a precomputed
-//                    (window, value) -> affine multiple table (gtable.h, 11.8 GB of the 288 GB of HBM), 11 mixed additions.
+//   generator:       no doublings at all: ng is cut into 10 signed digits of 26 bits (S2K_GTAB_BITS), each indexing a precomputed
+//                    (window, |digit|) -> affine multiple table (gtable.h, 21.5 GB of the 288 GB of HBM), 10 mixed additions.
 //   digits:          both digit streams live in LDS (lane_mem), not in registers.
 //   control:         one loop whose body contains exactly ONE doubling site and ONE mixed-add site, driven by a
 //                    per-lane micro-program counter.  The only data-dependent *arithmetic* case (P + P inside an add)
@@ -26,24 +26,60 @@
 #include "scalar.h"
 
 // ---- generator table ---------------------------------------------------------------------------------
-// gtab[((w << B) + v) * 16 .. +16) = affine (x words[8], y words[8], canonical, least significant word first) of
-// v * 2^(B w) * G ,  v = 1..2^B-1, w = 0..W-1, with B = S2K_GTAB_BITS and W = ceil(256 / B).  One entry = one aligned 64-byte
-// sector, the same record format as the per-lane table below, so that the main loop has a single operand pipeline.
-// B = 24: 11 windows, 11 x 2^24 x 64 B = 11.8 GB of the 288 GB (B = 20: 13 windows, 872 MB, two more additions per
-// multiplication; the host emulation builds B = 12).
+// Fixed-base table of G (and, same layout, of a rangeproof generator): SIGNED digits of D = S2K_GTAB_BITS bits.  A scalar s < 2^256 is
+// cut as  s = sum_w d_w 2^(D w)  with d_w in [-2^(D-1), 2^(D-1)) for every window but the top one (which takes what is left, >= 0):
+// adding the constant K = sum_{w < W-1} 2^(D-1 + D w) once turns that into plain unsigned windows t_w of s' = s + K with d_w = t_w - 2^(D-1)
+// (gtab_recode; s' has up to 257 bits: 9 words), so a window is still read straight off the stored words, with no carry chain.  The
+// table holds v * 2^(D w) * G for v = 1 .. 2^(D-1) only -- a negative digit negates y when the operand is decoded -- i.e. HALF the entries
+// an unsigned window of the same width needs: D = 26 gives W = 10 windows (one addition less per multiplication than the 11 unsigned
+// 24-bit windows of rounds 1-3) in 10 x 2^25 x 64 B = 21.5 GB of the 288 GB; D = 24 would be 11 windows in 5.9 GB.
+// Slot (w, v) = (w << (D-1)) + v: v = 2^(D-1) lands on slot (w+1, 0), which no window ever reads (a zero digit adds nothing).
+// One entry = one aligned 64-byte sector of canonical words (x[8], y[8], least significant first), the same record format as the
+// per-lane tables below, so that the main loops have a single operand pipeline.  (The host emulation builds D = 12.)
 #ifndef S2K_GTAB_BITS
-#define S2K_GTAB_BITS 24
+#define S2K_GTAB_BITS 26
 #endif
+#define S2K_GTAB_HALF (1u << (S2K_GTAB_BITS - 1))
 #define S2K_GTAB_WINDOWS ((256 + S2K_GTAB_BITS - 1) / S2K_GTAB_BITS)
+#define S2K_GTAB_TOP_BITS (256 - S2K_GTAB_BITS * (S2K_GTAB_WINDOWS - 1))      /* the top window's value is at most 2^TOP_BITS (its bits + the carry) */
 #define S2K_GTAB_ENTRY_WORDS 16
-#define S2K_GTAB_WORDS (((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) * S2K_GTAB_ENTRY_WORDS)
+#define S2K_GTAB_SLOT(w, v) (((size_t)(w) << (S2K_GTAB_BITS - 1)) + (size_t)(v))
+#define S2K_GTAB_SLOTS (S2K_GTAB_SLOT(S2K_GTAB_WINDOWS, 0) + 1)
+#define S2K_GTAB_WORDS (S2K_GTAB_SLOTS * S2K_GTAB_ENTRY_WORDS)
+#define S2K_GTAB_SWORDS 9           /* words of a recoded scalar */
+static_assert(S2K_GTAB_TOP_BITS >= 1 && S2K_GTAB_TOP_BITS < S2K_GTAB_BITS - 1, "the top window must fit the table");
 
 S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
-    const u32* p = gtab + ((size_t)(window << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
+    const u32* p = gtab + S2K_GTAB_SLOT(window, v) * S2K_GTAB_ENTRY_WORDS;
     u32 w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = p[i];
     fe_from_words(r.x, w); fe_from_words(r.y, w + 8);
+}
+// s (8 little-endian words) -> s' = s + K (9 words)
+S2K_HD void gtab_recode(u32 out[S2K_GTAB_SWORDS], const u32 s[8]) {
+    u64 cy = 0;
+#pragma unroll
+    for (int i = 0; i < S2K_GTAB_SWORDS; i++) {
+        u32 k = 0;
+#pragma unroll
+        for (int w = 0; w + 1 < S2K_GTAB_WINDOWS; w++) { const int bit = S2K_GTAB_BITS - 1 + S2K_GTAB_BITS * w; if ((bit >> 5) == i) k |= 1u << (bit & 31); }
+        cy += (u64)(i < 8 ? s[i] : 0u) + k;
+        out[i] = (u32)cy; cy >>= 32;
+    }
+}
+// window g of a recoded scalar, given the two words that hold its bits (lo = word (D g) >> 5, hi = the next one or 0): the table record to
+// add (returns 0: the digit is zero) and whether its y has to be negated
+S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, int g, u32 lo, u32 hi) {
+    const int b = g * S2K_GTAB_BITS;
+    const u64 pair = (u64)lo | ((u64)hi << 32);
+    const u32 t = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+    u32 v;
+    if (g + 1 < S2K_GTAB_WINDOWS) { const int d = (int)t - (int)S2K_GTAB_HALF; neg = d < 0; v = (u32)(d < 0 ? -d : d); }
+    else { neg = 0; v = t; }
+    if (!v) return 0;
+    addr = tab + S2K_GTAB_SLOT(g, v) * S2K_GTAB_ENTRY_WORDS;
+    return 1;
 }
 
 // ---- per-lane table of odd multiples ----------------------------------------------------------------------
@@ -192,8 +228,8 @@ S2K_HD void ptab_load_ziso(fe& zi, const u32* ptab) {
 // spill around every point operation; in LDS it costs one ds_read per addition.  Word-major layout (word k of lane t at
 // [k * S2K_DIG_STRIDE + t]) keeps the accesses bank-conflict free.
 //   words 0..8 : 4-bit digit of addition a (2 <= a < 66) in nibble a & 7 of word a >> 3
-//   words 9..16: ng (little-endian words); window g of the generator phase is bits [B g, B g + B)
-#define S2K_DIG_WORDS 17
+//   words 9..17: ng recoded for the signed fixed-base windows (gtab_recode: 9 words); window g is bits [D g, D g + D)
+#define S2K_DIG_WORDS 18
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) u32* s2k_lds_ptr;
 #define S2K_DIG_STRIDE 256                  /* every kernel that calls ecmult_lane runs 256-lane workgroups */
@@ -257,8 +293,11 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
         }
     }
+    {
+        u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d);
 #pragma unroll
-    for (int i = 0; i < 8; i++) dig[(9 + i) * S2K_DIG_STRIDE] = ng.d[i];
+        for (int i = 0; i < S2K_GTAB_SWORDS; i++) dig[(9 + i) * S2K_DIG_STRIDE] = ngr[i];
+    }
 
     S2K_PROF_MARK(2);
     // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
@@ -282,11 +321,8 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
             addr = ptab + e * S2K_PTAB_ENTRY_WORDS + ((h && S2K_PTAB_TWINS) ? 16 : 0); lam = h && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
-            const int g = idx - S2K_ADD_G0;
-            const int b = g * S2K_GTAB_BITS, w = b >> 5;
-            const u64 pair = (u64)dig[(9 + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(10 + w) * S2K_DIG_STRIDE] : 0u) << 32);
-            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
-            if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+            const int g = idx - S2K_ADD_G0, w = (g * S2K_GTAB_BITS) >> 5;
+            valid = gtab_locate(addr, neg, gtab, g, dig[(9 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(10 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
@@ -393,7 +429,7 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
 // digits, 4 doublings + 4 additions per digit position.  Both tables are rescaled to ONE common Z (ptab_rescale), so the
 // accumulator sits on one isomorphic curve as before.  Only the lock-step form exists: the function returns 0 without having
 // produced anything when the wavefront is not uniform or a lane meets an operand with its own x coordinate, and the caller then
-// runs ecmult_lane.  Digit stream in LDS: words 0..7 = nibble (pos * 4 + stream), words 8..15 = ng.
+// runs ecmult_lane.  Digit stream in LDS: words 0..7 = nibble (pos * 4 + stream), words 8..16 = ng recoded (gtab_recode).
 #define S2K_SPLIT_ADDS_P 68          // 4 streams x 17 digits
 struct piece65 { u32 w[3]; int neg; };
 S2K_HD void sc_split_pieces(piece65 out[4], const half_scalar& h0, const half_scalar& h1) {
@@ -443,8 +479,11 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
+        {
+            u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d);
 #pragma unroll
-        for (int i = 0; i < 8; i++) dig[(8 + i) * S2K_DIG_STRIDE] = ng.d[i];
+            for (int i = 0; i < S2K_GTAB_SWORDS; i++) dig[(8 + i) * S2K_DIG_STRIDE] = ngr[i];
+        }
         fe za, zt, ziso;
         S2K_PROF_MARK(1);
         ptab_build_raw(za, ptab, A);
@@ -470,11 +509,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
             addr = ptab + (st >> 1) * S2K_PTAB_TABLE_WORDS + e * S2K_PTAB_ENTRY_WORDS + (((st & 1) && S2K_PTAB_TWINS) ? 16 : 0); lam = (st & 1) && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
-            const int g = idx - a_g0;
-            const int b = g * S2K_GTAB_BITS, w = b >> 5;
-            const u64 pair = (u64)dig[(8 + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(9 + w) * S2K_DIG_STRIDE] : 0u) << 32);
-            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
-            if (v) { addr = gtab + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+            const int g = idx - a_g0, w = (g * S2K_GTAB_BITS) >> 5;
+            valid = gtab_locate(addr, neg, gtab, g, dig[(8 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(9 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
@@ -553,7 +589,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 // + 2 tables + a chain quarter + 2 key updates) for ecmult_lane_split.
 // Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches) and the Z
 // factor; the parked entries of the construction live in a per-wavefront, lane-interleaved area (S2K_RRAW_WAVE_WORDS).
-// Digit stream in LDS (S2K_RING_DIG_WORDS words per lane): words 0..8 = 5-bit digit (pos * 4 + stream), six per word; 9..16 = s; 17..24 = f.
+// Digit stream in LDS (S2K_RING_DIG_WORDS words per lane): words 0..8 = 5-bit digit (pos * 4 + stream), six per word; 9..17 = s and 18..26 = f,
+// both recoded for the signed fixed-base windows (gtab_recode).
 // Only the lock-step form exists (every lane of the wavefront works: the caller gives idle lanes a dummy point and dummy scalars);
 // ecmult_ring_step returns 0, having produced nothing, when a lane met an operand with its own x coordinate, and the caller then takes
 // that step through ecmult_lane on P_j itself.
@@ -561,7 +598,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #define S2K_RING_ENTRIES 16
 #define S2K_RING_DIGITS 13                                      /* 13 signed odd 5-bit digits: every odd |k| < 2^65, no extra top digit (below) */
 #define S2K_RING_ADDS_P (4 * S2K_RING_DIGITS)
-#define S2K_RING_DIG_WORDS 25
+#define S2K_RING_DIG_WORDS 27
 #define S2K_RTAB_TABLE_WORDS (S2K_RING_ENTRIES * 16)
 #define S2K_RTAB_ZISO (2 * S2K_RTAB_TABLE_WORDS)
 #define S2K_RTAB_WORDS (S2K_RTAB_ZISO + 16)                     /* per lane: 32 finished sectors + the Z factor */
@@ -612,8 +649,9 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         }
 #pragma unroll
         for (int i = 0; i < 9; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
+        u32 sr[S2K_GTAB_SWORDS], fr[S2K_GTAB_SWORDS]; gtab_recode(sr, s.d); gtab_recode(fr, f.d);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { dig[(9 + i) * S2K_DIG_STRIDE] = s.d[i]; dig[(17 + i) * S2K_DIG_STRIDE] = f.d[i]; }
+        for (int i = 0; i < S2K_GTAB_SWORDS; i++) { dig[(9 + i) * S2K_DIG_STRIDE] = sr[i]; dig[(18 + i) * S2K_DIG_STRIDE] = fr[i]; }
     }
     S2K_PROF_MARK(1);
     const int a_g0 = S2K_RING_ADDS_P, a_h0 = a_g0 + S2K_GTAB_WINDOWS;
@@ -629,11 +667,8 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
             addr = rtab + (st >> 1) * S2K_RTAB_TABLE_WORDS + en * 16;
         } else if (idx < a_end) {
             const int second = idx >= a_h0;
-            const int g = idx - (second ? a_h0 : a_g0), base = second ? 17 : 9;
-            const int b = g * S2K_GTAB_BITS, w = b >> 5;
-            const u64 pair = (u64)dig[(base + w) * S2K_DIG_STRIDE] | ((u64)(w + 1 < 8 ? dig[(base + 1 + w) * S2K_DIG_STRIDE] : 0u) << 32);
-            const u32 v = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
-            if (v) { addr = (second ? htab : gtab) + ((size_t)((u32)g << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS; valid = 1; }
+            const int g = idx - (second ? a_h0 : a_g0), base = second ? 18 : 9, w = (g * S2K_GTAB_BITS) >> 5;
+            valid = gtab_locate(addr, neg, second ? htab : gtab, g, dig[(base + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(base + 1 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {

@@ -199,10 +199,9 @@ __global__ void k_gtab_base(u32* gtab) {
 __global__ void __launch_bounds__(256)
 k_gtab_entries(u32* gtab) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 w = t >> S2K_GTAB_BITS, v = t & ((1u << S2K_GTAB_BITS) - 1u);
-    // the top window only ever sees the bits that are left of a 256-bit scalar
-    const u32 top_bits = 256 - S2K_GTAB_BITS * (S2K_GTAB_WINDOWS - 1);
-    if (w < S2K_GTAB_WINDOWS && v >= 2 && (w + 1 < S2K_GTAB_WINDOWS || v < (1u << top_bits))) gtab_build_entry(gtab, w, v);
+    const u32 w = t >> (S2K_GTAB_BITS - 1), v = (t & (S2K_GTAB_HALF - 1u)) + 1u;          // v = 1 .. 2^(D-1): the magnitudes of a signed D-bit digit
+    // the top window only ever sees the bits that are left of a 256-bit scalar, plus the carry of the recoding
+    if (w < S2K_GTAB_WINDOWS && v >= 2 && (w + 1 < S2K_GTAB_WINDOWS || v <= (1u << S2K_GTAB_TOP_BITS) + 1u)) gtab_build_entry(gtab, w, v);
 }
 
 // fixed-base table of another point than G (a rangeproof generator): window bases from the 64 generator bytes, then k_gtab_entries
@@ -273,8 +272,8 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
 // ------------------------------------------------------------------------------------------------------------
 // per-device table pool + generator-table cache (rangeproof.h, shared-generator form): host side
 // ------------------------------------------------------------------------------------------------------------
-// The big tables belong to the DEVICE, not to an engine: the 11.8 GB fixed-base table of G and the cache of rangeproof generator tables
-// (11.8 GB each) are held once per HIP device in a reference-counted pool that every engine on that device shares.  A second engine on
+// The big tables belong to the DEVICE, not to an engine: the 21.5 GB fixed-base table of G and the cache of rangeproof generator tables
+// (21.5 GB each) are held once per HIP device in a reference-counted pool that every engine on that device shares.  A second engine on
 // a device -- the documented way to give every verifier thread its own stream, scratch and lock -- costs a few streams and events,
 // no table memory and no table build.  Tables are built lazily, by the first call that needs one (s2k_engine_reserve warms them up).
 // Ordering between engines: a build is stream-ordered on the building engine's stream and publishes an event; every other stream
@@ -356,11 +355,11 @@ static const u32* engine_gtab(s2k_engine* e, hipStream_t st) {
     std::lock_guard<std::recursive_mutex> lock(p->mu);
     if (p->gtab_state == 2) return p->gtab;
     if (p->gtab_state == 0) {
-        if (hipMalloc((void**)&p->gtab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); p->gtab = nullptr; s2k_fail("engine_gtab", "no memory for the generator table (11.8 GB of HBM)"); return nullptr; }
+        if (hipMalloc((void**)&p->gtab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); p->gtab = nullptr; s2k_fail("engine_gtab", "no memory for the generator table (21.5 GB of HBM)"); return nullptr; }
         int ok = hipMemsetAsync(p->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, st) == hipSuccess;
         if (ok) {
             hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, p->gtab);
-            hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, p->gtab);
+            hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << (S2K_GTAB_BITS - 1)) / 256)), dim3(256), 0, st, p->gtab);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(p->ev_gtab, st) == hipSuccess;
         }
         if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); hipFree(p->gtab); p->gtab = nullptr; s2k_fail("engine_gtab", "generator table build failed"); return nullptr; }
@@ -428,7 +427,7 @@ static int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* k
     memcpy(g.key, key, 64);
     if (hipMemcpyAsync(p->gen_keys + 64 * slot, g.key, 64, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
     hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, p->gen_keys + 64 * slot);
-    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << S2K_GTAB_BITS) / 256)), dim3(256), 0, st, g.tab);
+    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << (S2K_GTAB_BITS - 1)) / 256)), dim3(256), 0, st, g.tab);
     hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, p->gen_keys + 64 * slot, gtab, e->ptab);
     if (hipGetLastError() != hipSuccess || hipEventRecord(g.ev_ready, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
     g.valid = 1; g.done = 0; g.pinned = pinned; g.stamp = ++p->gen_clock;

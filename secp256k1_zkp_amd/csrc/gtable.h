@@ -2,11 +2,11 @@
 //
 // Role of the reference's secp256k1_pre_g / secp256k1_pre_g_128 (src/precomputed_ecmult.h:30-33, built by
 // src/ecmult_compute_table_impl.h:14-46): odd multiples for wNAF(15).  Here the table is organised for a machine with
-// 288 GB of HBM that would rather gather 64 bytes than execute doublings: entry (w, v) = v * 2^(B w) * G for every B-bit
-// value of every window of a scalar (B = S2K_GTAB_BITS = 24: 11 windows), as one aligned 64-byte sector of canonical words
-// (affine x, y), so ng*G is 11 mixed additions and zero doublings.  11 x 2^24 entries x 64 B = 11.8 GB; the gathers are issued one
-// addition ahead, so their HBM latency is covered.  The table is *computed on the device* when an engine is created (two
-// kernels, ~0.4 s), never shipped as data.
+// 288 GB of HBM that would rather gather 64 bytes than execute doublings: entry (w, v) = v * 2^(D w) * G for every magnitude
+// v = 1 .. 2^(D-1) of a SIGNED D-bit digit of every window of a scalar (D = S2K_GTAB_BITS = 26: 10 windows; ecmult.h "generator
+// table"), as one aligned 64-byte sector of canonical words (affine x, y), so ng*G is 10 mixed additions and zero doublings.
+// 10 x 2^25 entries x 64 B = 21.5 GB; the gathers are issued one addition ahead, so their HBM latency is covered.  The table is
+// *computed on the device* by the first call that needs it (two kernels, ~0.6 s), never shipped as data.
 #pragma once
 #include "ecmult.h"
 
@@ -17,7 +17,7 @@ S2K_HD void ge_set_generator(ge& g) {
     for (int i = 0; i < 9; i++) { g.x.n[i] = gx[i]; g.y.n[i] = gy[i]; }
 }
 S2K_HD void gtab_store(u32* gtab, u32 w, u32 v, const ge& a) {
-    u32* p = gtab + ((size_t)(w << S2K_GTAB_BITS) + v) * S2K_GTAB_ENTRY_WORDS;
+    u32* p = gtab + S2K_GTAB_SLOT(w, v) * S2K_GTAB_ENTRY_WORDS;
     u32 wx[8], wy[8];
     fe_to_words(wx, a.x); fe_to_words(wy, a.y);                     // `a` is normalised (ge_set_gej)
     for (int i = 0; i < 8; i++) { p[i] = wx[i]; p[8 + i] = wy[i]; }
@@ -31,7 +31,7 @@ S2K_HD void gtab_build_base(u32* gtab, u32 w, const ge* base = nullptr) {
     ge a; ge_set_gej(a, j);
     gtab_store(gtab, w, 1, a);
 }
-// step 2 (one thread per (w, v), v = 2..2^B-1): entry = v * base[w] by left-to-right double-and-add.
+// step 2 (one thread per (w, v), v = 2..2^(D-1)): entry = v * base[w] by left-to-right double-and-add.
 S2K_HD void gtab_build_entry(u32* gtab, u32 w, u32 v) {
     ge base; gtab_load(base, gtab, w, 1);
     gej acc; gej_set_infinity(acc);

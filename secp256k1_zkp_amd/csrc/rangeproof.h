@@ -410,7 +410,7 @@ struct rp_gen_dev {                       // by value to the kernels: the cache 
     u32 any;                              // index of some valid slot (idle lanes read its x-table)
 };
 // Generators that had no table, reported by the LAST stage (k_rp_final) for proofs that VERIFIED only -- an attacker cannot make the
-// engine spend 0.3 s and 11.8 GB on a table by sending junk proofs that merely name a generator (the first few distinct generators of
+// engine spend 0.6 s and 21.5 GB on a table by sending junk proofs that merely name a generator (the first few distinct generators of
 // a call, with the number of valid proofs that carried them).  A slot is claimed by a 64-bit tag of the generator bytes (one
 // compare-and-swap; lanes with the same generator then only count), so nothing on the device ever waits for another lane's key bytes
 // -- the host reads those after the call and ignores a slot whose bytes do not hash to its tag.  Two generators with the same tag

@@ -12,7 +12,7 @@ What an adversarial prover can choose that an honest one never produces, and wha
 * a VALID proof whose verification runs into an exceptional addition: `sign` is a plain Borromean signer over the reference's group
   operations (it doubles as the check that this file's hashing matches the reference: its proofs verify), and
   `grind_exceptional_doubling` chooses the nonce of a ring so that, when the verifier evaluates s*G + e*P with the generator part taken
-  window by window from the low end (24-bit windows, the engine's fixed-base table), the accumulator in front of the LAST window equals
+  digit by digit from the low end (signed 26-bit digits, the engine's fixed-base table), the accumulator in front of the LAST window equals
   that window's table entry: P + P inside an addition chain, on a proof the reference accepts.
 """
 import hashlib
@@ -158,38 +158,45 @@ class Crafter:
         s[ring][0] = (-e * ks[ring]) % N
         return self.commit33(commit_pt), self._assemble(ring_pts, e0, [v for row in s for v in row])
 
-    def grind_exceptional_doubling(self, rng, tries=4, window_bits=24):
-        """A VALID one-ring proof (value 0: the real signature sits at position 0, whose key is C = x*G) with the nonce chosen so that
-        e*C + (s mod 2^240)*G == (s >> 240) * 2^240 * G: the last generator window of a low-to-high fixed-base evaluation adds a point
-        to itself.  k = 2 w 2^240 for the right w, found by running all 65 535 candidates through the ring (batched).
-        Returns (commit33, proof, w) or None."""
-        top = 256 - (256 // window_bits) * window_bits if 256 % window_bits else window_bits      # bits of the last window (16 for 24-bit windows)
-        shift = 256 - top
+    @staticmethod
+    def fixed_base_top(s, D):
+        """(top digit, shift) of the engine's signed D-bit fixed-base recoding of the scalar s (csrc/ecmult.h: gtab_recode)"""
+        W = (256 + D - 1) // D
+        K = sum(1 << (D - 1 + D * w) for w in range(W - 1))
+        return (s + K) >> (D * (W - 1)), D * (W - 1)
+
+    def grind_exceptional_doubling(self, rng, D=26, w_lo=1, w_hi=None, chunk=1 << 15):
+        """A VALID one-ring proof (mantissa 1: two keys; value 0: the real signature sits at position 0, whose key is C = x*G) with the nonce
+        chosen so that, in a fixed-base evaluation of s*G by signed D-bit digits taken from the low end (the engine's table of G), the
+        accumulator in front of the LAST window equals that window's table entry:  e*C + sum_{w < W-1} d_w 2^(D w) G == d_top 2^(D (W-1)) G,
+        i.e. the nonce is k = 2 d_top 2^(D (W-1)) for the d_top that the resulting s = k - e*x really has.  e depends on k through the hash
+        chain, so the candidates d_top = w_lo .. w_hi-1 are run through the ring (batched through the reference) until one fits: each
+        fits with probability 2^-(256 - D (W-1)).  Returns (commit33, proof, d_top) or None."""
+        W = (256 + D - 1) // D
+        shift = D * (W - 1)
+        w_hi = w_hi or (1 << (256 - shift))
         rnd = lambda: int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "big") % (N - 1) + 1
-        for _ in range(tries):
-            x = rnd()
-            commit_pt = self.lin(0, x)
-            m = self._m(commit_pt, [], 1)
-            s = [0, rnd(), rnd(), rnd()]
-            ws = np.arange(1, 1 << top, dtype=np.int64)
-            cnt = ws.size
-            ks = [(2 * int(w) << shift) % N for w in ws]
-            R, inf = self.lin_many(np.tile(self.G, (cnt, 1)), np.frombuffer(b"".join(_b(k) for k in ks), np.uint8).reshape(cnt, 32), np.zeros((cnt, 32), np.uint8))
-            for j in range(1, 4):
-                es = b"".join(self._hash_e(self.ser33(R[t].tobytes()), m, 0, j) for t in range(cnt))
-                key = np.frombuffer(self.lin(-j, x), np.uint8)
-                R, inf = self.lin_many(np.tile(key, (cnt, 1)), np.frombuffer(es, np.uint8).reshape(cnt, 32), np.tile(np.frombuffer(_b(s[j]), np.uint8), (cnt, 1)))
-            for t in range(cnt):
+        x = rnd(); s1 = rnd()
+        commit_pt = self.lin(0, x)
+        hdr = bytes([0x40, 0])                                                  # exp 0, mantissa 1: one ring of two keys
+        m = _sha(self.ser_point(commit_pt), self.ser_point(self.gen), hdr)
+        key1 = np.frombuffer(self.lin(-1, x), np.uint8)                         # P_1 = C - H
+        s1b = np.frombuffer(_b(s1), np.uint8)
+        for lo in range(w_lo, w_hi, chunk):
+            ws = range(lo, min(lo + chunk, w_hi)); cnt = len(ws)
+            ks = [(2 * w << shift) % N for w in ws]
+            R, _ = self.lin_many(np.tile(self.G, (cnt, 1)), np.frombuffer(b"".join(_b(k) for k in ks), np.uint8).reshape(cnt, 32), np.zeros((cnt, 32), np.uint8))
+            es = b"".join(self._hash_e(self.ser33(R[t].tobytes()), m, 0, 1) for t in range(cnt))
+            R, _ = self.lin_many(np.tile(key1, (cnt, 1)), np.frombuffer(es, np.uint8).reshape(cnt, 32), np.tile(s1b, (cnt, 1)))
+            for t, w in enumerate(ws):
                 e0 = _sha(self.ser33(R[t].tobytes()), m)
                 e = int.from_bytes(self._hash_e(e0, m, 0, 0), "big") % N
                 s0 = (ks[t] - e * x) % N
-                if (s0 >> shift) == int(ws[t]) and s0 != 0 and e != 0:
+                if s0 != 0 and e != 0 and self.fixed_base_top(s0, D)[0] == w:
                     # the accumulator in front of the last window really is that window's entry
-                    assert (e * x + (s0 & ((1 << shift) - 1))) % N == (int(ws[t]) << shift) % N
-                    s[0] = s0
-                    return self.commit33(commit_pt), self._assemble([], e0, s), int(ws[t])
+                    assert (e * x + s0 - (w << shift)) % N == (w << shift) % N
+                    return self.commit33(commit_pt), hdr + e0 + _b(s0) + _b(s1), w
         return None
-
 
     # ---- a verifier WITHOUT the reference's two infinity rejections (what the forgeries are measured against) ---------------------------
     @staticmethod

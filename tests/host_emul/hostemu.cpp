@@ -93,7 +93,7 @@ static const lane_mem g_lm{g_ptab, g_dig};
 static void table_host(std::vector<u32>& g_gtab, const ge* point) {
     {
         g_gtab.assign(S2K_GTAB_WORDS, 0);
-        const u32 NV = 1u << S2K_GTAB_BITS; std::vector<gej> acc(NV); std::vector<fe> pre(NV);
+        const u32 NV = S2K_GTAB_HALF + 1u; std::vector<gej> acc(NV); std::vector<fe> pre(NV);      // magnitudes 1 .. 2^(D-1) of a signed digit
         for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
             gtab_build_base(g_gtab.data(), w, point);
             ge base; gtab_load(base, g_gtab.data(), w, 1);

@@ -64,7 +64,7 @@ def test_exceptional_fixture(ref, emu):
     c = bytes.fromhex(fx["commit33"]); p = bytes.fromhex(fx["proof"])
     assert _ref1(ref, c, p) == (1, fx["min_value"], fx["max_value"]) and fx["result"] == 1
     s0 = int.from_bytes(p[2 + 32:2 + 64], "big")                    # header (2 bytes, no sign byte for one ring), e0, then s_0
-    assert s0 >> 240 == fx["top_window"]
+    assert Crafter.fixed_base_top(s0, fx["digit_bits"])[0] == fx["top_digit"] and fx["digit_bits"] == 26
     ca = np.frombuffer(c, np.uint8)
     assert _emu_rp(emu, ca, p, GH[0])[0] == 1 and _emu_rp_shared(emu, ca, p, GH[0])[0][0] == 1
 

@@ -145,6 +145,42 @@ def test_emu_ecmult_two_piece_form(emu, ref):
     assert n_split >= 2 * len(scal)          # the two-piece form itself produced (nearly) all of these
 
 
+def fixed_base_edge_scalars(D, rng, count):
+    """scalars whose SIGNED D-bit fixed-base digits (csrc/ecmult.h, "generator table") sit on every edge: the recoded scalar s' = s + K is built
+    window by window from {0, 1, half - 1, half, half + 1, 2^D - 1} (digits -half, -half + 1, -1, 0, +1, half - 1) and random values, and
+    s = s' - K is kept when it is a scalar; plus n - 1, 1, and the values around 2^256 - K where s' needs its 257th bit."""
+    W = (256 + D - 1) // D
+    half = 1 << (D - 1)
+    K = sum(1 << (D - 1 + D * w) for w in range(W - 1))
+    out = [N - 1, N - 2, 1, 2, K % N, (K + 1) % N, (N - K) % N, (1 << 256) - K - 1 if (1 << 256) - K - 1 < N else N - 3]
+    edges = [0, 1, half - 1, half, half + 1, (1 << D) - 1]
+    top_bits = 256 - D * (W - 1)
+    while len(out) < count:
+        sp = 0
+        for w in range(W - 1):
+            t = edges[int(rng.integers(0, 6))] if rng.integers(0, 4) else int(rng.integers(0, 1 << D))
+            sp |= t << (D * w)
+        sp |= int(rng.integers(0, 1 << top_bits)) << (D * (W - 1))
+        s = sp - K
+        if 0 < s < N:
+            out.append(s)
+    return out
+
+
+def test_emu_signed_fixed_base_digits(emu, ref):
+    """the generator part of the double multiplication with every edge of the signed digit recoding (host build: 12-bit digits), alone and
+    next to a variable point, through both forms"""
+    rng = np.random.default_rng(46)
+    a = ref.rand_point(rng)
+    took = ctypes.c_int(0)
+    for s in fixed_base_edge_scalars(12, rng, 60):
+        ng = _b(s)
+        for na in (_b(0), bytes(rng.integers(0, 256, 32, dtype=np.uint8))):
+            want = _call(ref.lib, "ref_ecmult", [64], a, 0, na, ng)
+            assert _call(emu, "emu_ecmult", [64], a, 0, na, ng, None) == want, hex(s)
+            assert _call(emu, "emu_ecmult_split", [64], ctypes.byref(took), a, na, ng, None) == want, hex(s)
+
+
 def _emu_rp(emu, c, p, g, extra=b""):
     mn = ctypes.c_ulonglong(0); mx = ctypes.c_ulonglong(0)
     r = emu.emu_rangeproof_verify(ctypes.byref(mn), ctypes.byref(mx), c.tobytes(), p, ctypes.c_size_t(len(p)), extra, ctypes.c_size_t(len(extra)), g.tobytes())

@@ -135,16 +135,17 @@ def _gtab_bits():
 
 def test_generator_table(prims, ref):
     """entries (w, v) of the device-built window table equal v*2^(B w)*G computed by the reference's ecmult (role of
-    test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample."""
+    test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample.  The table holds the magnitudes
+    v = 1 .. 2^(B-1) of a signed B-bit digit; the top window what is left of a 256-bit scalar plus the recoding's carry."""
     rng = np.random.default_rng(16)
     B = _gtab_bits(); W = (256 + B - 1) // B; top = 256 - B * (W - 1)
-    nv = lambda w: (1 << B) if w + 1 < W else (1 << top)
+    nv = lambda w: (1 << (B - 1)) + 1 if w + 1 < W else (1 << top) + 2
     idx = [(w, v) for w in range(W) for v in (1, 2, 3, 255, 256, 257, nv(w) // 2 - 1, nv(w) // 2, nv(w) - 2, nv(w) - 1)]
     idx += [(w, int(rng.integers(1, nv(w)))) for w in rng.integers(0, W, 4000)]
     n = len(idx)
     sel = np.array([(int(w) << B) | v for (w, v) in idx], np.uint32)
     got, _ = prims(11, n, 64, sel.view(np.uint8))
-    ng = np.stack([np.frombuffer(_b(v << (B * int(w))), np.uint8) for (w, v) in idx])
+    ng = np.stack([np.frombuffer(_b((v << (B * int(w))) % N), np.uint8) for (w, v) in idx])      # (the top window's largest entries exceed 2^256: mod n)
     g = np.frombuffer(G_XY * n, np.uint8).reshape(-1, 64)
     exp, inf = ref.ecmult_batch(g, np.zeros((n, 32), np.uint8), ng)
     assert not inf.any()

