@@ -159,7 +159,9 @@ S2K_API int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, c
  *                                        rangeproof_impl.h:541-683, borromean_impl.h:53-104)
  * Packed form: proofs = all proofs back to back, proof_off[n+1] byte offsets (proof i = [off[i], off[i+1]));
  * commits n*33 = serialised Pedersen commitments (equivalently the first 33 bytes of each 64-byte
- * secp256k1_pedersen_commitment object); gens n*64 = secp256k1_generator objects; extra / extra_off likewise or NULL.
+ * secp256k1_pedersen_commitment object; an encoding that secp256k1_pedersen_commitment_parse refuses -- a prefix other than 8 / 9, x >= p,
+ * x not on the curve -- can never be such an object and gives results[i] = 0); gens n*64 = secp256k1_generator objects; extra / extra_off
+ * likewise or NULL.
  * min_value / max_value are written exactly when the reference writes them (header parsed), starting from 0. */
 S2K_API int secp256k1_rangeproof_verify_batch(s2k_engine* e, int32_t* results, uint64_t* min_value, uint64_t* max_value,
                                               const unsigned char* commits33, const unsigned char* proofs, const uint64_t* proof_off,

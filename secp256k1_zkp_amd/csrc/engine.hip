@@ -755,9 +755,10 @@ k_rp_prologue(rp_ws ws, const uint64_t* min_value, const unsigned char* commits3
     __builtin_amdgcn_s_setprio(3);
     const u32 role = threadIdx.x >> 6;
     const size_t p = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    int commit_ok = 0;
     if (p < n) {
         rp_rec& rec = ws.rec[p];
-        if (role == 0) rp_pp_commit(rec, min_value[p], commits33 + 33 * p, gens64 + 64 * p);
+        if (role == 0) commit_ok = rp_pp_commit(rec, min_value[p], commits33 + 33 * p, gens64 + 64 * p);
         else if (role == 1) {
             const unsigned char* ex = nullptr; uint64_t exlen = 0;
             if (extra && extra_off) { ex = extra + extra_off[p]; exlen = extra_off[p + 1] - extra_off[p]; if (exlen == 0) ex = nullptr; }
@@ -765,7 +766,7 @@ k_rp_prologue(rp_ws ws, const uint64_t* min_value, const unsigned char* commits3
         } else rp_pp_bases(rec, ws.bases + p * RP_MAX_RINGS * RP_GEJ_WORDS, gens64 + 64 * p, ws.dbases + p * RP_MAX_RINGS * RP_GEJ_WORDS);
     }
     __syncthreads();
-    if (p < n && role == 0 && (ws.rec[p].hdr & 1u)) ws.rec[p].ok = 1;
+    if (p < n && role == 0 && (ws.rec[p].hdr & 1u) && commit_ok) ws.rec[p].ok = 1;      // (a commitment encoding that does not parse: never valid)
 }
 __global__ void __launch_bounds__(256)
 k_rp_lift(rp_ws ws, const unsigned char* proofs, const uint64_t* proof_off, size_t n) {

@@ -136,12 +136,17 @@ S2K_HD void rp_load_generator(ge& g, const unsigned char* gen64) {              
 // A: commitment: x = b32 mod p, y = sqrt(x^3+7), negated when bit 0 of the prefix is set (generator/main_impl.h:266-273);
 //    accj = min_value * H (pedersen_ecmult_small, generator/pedersen_impl.h:33-38): plain double-and-add, the same group
 //    element as the reference's ecmult_const
-S2K_HD void rp_pp_commit(rp_rec& rec, u64 min_value, const unsigned char* commit33, const unsigned char* gen64) {
-    if (!(rec.hdr & 1u)) return;
+// Returns whether the 33 bytes are an encoding secp256k1_pedersen_commitment_parse accepts (generator/main_impl.h:281-297: prefix 8 or 9,
+// x below p, x on the curve).  The reference's verifier only ever sees parsed objects, so for a caller that hands over serialised bytes
+// a refused encoding must end as "invalid" here -- the load below would otherwise read just bit 0 of the prefix and lift whatever x says
+// (found by the differential fuzz, round 4: a flipped bit 7 of the prefix on an otherwise valid proof was accepted).
+S2K_HD int rp_pp_commit(rp_rec& rec, u64 min_value, const unsigned char* commit33, const unsigned char* gen64) {
+    if (!(rec.hdr & 1u)) return 0;
     ge c;
+    int valid = (commit33[0] & 0xFEu) == 8u;
     {
-        fe x; fe_set_b32_mod(x, commit33 + 1);
-        ge_set_xquad(c, x);
+        fe x; valid &= fe_set_b32_limit(x, commit33 + 1);
+        valid &= ge_set_xquad(c, x);
         fe_normalize(c.x); fe_normalize(c.y);
         if (commit33[0] & 1) { fe_neg(c.y, c.y, 1); fe_normalize(c.y); }
     }
@@ -158,6 +163,7 @@ S2K_HD void rp_pp_commit(rp_rec& rec, u64 min_value, const unsigned char* commit
         }
     }
     gej_store28_h(rec.accj, acc);
+    return valid;
 }
 // B: m = SHA256( ser(commit) || ser(gen) || proof[0..off_hdr) || (sign_i || x_i)_{i<rings-1} || extra )   (:588-651)
 //    ser(point) = [ !is_square(y) ] || x   (rangeproof_serialize_point :53-59)
@@ -215,10 +221,10 @@ S2K_HD void rp_pp_bases(const rp_rec& rec, u32* bases /*[32][28]*/, const unsign
 S2K_HD void rp_prologue_points(rp_rec& rec, u32* bases /*[32][28]*/, u64 min_value, const unsigned char* commit33,
                                const unsigned char* proof, const unsigned char* extra, u64 extra_len, const unsigned char* gen64, u32* dbases = nullptr) {
     if (!(rec.hdr & 1u)) return;
-    rp_pp_commit(rec, min_value, commit33, gen64);
+    const int commit_ok = rp_pp_commit(rec, min_value, commit33, gen64);
     rp_pp_hash(rec, commit33, proof, extra, extra_len, gen64);
     rp_pp_bases(rec, bases, gen64, dbases);
-    rec.ok = 1;
+    rec.ok = (u32)commit_ok;
 }
 
 // both halves back to back (host emulation, tests)

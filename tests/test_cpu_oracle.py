@@ -209,6 +209,19 @@ def test_emu_rangeproof(emu, ref):
             assert _emu_rp(emu, commits[0], p, gens[0]) == (rr[0], rmn[0], rmx[0])
 
 
+def test_emu_refused_commitment_encodings(emu, ref):
+    """a serialised commitment secp256k1_pedersen_commitment_parse refuses makes an otherwise valid proof invalid (host build of the stages)"""
+    rng = np.random.default_rng(32)
+    commits, plist, gens, _ = ref.make_rangeproofs(1, rng, min_bits=6)
+    assert _emu_rp(emu, commits[0], plist[0], gens[0])[0] == 1
+    for (byte, mask) in ((0, 0x80), (0, 0x02), (0, 0x10)):
+        c = commits[0].copy(); c[byte] ^= mask
+        assert _emu_rp(emu, c, plist[0], gens[0])[0] == 0
+        assert ref.rangeproof_verify_many(c[None], plist, gens)[0][0] == 0
+    c = commits[0].copy(); c[1:] = 0xFF
+    assert _emu_rp(emu, c, plist[0], gens[0])[0] == 0
+
+
 def _emu_rp_shared(emu, c, p, g, extra=b"", k=None):
     """K3 in the shared-generator form with k rings per lane; k = None: 1, 2 and 4 must agree"""
     outs = []

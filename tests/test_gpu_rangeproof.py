@@ -156,3 +156,25 @@ def test_config3_full_size(engine, ref):
     assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
     assert e_res.sum() == n - len(range(0, n, 37))
     assert int(mx[1]) == 2**64 - 1
+
+
+def test_commitment_encodings_the_reference_refuses(engine, ref):
+    """serialised commitments that secp256k1_pedersen_commitment_parse refuses (generator/main_impl.h:281-297) can never reach the reference's
+    verifier; handed to the batch call with an otherwise VALID proof they must come out invalid: a prefix other than 8 / 9 (the load only
+    looks at bit 0: found by the differential fuzz, profiles/r04_fuzz_tally_large.txt seed 223), x >= p, x not on the curve"""
+    from tests.refapi import P
+    rng = np.random.default_rng(80)
+    commits, proofs, gens, _ = ref.make_rangeproofs(8, rng, min_bits=12)
+    C = [commits[i].copy() for i in range(8)]
+    C[1][0] ^= 0x80; C[2][0] ^= 0x02; C[3][0] = 0; C[4][0] ^= 0x10                       # prefixes 0x88/0x89, 0x0a/0x0b, 0, 0x18/0x19
+    C[5][1:] = np.frombuffer((P + 5).to_bytes(32, "big"), np.uint8)                        # x >= p
+    x = int.from_bytes(C[6][1:].tobytes(), "big")
+    while pow((x * x * x + 7) % P, (P - 1) // 2, P) == 1:                                  # next x that is not on the curve
+        x += 1
+    C[6][1:] = np.frombuffer(x.to_bytes(32, "big"), np.uint8)
+    C = np.stack(C)
+    res, mn, mx = engine.rangeproof_verify_batch(C, proofs, gens)
+    assert list(res) == [1, 0, 0, 0, 0, 0, 0, 1]
+    # what the reference does with these: parse fails for items 1..6, verify accepts 0 and 7
+    want = ref.rangeproof_verify_many(C, proofs, gens)[0]
+    assert list(want) == [1, 0, 0, 0, 0, 0, 0, 1]
