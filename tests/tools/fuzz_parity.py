@@ -45,6 +45,10 @@ def main():
         if i % 4: P[i] = mutate(P[i], rng, int(rng.integers(0, 8)))
         if i % 16 == 5: C[i, int(rng.integers(0, 33))] ^= 1 << int(rng.integers(0, 8))
         if i % 16 == 9: G[i, int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
+        # (5 and 9 are odd: those proofs are always mutated as well.  The same on UNMUTATED proofs -- i % 4 == 0 -- is what finds a verifier that is
+        #  more permissive than parse + verify about the OTHER inputs: round 4, a commitment prefix with bit 7 set on a valid proof)
+        if i % 16 == 4: C[i, int(rng.integers(0, 33)) if rng.integers(0, 4) else 0] ^= 1 << int(rng.integers(0, 8))
+        if i % 16 == 8: G[i, int(rng.integers(0, 64))] ^= 1 << int(rng.integers(0, 8))
     e = ref.rangeproof_verify_many(C, P, G, threads=16)
     r = eng.rangeproof_verify_batch(C, P, G)
     # a commitment that secp256k1_pedersen_commitment_parse refuses never reaches secp256k1_rangeproof_verify in the reference
