@@ -1,0 +1,65 @@
+"""GPU tier: the reference's OWN test program as a differential driver of the engine (tests/integration/route_modules.h, route_api.h).
+
+oracle/_ref/ref_tests_routed is the reference's src/tests.c compiled from the sources where they lie, with every call of the two static
+seams of the hot path (secp256k1_ecmult, secp256k1_ecmult_multi_var -- made by the modules and by the tests) and every call of a public
+verifier on the path (rangeproof verify / rewind, BIP-340 verify, half-aggregate verify, Pedersen tally, surjection proof, the BP++ norm
+argument) followed by the engine's form of the same call on the same operands; a difference aborts the program.  The reference's tests
+bring what a hand-written parity test does not think of: proofs of every shape its signer can make (exponents, min_bits, min_value,
+messages, extra_commit), its corrupted and truncated proofs, its fixed vectors, test_ecmult_multi's infinities / zero scalars / cancelling
+terms / every batching size, the GLV edge scalars, MuSig key aggregation, whitelist and adaptor signatures running on secp256k1_ecmult.
+The program's exit status is the verdict: 0 = the reference's own assertions hold AND the engine agreed on every checked call."""
+import os
+import re
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BIN = os.path.join(ROOT, "oracle", "_ref", "ref_tests_routed")
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout, env=None):
+    e = dict(os.environ); e.update(env or {})
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=timeout, env=e)
+    rep = {}
+    for m in re.finditer(r"s2k-route: (\S+)\s+calls\s+(\d+)\s+checked\s+(\d+)\s+reference-accepted\s+(\d+)", r.stderr):
+        rep[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
+    return r, rep
+
+
+@pytest.fixture(scope="module")
+def binary():
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/ref_tests_routed not built (make -C oracle routed, needs the reference tree)")
+    return BIN
+
+
+def test_protocol_modules_of_the_reference_suite(binary):
+    """rangeproof, generator (Pedersen), surjection, schnorrsig, half-aggregate, BP++, MuSig, whitelist: the modules whose verifiers sit on
+    the path.  Every public verifier call and every multi-scalar multiplication is checked, every 16th double multiplication."""
+    r, rep = _run(["-t=rangeproof", "-t=generator", "-t=surjection", "-t=schnorrsig", "-t=schnorrsig_halfagg", "-t=bppp", "-t=musig", "-t=whitelist"], 1500, {"S2K_RT_ECMULT_EVERY": "16"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "engine on" in r.stderr
+    for name, floor in (("rangeproof_verify", 1000), ("rangeproof_rewind", 100), ("schnorrsig_verify", 100), ("pedersen_verify_tally", 50),
+                        ("surjectionproof_verify", 50), ("schnorrsig_aggverify", 50), ("bppp_norm_product_verify", 20), ("ecmult_multi_var", 100), ("ecmult", 1000)):
+        calls, checked, accepted = rep[name]
+        assert checked >= floor, (name, rep[name])
+    # both verdicts were seen: the reference's tests corrupt what they sign
+    for name in ("rangeproof_verify", "schnorrsig_verify", "surjectionproof_verify", "schnorrsig_aggverify", "bppp_norm_product_verify", "pedersen_verify_tally"):
+        calls, checked, accepted = rep[name]
+        assert 0 < accepted < checked, (name, rep[name])
+    print("\n" + "\n".join(l for l in r.stderr.splitlines() if l.startswith("s2k-route")))
+
+
+def test_ecmult_module_of_the_reference_suite(binary):
+    """The reference's ecmult tests (run_ecmult_chain, run_ecmult_constants, run_ecmult_near_split_bound, test_ecmult_multi over both
+    algorithms and every batching size, ...): ~85 000 multi-scalar multiplications, all checked; double multiplications sampled."""
+    r, rep = _run(["-t=ecmult"], 1500, {"S2K_RT_ECMULT_EVERY": "16"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    calls, checked, accepted = rep["ecmult_multi_var"]
+    assert checked >= 10000 and checked == accepted, rep
+    assert rep["ecmult"][1] >= 5000, rep
+    print("\n" + "\n".join(l for l in r.stderr.splitlines() if l.startswith("s2k-route")))
