@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on ONE box: resident 64-bit rangeproof throughput (the bench's headline loop) and 2^16 BIP-340, alternating
-between the libraries (each in its own subprocess: S2K_LIB).    python tools/ab_probe.py libA.so libB.so [rounds]"""
+between the libraries (each in its own subprocess: S2K_LIB).    python tools/ab_probe.py libA.so libB.so [libC.so ...] [rounds]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -42,7 +42,7 @@ sch = m * 10 / (time.perf_counter() - t)
 assert bool(r.all().item())
 print("RESULT rp %%s  kernel_ms %%.3f  bip340 %%.3e" %% (" ".join("%%.0f" %% x for x in res), float(np.mean(kern)), sch))
 ''' % ROOT
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]; rounds = ([int(a) for a in sys.argv[1:] if a.isdigit()] or [2])[0]
 for rd in range(rounds):
     for lib in libs:
         out = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, S2K_LIB=os.path.abspath(lib)), capture_output=True, text=True, timeout=600)
