@@ -107,7 +107,8 @@ S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, int g, u32 lo
 // that one store / load instruction moves 256 contiguous bytes instead of touching 64 different lines).
 // Non-temporal hints for data that is touched once, so that it does not displace the finished per-lane tables (2 KB per lane, re-read ~50
 // times per ring position, 268 MB over the resident lanes: right at the size of the Infinity Cache) from the caches.  S2K_NT_PARK: the parked
-// entries of a table under construction (written once, read once by the rescaling pass); S2K_NT_GTAB: the operands the shared-generator
+// entries of a table under construction in the ring form's SEPARATE, wave-interleaved parking area (written once, read once by the rescaling
+// pass; NOT the in-place parking of the general form, whose lines the finished sectors overwrite at once: hinted, it lost 15 %); S2K_NT_GTAB: the operands the shared-generator
 // ring form takes from the 21.5 GB fixed-base tables (random sectors, never reused).  Measured together on one box (tools/ab_probe.py,
 // profiles/r04v_ab_nontemporal.txt): 1.0425e6 -> 1.053e6 verifies/s; either one alone is inside the noise (+-0.4 %).  0 = plain accesses.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -127,7 +128,7 @@ template <int WS = 1>
 S2K_HD void ptab_store_raw(u32* e, const fe& x, const fe& y, const fe& third) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        if (S2K_NT_PARK) { S2K_ST_NT(x.n[i], &e[i * WS]); S2K_ST_NT(y.n[i], &e[(9 + i) * WS]); S2K_ST_NT(third.n[i], &e[(18 + i) * WS]); }
+        if (S2K_NT_PARK && WS > 1) { S2K_ST_NT(x.n[i], &e[i * WS]); S2K_ST_NT(y.n[i], &e[(9 + i) * WS]); S2K_ST_NT(third.n[i], &e[(18 + i) * WS]); }
         else { e[i * WS] = x.n[i]; e[(9 + i) * WS] = y.n[i]; e[(18 + i) * WS] = third.n[i]; }
     }
 }
@@ -184,7 +185,7 @@ S2K_HD void ptab_rescale_n(u32* tab, u32* fin, int fin_stride, const fe* zs0) {
     u32 nraw[27];
     fe x, y, h;
 #pragma unroll
-    for (int k = 0; k < 27; k++) nraw[k] = S2K_NT_PARK ? S2K_LD_NT(&tab[(N - 1) * ES + k * WS]) : tab[(N - 1) * ES + k * WS];
+    for (int k = 0; k < 27; k++) nraw[k] = (S2K_NT_PARK && WS > 1) ? S2K_LD_NT(&tab[(N - 1) * ES + k * WS]) : tab[(N - 1) * ES + k * WS];
 #pragma unroll
     for (int k = 0; k < 9; k++) { x.n[k] = nraw[k]; y.n[k] = nraw[9 + k]; h.n[k] = nraw[18 + k]; }
     for (int i = N - 1; i >= 0; i--) {
@@ -192,7 +193,7 @@ S2K_HD void ptab_rescale_n(u32* tab, u32* fin, int fin_stride, const fe* zs0) {
         u32* e = fin + i * fin_stride;
         if (i > 0) {
 #pragma unroll
-            for (int k = 0; k < 27; k++) nraw[k] = S2K_NT_PARK ? S2K_LD_NT(&er[k * WS - ES]) : er[k * WS - ES];
+            for (int k = 0; k < 27; k++) nraw[k] = (S2K_NT_PARK && WS > 1) ? S2K_LD_NT(&er[k * WS - ES]) : er[k * WS - ES];
         }
         if (zs0 || i != N - 1) {
             fe zs2, zs3; fe_sqr(zs2, zs); fe_mul(zs3, zs2, zs);
@@ -738,17 +739,17 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
     }
     // table part (G, then H): a zero window adds nothing (per lane), so these additions are committed by select
     while (au < a_end) {
-        if (S2K_NT_GTAB) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if S2K_NT_GTAB && defined(__HIP_DEVICE_COMPILE__)
+        {
             typedef unsigned int s2k_u32x4 __attribute__((ext_vector_type(4)));
             const s2k_u32x4* q = (const s2k_u32x4*)nxt_addr;
 #pragma unroll
             for (int k = 0; k < 4; k++) { const s2k_u32x4 v = __builtin_nontemporal_load(q + k); raw[4 * k] = v.x; raw[4 * k + 1] = v.y; raw[4 * k + 2] = v.z; raw[4 * k + 3] = v.w; }
-#endif
-        } else {
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
-        }
+#endif
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);
         if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
         if (cur_valid) R = t;
