@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: 64-bit Borromean rangeproof verifies/s on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts the N ranks itself, one per GPU, through the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one pass of the verification hot path (secp256k1_rangeproof_verify semantics, five HIP kernels) over one batch
@@ -309,9 +309,9 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     sec = loop(lambda: eng.ecmult_multi_dev(r_xy, r_inf, d_s, d_p, g_sc=d_g))
     exp_xy, exp_inf = ref.ecmult_multi(scs, pts, gsc.tobytes())
     assert bytes(r_xy.cpu().numpy()) == exp_xy.tobytes() and int(r_inf.item()) == exp_inf, "1 024-term MSM differs from the reference's ecmult_multi_var"
-    # the same call with TWO in flight (S2K_OPT_RP_INPUTS_READY: resident, untouched inputs let the engine alternate between two stream /
-    # workspace sets for small sums): what a caller with a stream of small sums sees
-    eng.set_option(Engine.OPT_RP_INPUTS_READY, 1)
+    # the same call with TWO in flight (S2K_OPT_MSM_PIPELINE: the engine alternates between two stream / workspace sets for small sums;
+    # S2K_OPT_RP_INPUTS_READY: the inputs are resident and untouched): what a caller with a stream of small sums sees
+    eng.set_option(Engine.OPT_RP_INPUTS_READY, 1); eng.set_option(Engine.OPT_MSM_PIPELINE, 1)
     o2 = [(torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) for _ in range(2)]
     torch.cuda.synchronize()
     for k in range(2):
@@ -323,7 +323,7 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
         eng.ecmult_multi_dev(o2[k & 1][0], o2[k & 1][1], d_s, d_p, g_sc=d_g)
     torch.cuda.synchronize()
     sec2 = (time.perf_counter() - t0) / kq
-    eng.set_option(Engine.OPT_RP_INPUTS_READY, 0)
+    eng.set_option(Engine.OPT_RP_INPUTS_READY, 0); eng.set_option(Engine.OPT_MSM_PIPELINE, 0)
     assert all(bytes(o[0].cpu().numpy()) == exp_xy.tobytes() and int(o[1].item()) == exp_inf for o in o2), "1 024-term MSM with two calls in flight differs"
     out["bench_ecmult_1023p_g"] = {"metric": "one 1 024-term multi-scalar multiplication incl. G (BASELINE config 1's input shape)", "value": nm / sec / 1e6, "unit": "Mpoint-scalar/s",
                                    "ms": sec * 1e3, "terms": nm, "verified": True, "result_check": "== secp256k1_ecmult_multi_var of the reference on the same inputs",
@@ -508,18 +508,45 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # one process per GPU over RCCL ("nccl"); S2K_DIST_BACKEND=gloo lets the N>1 code path be exercised on a box with
     # fewer GPUs than ranks (ranks then share devices) -- for testing only, never for reported numbers
     backend = os.environ.get("S2K_DIST_BACKEND", "nccl")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        sys.exit("bench.py: --gpus %d but this node has %d GPU(s): one rank per GPU over RCCL needs %d devices "
+                 "(S2K_DIST_BACKEND=gloo lets ranks share a device, for testing only)" % (args.gpus, torch.cuda.device_count(), args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher of N ranks, one per GPU (exactly the command the docstring shows);
+        # rank 0's JSON line goes to this process's stdout.  Under torch.distributed.run (WORLD_SIZE set) this branch is not taken.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execvpe(cmd[0], cmd, dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, world))
     local = local % torch.cuda.device_count()
+    rank_devices, collective_world = [local], 1
     if world > 1:
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # proof that the collective library saw every rank: a checked all-reduce (sum of rank + 1) and the ranks' device ids gathered
+        chk = torch.tensor([rank + 1], dtype=torch.int64, device=torch.device("cuda", local)); dist.all_reduce(chk)
+        collective_world = dist.get_world_size()
+        assert int(chk.item()) == world * (world + 1) // 2 and collective_world == world, "all-reduce over the ranks gave %d for world %d" % (int(chk.item()), world)
+        ids = [torch.zeros(1, dtype=torch.int64, device=torch.device("cuda", local)) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local], dtype=torch.int64, device=torch.device("cuda", local)))
+        rank_devices = [int(t.item()) for t in ids]
+        if backend == "nccl":
+            assert sorted(rank_devices) == list(range(world)), "ranks do not own distinct devices: %r" % (rank_devices,)
     from secp256k1_zkp_amd import Engine
     eng = Engine(local)
     torch.cuda.set_device(local)
@@ -754,7 +781,7 @@ def main():
             dist.barrier()
         if rank == 0:
             ndev = torch.cuda.device_count()
-            devs = list(range(min(world, ndev))) if world > 1 else [local, local]
+            devs = [i % ndev for i in range(world)] if world > 1 else [local, local]      # devices 0..N-1 of the run (ranks sharing a device under gloo: the same sharing)
             try:
                 group = measure_group(devs, commits, proofs, gens, ref, steps=max(2, min(args.steps, 4)))
             except Exception as ex:      # noqa: BLE001  (the headline must not be lost to a failure of this extra block)
@@ -805,6 +832,10 @@ def main():
         mad_rate = 4 * MAC64_PER_PROOF * n / (kms * 1e-3)
         out = {
             "metric": "64-bit Borromean rangeproof verifies/sec", "value": value, "unit": "verifies/s", "n_gpus": world,
+            # the exchange library's own view of the job: world size after a checked all-reduce ("rccl" when the backend is nccl), the device of every rank
+            "collective": {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+                           "world_size": collective_world, "rank_devices": rank_devices},
+            "rccl_world_size": collective_world if (world > 1 and backend == "nccl") else (1 if world == 1 else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (9x29-bit), 32x32->64 integer MAC", "data": data_desc,
             # verified: every timed proof was signed by the reference (oracle/_ref) and accepted; false when the run fell back to a tiled golden proof

@@ -51,10 +51,12 @@ S2K_API void s2k_clear_status(void);
  *   that stage still waits for everything queued on the caller's stream before the call, because the inputs may be produced there.
  *   Setting the option to 1 is the caller's promise that the input arrays of a `_dev` call are complete when the call is made (and
  *   stay untouched until its results are consumed); min_value/max_value may then be written before the stream reaches the call.
- *   Results are unaffected; host-buffer entry points ignore the option.  The same promise lets s2k_ecmult_multi_dev and
- *   s2k_ecmult_multi_partial_dev keep TWO calls in flight for small sums (up to 2^13 terms, where one call is a chain of latency-bound
- *   launches): calls alternate between two internal stream / workspace sets and the caller's stream only waits for each call's result
- *   (give calls that may overlap different output buffers).  Larger sums fill the machine by themselves and run one after the other.
+ *   Results are unaffected; host-buffer entry points ignore the option.  An option only: the environment cannot make this promise.
+ * S2K_OPT_MSM_PIPELINE (default 0): s2k_ecmult_multi_dev and s2k_ecmult_multi_partial_dev keep TWO calls in flight for small sums (up
+ *   to 2^13 terms, where one call is a chain of latency-bound launches): calls alternate between two internal stream / workspace sets
+ *   and the caller's stream only waits for each call's result (give calls that may overlap different OUTPUT buffers: results of
+ *   consecutive calls are not ordered against each other's writes).  Inputs stay ordered behind the caller's stream unless
+ *   S2K_OPT_RP_INPUTS_READY is also set.  Larger sums fill the machine by themselves and run one after the other.
  * S2K_OPT_RP_SPLIT (default 1): two-piece double multiplication in the ring kernel (0: the one-piece form; same results).
  * S2K_OPT_GEN_CACHE_SLOTS (default 2, 0..8; $S2K_GEN_CACHE): how many rangeproof generators may have a fixed-base table at a time
  *   (21.5 GB of HBM each, see s2k_engine_cache_generator).  0 turns the shared-generator form of the ring kernel off.
@@ -62,11 +64,23 @@ S2K_API void s2k_clear_status(void);
  *   carrying it have VERIFIED (the last kernel of a call reports them through a device mailbox that the next call reads: junk proofs
  *   that merely name a generator never cost a table).  At most one automatic table is built per call, and it only takes a free slot
  *   or the slot of another automatic table -- never the table of secp256k1_generator_h or one requested through
- *   s2k_engine_cache_generator. */
+ *   s2k_engine_cache_generator.
+ * S2K_OPT_MAX_LANES (default 2^20, multiples of 256, >= 256): lanes per launch; larger batches run as consecutive sub-range launches.
+ * S2K_OPT_STAGE_THREADS (default min(8, cores / 2); $S2K_STAGE_THREADS): host threads that gather a host-buffer rangeproof batch.
+ * S2K_OPT_HALFAGG_HOST_CHAIN (default 1): the host-buffer half-aggregate verifier walks the randomizer hash chain on the host
+ *   underneath the point-lifting kernel (0: on the device; same verdicts).
+ * S2K_OPT_SYNC_SPLIT (default 1): a lone synchronous host-buffer rangeproof call that finds both staging sets free goes as two halves.
+ * Environment: only start-up defaults are read from it, once, when an engine (or the device's table pool) is created: S2K_DEVICE,
+ * S2K_GEN_CACHE, S2K_GEN_CACHE_MIN, S2K_STAGE_THREADS.  Nothing on a call path reads the environment. */
 #define S2K_OPT_RP_INPUTS_READY 1
 #define S2K_OPT_RP_SPLIT 2
 #define S2K_OPT_GEN_CACHE_SLOTS 3
 #define S2K_OPT_GEN_CACHE_MIN 4
+#define S2K_OPT_MSM_PIPELINE 5
+#define S2K_OPT_MAX_LANES 6
+#define S2K_OPT_STAGE_THREADS 7
+#define S2K_OPT_HALFAGG_HOST_CHAIN 8
+#define S2K_OPT_SYNC_SPLIT 9
 S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
 /* Rangeproof generator tables.  The four public keys of a Borromean ring differ by multiples of the proof's generator
  * (secp256k1_rangeproof_pub_expand, src/modules/rangeproof/rangeproof_impl.h:19-51), so when the engine holds a fixed-base table of that

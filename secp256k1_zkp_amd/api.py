@@ -79,6 +79,11 @@ class Engine:
     OPT_RP_SPLIT = 2
     OPT_GEN_CACHE_SLOTS = 3
     OPT_GEN_CACHE_MIN = 4
+    OPT_MSM_PIPELINE = 5
+    OPT_MAX_LANES = 6
+    OPT_STAGE_THREADS = 7
+    OPT_HALFAGG_HOST_CHAIN = 8
+    OPT_SYNC_SPLIT = 9
 
     def cache_generator(self, gen64):
         """Build the fixed-base table of one rangeproof generator now (s2k_engine_cache_generator)."""

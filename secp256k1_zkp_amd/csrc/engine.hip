@@ -119,9 +119,18 @@ struct s2k_engine {
     // workspace, calls alternate between the slots, and the caller's stream only waits for a call's result -- the latency-bound tail of
     // call k (Horner, tree sums, bucket weights: ~25 small launches during which most CUs idle) runs underneath the binning and
     // partial-sum rounds of call k+1.
-    struct msm_slot { hipStream_t s, s2; hipEvent_t fork, join, done, in; unsigned char* ws; size_t ws_bytes; } msm_slot[2];
+    struct msm_slot { hipStream_t s, s2; hipEvent_t fork, join, done, in; unsigned char* ws; size_t ws_bytes; unsigned long long seen_epoch; } msm_slot[2];
     unsigned msm_seq;
-    int cur_pipe, prev_pipe;   // the current / the previous entry-point call was a pipelined MSM (stream_guard, msm_pipelined)
+    int cur_pipe;              // the current entry-point call is a pipelined MSM (stream_guard, msm_pipelined)
+    // Work that did NOT go through an MSM slot shares the engine's table arena with the slots' gated exact path: `np_epoch` counts such calls
+    // and `ev_last_np` is recorded at the end of each; a slot waits for it whenever it has not yet seen the current epoch (msm_pipelined).
+    hipEvent_t ev_last_np; unsigned long long np_epoch; int np_valid;
+    int msm_pipeline;          // S2K_OPT_MSM_PIPELINE: small multi-scalar multiplications keep two calls in flight (msm_pipelined)
+    int halfagg_host_chain;    // S2K_OPT_HALFAGG_HOST_CHAIN
+    int sync_split;            // S2K_OPT_SYNC_SPLIT: a lone synchronous host-buffer rangeproof call goes as two halves
+    int stage_log;             // diagnostic builds: phase times of a host-buffer call on stderr
+    // diagnostic overrides of the MSM launcher (-DS2K_DIAG builds read them from the environment ONCE, at engine creation; 0 = the plan's choice)
+    struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small; } msm_diag;
     u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
     std::recursive_mutex mu;
 };
@@ -131,11 +140,14 @@ struct s2k_engine {
 struct stream_guard {
     s2k_engine* e; hipStream_t st;
     stream_guard(s2k_engine* e_, hipStream_t st_) : e(e_), st(st_) {
-        e->prev_pipe = e->cur_pipe; e->cur_pipe = 0;
+        e->cur_pipe = 0;
         if (e->last_stream_valid && e->last_stream != st) { if (hipStreamWaitEvent(st, e->ev_last, 0) != hipSuccess) (void)hipGetLastError(); }
     }
     ~stream_guard() {
         if (hipEventRecord(e->ev_last, st) == hipSuccess) { e->last_stream = st; e->last_stream_valid = 1; } else (void)hipGetLastError();
+        if (!e->cur_pipe) {            // a call that used the engine's own scratch: the MSM slots must not run their exact path under it
+            if (hipEventRecord(e->ev_last_np, st) == hipSuccess) { e->np_epoch++; e->np_valid = 1; } else (void)hipGetLastError();
+        }
     }
 };
 // per-lane table scratch for `lanes` concurrent ecmult_lane callers (lane = global thread index of the launch)
@@ -321,7 +333,9 @@ static s2k_dev_pool* pool_acquire(int device) {
     p->gen_slots = 2; p->gen_clock = 0; p->gen_min = size_t(1) << 16; p->gen_h = 1;
     if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); p->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
     if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) p->gen_min = (size_t)strtoull(gm, nullptr, 10);
+#ifdef S2K_DIAG
     if (const char* gh = getenv("S2K_GEN_CACHE_H")) p->gen_h = atoi(gh) != 0;
+#endif
     int ok = hipEventCreateWithFlags(&p->ev_gtab, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < RP_GEN_SLOTS; i++) ok = hipEventCreateWithFlags(&p->gen[i].ev_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&p->gen_keys, 64 * RP_GEN_SLOTS) == hipSuccess && hipMemset(p->gen_keys, 0, 64 * RP_GEN_SLOTS) == hipSuccess;
@@ -496,10 +510,11 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     e->rp_last_plan[0] = e->rp_last_plan[1] = nullptr;
     e->ha_pin = nullptr; e->ha_pin_words = 0;
-    for (int i = 0; i < 2; i++) { auto& m = e->msm_slot[i]; m.s = m.s2 = nullptr; m.fork = m.join = m.done = m.in = nullptr; m.ws = nullptr; m.ws_bytes = 0; }
-    e->msm_seq = 0; e->cur_pipe = e->prev_pipe = 0;
+    for (int i = 0; i < 2; i++) { auto& m = e->msm_slot[i]; m.s = m.s2 = nullptr; m.fork = m.join = m.done = m.in = nullptr; m.ws = nullptr; m.ws_bytes = 0; m.seen_epoch = 0; }
+    e->msm_seq = 0; e->cur_pipe = 0; e->ev_last_np = nullptr; e->np_epoch = 0; e->np_valid = 0;
+    e->msm_pipeline = 0; e->halfagg_host_chain = 1; e->sync_split = 1; e->stage_log = 0;
+    e->msm_diag = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
-    if (const char* rr = getenv("S2K_RP_INPUTS_READY")) e->rp_inputs_ready = atoi(rr) != 0;
     e->rp_debug = 0;
     for (int i = 0; i < 2; i++) { auto& S = e->stage[i]; S.in = S.out = S.dev = nullptr; S.in_bytes = S.out_bytes = S.dev_bytes = 0; S.ev_h2d = S.ev_out = nullptr; S.used = 0; S.ticket = 0; S.sync_owned = 0; }
     e->next_ticket = 1; e->stream_copy = nullptr;
@@ -507,6 +522,11 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (const char* th = getenv("S2K_STAGE_THREADS")) { const int v = atoi(th); if (v >= 1 && v <= 64) e->stage_threads = v; }
 #ifdef S2K_DIAG          /* diagnostic builds only (tools/rings_parts.py builds its own library with -DS2K_DIAG): a verifier's verdicts never depend on the environment */
     if (const char* sg = getenv("S2K_RP_DEBUG")) e->rp_debug = atoi(sg);
+    e->stage_log = getenv("S2K_STAGE_LOG") != nullptr;
+    {   auto num = [](const char* k) { const char* v = getenv(k); return v ? atoi(v) : 0; };
+        e->msm_diag.c = num("S2K_MSM_C"); e->msm_diag.T = num("S2K_MSM_T"); e->msm_diag.chunk = num("S2K_MSM_CHUNK");
+        e->msm_diag.two_pass = getenv("S2K_MSM_TWO_PASS") != nullptr; e->msm_diag.one_pass = getenv("S2K_MSM_ONE_PASS") != nullptr;
+        e->msm_diag.bin_plain = getenv("S2K_MSM_BIN_PLAIN") != nullptr; e->msm_diag.no_small = getenv("S2K_MSM_NO_SMALL") != nullptr; }
 #endif
     e->pool = nullptr;
     e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;
@@ -514,8 +534,6 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     schnorr_tag_midstate(e->bip340);
     e->max_lanes = size_t(1) << 20;
     e->rp_split = 1;
-    if (const char* sp = getenv("S2K_RP_SPLIT")) e->rp_split = atoi(sp) != 0;
-    if (const char* ml = getenv("S2K_MAX_LANES")) { const size_t v = (size_t)strtoull(ml, nullptr, 10); if (v >= 256) e->max_lanes = v & ~size_t(255); }
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     {   // the side stream carries throughput-bound kernels that run NEXT TO short latency-bound ones on the main stream (k_rp_lift beside
         // k_rp_prologue): lowest priority, so that the main stream's few waves are placed first instead of queueing behind 8192 others
@@ -527,6 +545,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 32; i++) { S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][0])); S2K_CREATE_CHK(hipEventCreate(&e->ev_ring[i][1])); }
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
+    S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_last_np, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_fork, hipEventDisableTiming));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_msm_join, hipEventDisableTiming));
     S2K_CREATE_CHK(hipStreamCreateWithFlags(&e->stream_pre, hipStreamNonBlocking));
@@ -599,6 +618,7 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     }
     for (int i = 0; i < 32; i++) for (int j = 0; j < 2; j++) if (e->ev_ring[i][j]) hipEventDestroy(e->ev_ring[i][j]);
     if (e->ev_last) hipEventDestroy(e->ev_last);
+    if (e->ev_last_np) hipEventDestroy(e->ev_last_np);
     if (e->ev_msm_fork) hipEventDestroy(e->ev_msm_fork);
     if (e->ev_msm_join) hipEventDestroy(e->ev_msm_join);
     if (e->ev_rp_in) hipEventDestroy(e->ev_rp_in);
@@ -1135,6 +1155,7 @@ static int rp_host_submit_impl(s2k_engine* e, const char* who, uint64_t* ticket,
     const int ptrs = src.commit_objs != nullptr;
     const int has_extra = ptrs ? (src.extra_ptrs != nullptr) : (src.extra != nullptr && src.extra_off != nullptr);
     int si = -1;
+    const auto t_queue = std::chrono::steady_clock::now();
     for (;;) {
         const int pref = (int)(e->next_ticket & 1u);
         si = !e->stage[pref].ticket ? pref : (!e->stage[pref ^ 1].ticket ? (pref ^ 1) : -1);
@@ -1143,6 +1164,9 @@ static int rp_host_submit_impl(s2k_engine* e, const char* who, uint64_t* ticket,
         // a synchronous caller queues behind other synchronous callers (they hand their sets back by themselves); when both sets belong to
         // asynchronous tickets only the application can free one, so the call reports "busy" at once instead of stalling
         if (!e->stage[0].sync_owned && !e->stage[1].sync_owned) return s2k_fail_busy(who, "both staging sets are held by asynchronous tickets: wait for one first");
+        // (bounded: an owner stuck in a hung device wait must not block every other synchronous caller for ever -- after two minutes the
+        //  call reports "busy" and the hook's caller takes the CPU path)
+        if (std::chrono::steady_clock::now() - t_queue > std::chrono::seconds(120)) return s2k_fail_busy(who, "waited 120 s for a staging set held by another synchronous call");
         e->stage_cv.wait_for(*queue, std::chrono::seconds(1));
     }
     s2k_engine::stage_set& S = e->stage[si];
@@ -1156,7 +1180,7 @@ static int rp_host_submit_impl(s2k_engine* e, const char* who, uint64_t* ticket,
         if (has_extra) { eoff_v.resize(n + 1); eoff_v[0] = 0; for (size_t i = 0; i < n; i++) eoff_v[i + 1] = eoff_v[i] + (src.extra_ptrs[i] ? src.elens[i] : 0); eoff = eoff_v.data(); }
     }
     const size_t pbytes = (size_t)poff[n], ebytes = has_extra ? (size_t)eoff[n] : 0;
-    const bool tlog = getenv("S2K_STAGE_LOG") != nullptr;
+    const bool tlog = e->stage_log != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_begin = now();
@@ -1306,8 +1330,7 @@ static int rp_host_sync(s2k_engine* e, const char* who, int32_t* results, uint64
     {
         std::unique_lock<std::recursive_mutex> lock(e->mu);
         HIPCHK(hipSetDevice(e->device));
-        static const int allow = [] { const char* v = getenv("S2K_SYNC_SPLIT"); return v ? atoi(v) != 0 : 1; }();
-        if (allow && n >= RP_SYNC_SPLIT_MIN && !e->stage[0].ticket && !e->stage[1].ticket) parts = 2;
+        if (e->sync_split && n >= RP_SYNC_SPLIT_MIN && !e->stage[0].ticket && !e->stage[1].ticket) parts = 2;
         const size_t h = parts == 2 ? ((n / 2 + 63) & ~size_t(63)) : n;
         rp_host_src a = src, b = src;
         std::vector<uint64_t> poff_b, eoff_b;
@@ -2153,13 +2176,13 @@ static msm_coarse msm_make_coarse(size_t nt, const msm_plan& pl, const msm_layou
     C.cap_top = msm_cap_for(per_bin);
     return C;
 }
-static size_t msm_pairs_words(size_t nt, const msm_plan& pl, const msm_layout& L) {
-    if (!(pl.c > 13 || getenv("S2K_MSM_TWO_PASS"))) return 8;
+static size_t msm_pairs_words(const s2k_engine* e, size_t nt, const msm_plan& pl, const msm_layout& L) {
+    if (!(pl.c > 13 || e->msm_diag.two_pass)) return 8;
     const msm_coarse C = msm_make_coarse(nt, pl, L);
     return (size_t)pl.windows * C.nco * (size_t)std::max(C.cap, C.cap_top) + 8;
 }
-static u32 msm_run_len(size_t E, const msm_plan& pl, const msm_layout& L) {
-    if (const char* t = getenv("S2K_MSM_T")) { const int v = atoi(t); if (v >= 2 && v <= 1024) return (u32)v; }      // diagnostic override
+static u32 msm_run_len(const s2k_engine* e, size_t E, const msm_plan& pl, const msm_layout& L) {
+    if (e->msm_diag.T >= 2 && e->msm_diag.T <= 1024) return (u32)e->msm_diag.T;      // diagnostic override (-DS2K_DIAG builds)
     // small inputs (the plan keeps their bucket regions short): one lane per bucket takes the whole region, no second round
     const u32 maxcap = msm_max_cap(pl, L);
     if (maxcap <= MSM_ONE_ROUND_CAP) return maxcap;
@@ -2169,12 +2192,13 @@ static u32 msm_run_len(size_t E, const msm_plan& pl, const msm_layout& L) {
 }
 #define MSM_T2 8u
 #define MSM_DIRECT_LANES 16384u          /* lanes of the bucket-free exact path (each walks its terms with a stride) */
-static size_t msm_ws_bytes(size_t nt, const msm_plan& pl) {
+static msm_plan engine_msm_plan(const s2k_engine* e, size_t nt) { return msm_make_plan(nt, e->msm_diag.c); }
+static size_t msm_ws_bytes(const s2k_engine* e, size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
-    const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(E, pl, L);
+    const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(e, E, pl, L);
     return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
-                    msm_refs_words(pl, L) * 4, nk * 28 * 4, msm_pairs_words(nt, pl, L) * 8, (size_t)pl.windows * 520 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
+                    msm_refs_words(pl, L) * 4, nk * 28 * 4, msm_pairs_words(e, nt, pl, L) * 8, (size_t)pl.windows * 520 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
                     (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2}) + 32 * 256;
 }
 static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
@@ -2199,7 +2223,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const size_t nt = n + (g_sc ? 1 : 0);
     if (parts == 0 || part >= parts) return s2k_fail_arg("s2k_ecmult_multi", "window share out of range");
     ENGINE_GTAB(e, st);                                        // (the bucket-free exact path multiplies by G through the table)
-    msm_plan pl = msm_make_plan(nt ? nt : 1);
+    msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
     // term references are packed as (u32)(term << 2 | half << 1 | sign): refuse what those cannot index instead of wrapping silently
     if (nt >= (size_t(1) << 30) || nt * 2 * pl.windows >= (size_t(1) << 32))
         return s2k_fail("s2k_ecmult_multi", "too many terms for 32-bit bucket references (2 * windows * n >= 2^32): split the sum, partial sums add");
@@ -2234,33 +2258,33 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     const u32 nk = pl.wn * pl.nb;
     const size_t E = nt * 2 * pl.wn;                           // upper bound on this share's bucket references
     const msm_layout L = msm_make_layout(nt, pl);
-    const msm_plan full = msm_make_plan(nt);                   // (run length as msm_ws_bytes sized the buffers for: from the whole plan, not the share)
-    const u32 T = msm_run_len(nt * 2 * pl.windows, full, L), T2 = MSM_T2;
+    const msm_plan full = engine_msm_plan(e, nt);              // (run length as msm_ws_bytes sized the buffers for: from the whole plan, not the share)
+    const u32 T = msm_run_len(e, nt * 2 * pl.windows, full, L), T2 = MSM_T2;
     const size_t bound1 = (size_t)nk + E / T + 2;
     u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
     u32* gcnt = c.take<u32>(nk + 1); u32* gclamp = c.take<u32>(nk + 1); u32* spare = c.take<u32>(nk + 1);
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
     u32* tile_sum = c.take<u32>(1024); (void)spare;
     u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* buckets = c.take<u32>((size_t)nk * 28);
-    unsigned long long* pairs = c.take<unsigned long long>(msm_pairs_words(nt, pl, L)); u32* ccnt = c.take<u32>((size_t)pl.windows * 520);
+    unsigned long long* pairs = c.take<unsigned long long>(msm_pairs_words(e, nt, pl, L)); u32* ccnt = c.take<u32>((size_t)pl.windows * 520);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
     HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
     const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
     hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
-    if (const char* ck = getenv("S2K_MSM_CHUNK")) { const int v = atoi(ck); if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override
+    { const int v = e->msm_diag.chunk; if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override (-DS2K_DIAG builds)
     u32 bin_dbg = 0;
 #ifdef S2K_DIAG          /* diagnostic builds only: launches of k_msm_bin with parts switched off (results are meaningless then) */
     if (const char* bd = getenv("S2K_MSM_BIN_DEBUG")) bin_dbg = ((u32)atoi(bd) & 7u) << 24;
 #endif
-    const int two_pass = (pl.c > 13 || getenv("S2K_MSM_TWO_PASS")) && !getenv("S2K_MSM_ONE_PASS");
+    const int two_pass = (pl.c > 13 || e->msm_diag.two_pass) && !e->msm_diag.one_pass;
     if (two_pass) {
         const msm_coarse C = msm_make_coarse(nt, pl, L);
         HIPCHK(hipMemsetAsync(ccnt, 0, (size_t)pl.wn * C.nco * 4, st));
         hipLaunchKernelGGL(k_msm_bin_coarse, dim3((unsigned)((nt + MSM_COARSE_TERMS - 1) / MSM_COARSE_TERMS)), dim3(MSM_BIN_THREADS), 0, st, pairs, ccnt, flags, halves, nt, pl, L, C);
         hipLaunchKernelGGL(k_msm_bin_fine, dim3(C.nco, pl.wn), dim3(MSM_FINE_THREADS), 0, st, refs_cap, gcnt, flags, (const unsigned long long*)pairs, (const u32*)ccnt, pl, L, C);
-    } else if (pl.c <= 13 && nt >= (size_t(1) << 15) && !getenv("S2K_MSM_BIN_PLAIN")) {
+    } else if (pl.c <= 13 && nt >= (size_t(1) << 15) && !e->msm_diag.bin_plain) {
         hipLaunchKernelGGL(k_msm_bin_staged, dim3((unsigned)((nt + MSM_STAGED_TERMS - 1) / MSM_STAGED_TERMS), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L);
     } else if (pl.c > 13) hipLaunchKernelGGL(k_msm_bin<1>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
     else hipLaunchKernelGGL(k_msm_bin<0>, dim3((unsigned)((nt + chunk - 1) / chunk), pl.wn), dim3(MSM_BIN_THREADS), 0, st, refs_cap, gcnt, flags, halves, nt, pl, L, chunk | bin_dbg);
@@ -2271,7 +2295,7 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
     hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, X.side, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, direct_ptab, n, nt, pl);
     const u32* ex = launch_gej_reduce(X.side, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
     HIPCHK(hipEventRecord(X.join, X.side));
-    if (msm_max_cap(full, L) <= MSM_ONE_ROUND_CAP && !getenv("S2K_MSM_NO_SMALL")) {
+    if (msm_max_cap(full, L) <= MSM_ONE_ROUND_CAP && !e->msm_diag.no_small) {
         const u32 nchunks = (pl.nb - 1 + 255) / 256;
         hipLaunchKernelGGL(k_msm_small_windows, dim3(nchunks, pl.wn), dim3(256), 0, st, partA, refs_cap, gcnt, term, pl, L, nchunks);
         const u32* wsum = launch_gej_reduce(st, partA, bufA, bufB, pl.wn, nchunks);
@@ -2321,8 +2345,8 @@ static int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result2
 static int msm_pipelined(s2k_engine* e, hipStream_t st, int finish, uint32_t* out28, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
                          const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
     const size_t nt = n + (g_sc ? 1 : 0);
-    const msm_plan pl = msm_make_plan(nt ? nt : 1);
-    const size_t need = msm_ws_bytes(nt + 1, pl);
+    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
+    const size_t need = msm_ws_bytes(e, nt + 1, pl);
     const unsigned si = e->msm_seq++ & 1u;
     auto& S = e->msm_slot[si];
     if (need > S.ws_bytes) {
@@ -2333,9 +2357,12 @@ static int msm_pipelined(s2k_engine* e, hipStream_t st, int finish, uint32_t* ou
         HIPCHK(hipMalloc((void**)&S.ws, bytes));
         S.ws_bytes = bytes;
     }
-    // the slot's streams are not the caller's: work of an earlier call of another kind (it may share the engine's table arena with this
-    // call's exact path) must be over first; consecutive pipelined MSM calls do not wait for each other -- that is the point
-    if (!e->prev_pipe && e->last_stream_valid) HIPCHK(hipStreamWaitEvent(S.s, e->ev_last, 0));
+    // the slot's streams are not the caller's: work of an earlier call of another kind (it shares the engine's table arena with this
+    // call's exact path) must be over first -- EVERY slot waits once for the latest such call (its epoch), not only the slot that happens to
+    // run right behind it; consecutive pipelined MSM calls do not wait for each other -- that is the point.  The caller's inputs: ordered
+    // behind the caller's stream unless the caller has promised that they are complete (S2K_OPT_RP_INPUTS_READY).
+    if (e->np_valid && S.seen_epoch != e->np_epoch) { HIPCHK(hipStreamWaitEvent(S.s, e->ev_last_np, 0)); S.seen_epoch = e->np_epoch; }
+    if (!e->rp_inputs_ready) { HIPCHK(hipEventRecord(S.in, st)); HIPCHK(hipStreamWaitEvent(S.s, S.in, 0)); }
     e->cur_pipe = 1;
     const msm_ctx ctx{S.s2, S.fork, S.join, 1u + si};
     ws_carver c{S.ws, 0}; u32* res = nullptr;
@@ -2357,9 +2384,9 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
-    if (e->rp_inputs_ready && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
-    const msm_plan pl = msm_make_plan(nt ? nt : 1);
-    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
+    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], st));
     if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
@@ -2375,8 +2402,8 @@ extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, 
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
-    const msm_plan pl = msm_make_plan(nt ? nt : 1);
-    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], st));
     if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n, part, parts)) return 0;
@@ -2392,9 +2419,9 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
-    if (e->rp_inputs_ready && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
-    const msm_plan pl = msm_make_plan(nt ? nt : 1);
-    if (!engine_workspace(e, msm_ws_bytes(nt + 1, pl))) return 0;
+    if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
+    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
+    if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], st));
     if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
@@ -2425,9 +2452,9 @@ extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
     const size_t nt = n + (g_sc ? 1 : 0);
-    const msm_plan pl = msm_make_plan(nt ? nt : 1);
+    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
     // the staged inputs come first in the workspace, the MSM passes carve what follows
-    if (!engine_workspace(e, ws_need({32 * n + 64, 64 * n + 64, n + 64, 64, 64, 16}) + msm_ws_bytes(nt + 1, pl))) return 0;
+    if (!engine_workspace(e, ws_need({32 * n + 64, 64 * n + 64, n + 64, 64, 64, 16}) + msm_ws_bytes(e, nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0};
     unsigned char* d_sc = c.take<unsigned char>(32 * n + 64); unsigned char* d_pt = c.take<unsigned char>(64 * n + 64); unsigned char* d_inf = c.take<unsigned char>(n + 64);
     unsigned char* d_g = c.take<unsigned char>(64); unsigned char* d_r = c.take<unsigned char>(64); int32_t* d_ri = c.take<int32_t>(4);
@@ -2894,9 +2921,9 @@ __global__ void k_ha_final(int32_t* result, const u32* flags, const u32* res28) 
     if (threadIdx.x || blockIdx.x) return;
     *result = (flags[0] == 0u) && (res28[27] != 0u);
 }
-static size_t ha_ws_bytes(size_t n) {
+static size_t ha_ws_bytes(const s2k_engine* e, size_t n) {
     const size_t nblocks = (3 * n) >> 1, nt = 2 * n + 1;
-    return ws_need({128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16}) + msm_ws_bytes(nt + 1, msm_make_plan(nt));
+    return ws_need({128 * n + 64, 32 * n + 64, nblocks * 256 + 64, nblocks * 32 + 64, 64 * n + 64, 64, 64, 16}) + msm_ws_bytes(e, nt + 1, engine_msm_plan(e, nt));
 }
 // The randomizer hash's chain on the host (host_sha256.h): state after every full 64-byte block of r_0|x(P_0)|m_0|r_1|..., into pinned
 // memory.  pk_format 0: the serialised key IS x(P_i) (a key that does not parse makes the verdict 0 whatever is hashed); 1: the object's
@@ -2969,7 +2996,7 @@ extern "C" int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, i
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) { HIPCHK(hipMemsetAsync(result_dev, 0, 4, st)); return 1; }     // main_impl.h:122-125
-    if (!engine_workspace(e, ha_ws_bytes(n))) return 0;
+    if (!engine_workspace(e, ha_ws_bytes(e, n))) return 0;
     ws_carver c{e->ws, 0};
     return ha_launch(e, st, c, result_dev, pubkeys, pk_format, msgs32, n, aggsig);
 }
@@ -2983,8 +3010,8 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     HIPCHK(hipSetDevice(e->device));
     const size_t pkb = pk_format ? 64 : 32;
     const size_t io = ws_need({pkb * n + 64, 32 * n + 64, 32 * (n + 1), 16});
-    if (!engine_workspace(e, ha_ws_bytes(n) + io)) return 0;
-    ws_carver c0{e->ws, ha_ws_bytes(n)};
+    if (!engine_workspace(e, ha_ws_bytes(e, n) + io)) return 0;
+    ws_carver c0{e->ws, ha_ws_bytes(e, n)};
     unsigned char* d_pk = c0.take<unsigned char>(pkb * n + 64); unsigned char* d_msg = c0.take<unsigned char>(32 * n + 64);
     unsigned char* d_agg = c0.take<unsigned char>(32 * (n + 1)); int32_t* d_res = c0.take<int32_t>(4);
     hipStream_t st = e->stream;
@@ -2995,7 +3022,7 @@ extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result
     }
     HIPCHK(hipMemcpyAsync(d_agg, aggsig, 32 * (n + 1), hipMemcpyHostToDevice, st));
     ws_carver c{e->ws, 0};
-    static const int host_chain = [] { const char* v = getenv("S2K_HALFAGG_HOST_CHAIN"); return v ? atoi(v) != 0 : 1; }();      // 0: the device chain (same verdicts; tests)
+    const int host_chain = e->halfagg_host_chain;      // S2K_OPT_HALFAGG_HOST_CHAIN 0: the device chain (same verdicts; tests)
     const ha_host_src hsrc{aggsig, pubkeys, pk_format, msgs32};
     if (!ha_launch(e, st, c, d_res, d_pk, pk_format, d_msg, n, d_agg, host_chain ? &hsrc : nullptr)) return 0;
     HIPCHK(hipMemcpyAsync(result, d_res, 4, hipMemcpyDeviceToHost, st));
@@ -3101,6 +3128,11 @@ extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
     switch (option) {
     case S2K_OPT_RP_INPUTS_READY: e->rp_inputs_ready = value != 0; return 1;
     case S2K_OPT_RP_SPLIT: e->rp_split = value != 0; return 1;
+    case S2K_OPT_MSM_PIPELINE: e->msm_pipeline = value != 0; return 1;
+    case S2K_OPT_MAX_LANES: if (value < 256) return s2k_fail_arg("s2k_engine_set_option", "S2K_OPT_MAX_LANES needs at least 256 lanes"); e->max_lanes = (size_t)value & ~size_t(255); return 1;
+    case S2K_OPT_STAGE_THREADS: if (value < 1 || value > 64) return s2k_fail_arg("s2k_engine_set_option", "S2K_OPT_STAGE_THREADS: 1..64"); e->stage_threads = (int)value; return 1;
+    case S2K_OPT_HALFAGG_HOST_CHAIN: e->halfagg_host_chain = value != 0; return 1;
+    case S2K_OPT_SYNC_SPLIT: e->sync_split = value != 0; return 1;
     case S2K_OPT_GEN_CACHE_SLOTS: {                             // (the cache belongs to the device: every engine on it sees the change)
         s2k_dev_pool* p = e->pool;
         std::lock_guard<std::recursive_mutex> pool_lock(p->mu);
@@ -3344,7 +3376,7 @@ static int group_msm(s2k_group* g, const char* who, unsigned char* r_xy, int32_t
             if (!resident) {
                 // slice to HBM: behind the MSM's own workspace need (s2k_ecmult_multi_partial_dev carves from the start)
                 const size_t nt = m + (gs ? 1 : 0);
-                const size_t base = ws_need({28 * 4}) + msm_ws_bytes(nt + 1, msm_make_plan(nt ? nt : 1));
+                const size_t base = ws_need({28 * 4}) + msm_ws_bytes(e, nt + 1, engine_msm_plan(e, nt ? nt : 1));
                 if (!engine_workspace(e, base + ws_need({32 * m + 64, 64 * m + 64, m + 64, 64}))) return 0;
                 ws_carver c{e->ws, base};
                 unsigned char* a = c.take<unsigned char>(32 * m + 64); unsigned char* b = c.take<unsigned char>(64 * m + 64); unsigned char* ci = c.take<unsigned char>(m + 64);

@@ -85,7 +85,7 @@ static inline msm_plan msm_plan_for(u32 c) {
 // 7) whose bucket regions are short enough for ONE round of partial sums (a lane per bucket walks its whole region: no counts / scan /
 // second and third round), which also means fewer windows for the Horner tail.  In between: measured (profiles/r03c_msm_c_sweep.txt).
 #define MSM_ONE_ROUND_CAP 40u
-static inline msm_plan msm_make_plan(size_t n_terms) {
+static inline msm_plan msm_make_plan(size_t n_terms, int c_override = 0) {
     u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n_terms) lg++;
     int c = (int)lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
     if (lg <= 13) {
@@ -94,9 +94,7 @@ static inline msm_plan msm_make_plan(size_t n_terms) {
     } else if (lg <= 15) c = 10;
     else if (lg <= 17) c = 12;
     else if (lg >= 22) c = 16;      // 9 windows, the ninth only holds the carries: 8.2 bucket additions per half-scalar instead of 10 (k_msm_bin<1>)
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (const char* o = getenv("S2K_MSM_C")) { const int v = atoi(o); if (v >= 4 && v <= 16) c = v; }      // diagnostic override
-#endif
+    if (c_override >= 4 && c_override <= 16) c = c_override;      // diagnostic override (the engine reads $S2K_MSM_C once, in -DS2K_DIAG builds only)
     if (c > 13) {                   // the wide binning pass packs region offsets into 16 bits
         const msm_plan p = msm_plan_for((u32)c); const msm_layout L = msm_make_layout(n_terms, p);
         if (L.cap >= 32768u || L.cap_top >= 32768u) c = 13;

@@ -203,9 +203,11 @@ def test_msm_on_reference_generated_points(engine, ref):
 
 
 def test_two_calls_in_flight(ref):
-    """S2K_OPT_RP_INPUTS_READY lets s2k_ecmult_multi_dev keep two calls in flight (two stream / workspace sets, the caller's stream waits for
-    each result): a queue of different sums -- sizes around the plan switches, one with a skewed scalar set that takes the exact path --
-    interleaved with calls of another kind gives, output by output, the reference's results."""
+    """S2K_OPT_MSM_PIPELINE lets s2k_ecmult_multi_dev keep two calls in flight (two stream / workspace sets, the caller's stream waits for
+    each result): a queue of different sums -- sizes around the plan switches, two with a skewed scalar set that takes the exact path --
+    interleaved with calls of another kind gives, output by output, the reference's results; with and without the inputs-ready promise.
+    The queue starts behind a LARGE batch of another kind that is still running (its lanes use the table arena the slots' exact paths
+    use): the second pipelined call -- the skewed one, on the other slot -- must wait for it too."""
     import torch
     from secp256k1_zkp_amd import Engine
     rng = np.random.default_rng(2024)
@@ -218,9 +220,9 @@ def test_two_calls_in_flight(ref):
         pts, _ = eng.ecmult_batch(np.tile(Gpt, (nmax, 1)), np.zeros((nmax, 32), np.uint8), ng=ks)
         pts[::5] = np.frombuffer(ref.rand_point(rng), np.uint8)
         jobs = []
-        for n in (40, 700, 5000, 20000, 33000, 70000, 300, 66000):
+        for n in (40, 3000, 700, 5000, 20000, 33000, 70000, 300, 66000):
             sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-            if n == 33000:
+            if n in (3000, 33000):
                 sc[:] = sc[0]                                               # one scalar for every term: bucket regions overflow -> exact path
             jobs.append((n, sc, ref.ecmult_multi(sc, pts[:n])))
         d_pts = torch.tensor(pts).to(dev)
@@ -228,22 +230,35 @@ def test_two_calls_in_flight(ref):
         outs = [(torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)) for _ in jobs]
         c, p, g, _ = ref.make_rangeproofs(8, rng, min_bits=16)
         want_rp = ref.rangeproof_verify_many(c, p, g)
+        # the large batch of another kind: 60 000 double multiplications (more lanes than one exact-path arena), queued, not waited for
+        nx = 60000
+        xa = pts[:nx].copy(); xna = rng.integers(0, 256, (nx, 32), dtype=np.uint8); xng = rng.integers(0, 256, (nx, 32), dtype=np.uint8)
+        want_x, want_xi = ref.ecmult_batch(xa, xna, xng)
+        d_xa, d_xna, d_xng = (torch.tensor(v).to(dev) for v in (xa, xna, xng))
+        d_xr = torch.zeros(nx, 64, dtype=torch.uint8, device=dev); d_xi = torch.zeros(nx, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        eng.set_option(Engine.OPT_RP_INPUTS_READY, 1)
-        for rep in range(2):
+        eng.set_option(Engine.OPT_MSM_PIPELINE, 1)
+        for rep in range(3):
+            eng.set_option(Engine.OPT_RP_INPUTS_READY, 1 if rep < 2 else 0)
+            if rep == 0:
+                eng.ecmult_batch_dev(d_xr, d_xi, d_xa, d_xna, d_xng)
             for i, (n, _, _) in enumerate(jobs):
                 eng.ecmult_multi_dev(outs[i][0], outs[i][1], d_sc[i], d_pts[:n])
                 if i == 3 and rep == 1:
                     assert np.array_equal(eng.rangeproof_verify_batch(c, p, g)[0], want_rp[0])      # another kind of call in between
             eng.sync()
+            if rep == 0:
+                assert np.array_equal(d_xi.cpu().numpy() != 0, np.asarray(want_xi) != 0) and np.array_equal(d_xr.cpu().numpy(), want_x), "the batch running under the pipelined sums was disturbed"
             for i, (n, _, (wxy, winf)) in enumerate(jobs):
                 assert int(outs[i][1].item()) == winf and bytes(outs[i][0].cpu().numpy()) == wxy.tobytes(), (rep, n)
-        eng.set_option(Engine.OPT_RP_INPUTS_READY, 0)
+                outs[i][0].zero_(); outs[i][1].zero_()
+            torch.cuda.synchronize()
+        eng.set_option(Engine.OPT_RP_INPUTS_READY, 0); eng.set_option(Engine.OPT_MSM_PIPELINE, 0)
     finally:
         eng.close()
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("S2K_TEST_LONG"), reason="2^24 terms through the reference take about a minute of one host core: S2K_TEST_LONG=1")
+@pytest.mark.skipif(__import__("os").environ.get("S2K_TEST_SHORT") == "1", reason="S2K_TEST_SHORT=1 (builder's quick runs): 2^24 terms through the reference take about a minute of one host core")
 def test_2p24_terms_against_ecmult_multi_var(engine, ref):
     """the largest size bench.py times (c = 16, two-pass binning), against secp256k1_ecmult_multi_var itself rather than the (sum s_i k_i)*G identity"""
     rng = np.random.default_rng(2424)

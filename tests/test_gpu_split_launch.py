@@ -1,5 +1,5 @@
 """GPU: batches larger than the engine's lanes-per-launch cap run as several launches over sub-ranges that reuse the same
-per-lane table arena and scratch records.  An engine created with a tiny cap ($S2K_MAX_LANES=512: 16 rangeproofs / 512
+per-lane table arena and scratch records.  An engine created with a tiny cap (S2K_OPT_MAX_LANES = 512: 16 rangeproofs / 512
 signatures per launch) must reproduce the reference (and therefore the default engine) item for item, in order, with ragged
 offsets and failing items straddling the chunk boundaries."""
 import os
@@ -13,11 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def small_engine(engine):
     from secp256k1_zkp_amd import Engine
-    os.environ["S2K_MAX_LANES"] = "512"
-    try:
-        return Engine(0)
-    finally:
-        del os.environ["S2K_MAX_LANES"]
+    e = Engine(0)
+    e.set_option(Engine.OPT_MAX_LANES, 512)
+    return e
 
 
 def test_ecmult_and_schnorr_split(small_engine, ref):
