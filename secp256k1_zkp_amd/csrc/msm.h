@@ -41,7 +41,7 @@
 // the shares simply add up.
 struct msm_plan { u32 c; u32 windows; u32 nb; u32 w0; u32 wn; };
 
-// Fixed-capacity bucket regions (binning pass, engine.hip): see k_msm_bin.  top_used: buckets 0..top_used-1 of the top window have a
+// Fixed-capacity bucket regions (binning pass, engine_msm.hip): see k_msm_bin.  top_used: buckets 0..top_used-1 of the top window have a
 // region; sub: power of two (every value of the top window is spread over `sub` buckets).
 struct msm_layout { u32 cap, cap_top, top_used, sub; };     // top_used: buckets 0..top_used-1 of the top window have a region; sub: power of two
 // bucket-region capacity of the fixed-capacity layout: the mean load plus ten standard deviations of a uniform digit

@@ -91,7 +91,7 @@ S2K_HD void rp_load_scalar_words(scalar& s, const u32* w8) { int ov; rp_words_to
 // rp_rewind_draws: the replay of the prover's RFC 6979 stream -- the ring nonces ("secs", [32][8] words) and the pad of every ring
 // position ("prep", [128][8] words).  It needs the nonce, the commitment, the generator and the proof's header only, NOT the outcome
 // of the verification, and it is a serial chain of ~1 500 SHA-256 compressions: the engine runs it on a side stream underneath the
-// rings kernel (engine.hip, rp_launch).
+// rings kernel (engine_rangeproof.hip, rp_launch).
 S2K_HD void rp_rewind_draws(const rp_rec& rec, const unsigned char* proof, const unsigned char* nonce32, const unsigned char* gen64, u32* prep, u32* secs) {
     const u32 rings = rec.rings, last = rec.last_rsize;
     rp_drbg rng;

@@ -145,7 +145,7 @@ def test_rangeproof_dev_calls_in_flight(engine, ref):
 
 def test_dev_calls_on_two_streams_share_the_scratch_safely(engine, ref):
     """The workspace and the table arena are per engine: `_dev` calls issued alternately on two caller streams must be ordered by the
-    engine itself (stream_guard in engine.hip), so that each result equals the reference's whatever the interleaving."""
+    engine itself (stream_guard in csrc/engine_internal.h), so that each result equals the reference's whatever the interleaving."""
     import torch
     from tests.refapi import G_XY
     rng = np.random.default_rng(5)

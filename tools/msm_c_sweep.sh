@@ -1,3 +1,4 @@
+# (needs a -DS2K_DIAG build: python -m secp256k1_zkp_amd.build_lib -o /tmp/libs2k_diag.so -DS2K_DIAG; export S2K_LIB=/tmp/libs2k_diag.so)
 # MSM time through the device entry point against the window width (S2K_MSM_C overrides msm_make_plan's choice): bash tools/msm_c_sweep.sh
 # -> what msm.h's plan was picked from (profiles/r03c_msm_c_sweep.txt)
 cd ${GRAFT_REPO_ROOT:-/root/repo}

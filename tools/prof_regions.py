@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Region attribution of k_rp_rings (diagnostic): build engine.hip with -DS2K_PROF into a side library, run one 2^14 batch,
+"""Region attribution of k_rp_rings (diagnostic): build the library with -DS2K_PROF into a side library, run one 2^14 batch,
 print the share of wave-cycles spent in each region of a ring step.
     python tools/prof_regions.py            (on the GPU box)
 """
@@ -9,8 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.environ.get("S2K_LIB") or os.path.join(ROOT, "secp256k1_zkp_amd", "libsecp256k1_zkp_amd_prof.so")   # S2K_LIB: a -DS2K_PROF build made elsewhere
 if not os.path.exists(lib):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-DS2K_PROF",
-                           "-fvisibility=hidden", "-o", lib, os.path.join(ROOT, "secp256k1_zkp_amd", "csrc", "engine.hip")])
+    subprocess.check_call([sys.executable, "-m", "secp256k1_zkp_amd.build_lib", "-o", lib, "-DS2K_PROF"], cwd=ROOT)
 os.environ["S2K_LIB"] = lib
 import torch
 from secp256k1_zkp_amd import Engine, _native

@@ -2,7 +2,7 @@
 """Diagnostic: wall time of the parts of the shared-generator rings kernel, by launching it with parts switched off ($S2K_RP_DEBUG bits:
 1 = no 2^64 chain, 2 = no table construction, 4 = no steps; results are meaningless in those launches).  The knob only exists in a
 -DS2K_DIAG build of the library (the product library ignores the environment): build one and point S2K_LIB at it, on the GPU box:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fvisibility=hidden -DS2K_DIAG -o /tmp/libs2k_diag.so secp256k1_zkp_amd/csrc/engine.hip
+    python -m secp256k1_zkp_amd.build_lib -o /tmp/libs2k_diag.so -DS2K_DIAG
     S2K_LIB=/tmp/libs2k_diag.so python tools/rings_parts.py [n]"""
 import os, sys, json
 import numpy as np
