@@ -421,7 +421,8 @@ k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* cnt_in, 
     // bucket k's references: its region of the fixed-capacity layout
     const size_t first = msm_region(L, pl, k / pl.nb, k % pl.nb); (void)off_in;
     const size_t start = first + (size_t)j * T, end = min(start + T, first + cnt_in[k]);
-    gej o; msm_sum_refs(o, refs, start, end, term);
+    gej o;
+    if (!msm_sum_refs_lean(o, refs, start, end, term)) msm_sum_refs(o, refs, start, end, term);      // (exceptional additions: adversarial inputs only)
     gej_store28(out28 + (size_t)m * 28, o);
 }
 __global__ void __launch_bounds__(256, 2)
@@ -460,7 +461,8 @@ k_msm_small_windows(u32* out28, const u32* refs, const u32* gcnt, const u32* ter
         u32 cnt = gcnt[k]; cnt = cnt < cap ? cnt : cap;            // (an overflowing region raised the flag: the result comes from the exact path)
         if (cnt) {
             const size_t first = msm_region(L, pl, w, b);
-            gej v; msm_sum_refs(v, refs, first, first + cnt, term);
+            gej v;
+            if (!msm_sum_refs_lean(v, refs, first, first + cnt, term)) msm_sum_refs(v, refs, first, first + cnt, term);
             msm_scale(o, v, msm_bucket_weight(L, pl, k));
         }
     }

@@ -295,6 +295,64 @@ S2K_HD void msm_sum_refs(gej& out, const u32* refs, size_t start, size_t end, co
     }
     gej_set_gez(out, acc);
 }
+// ---- the lean form of the same accumulation (round 5) --------------------------------------------------------------------------------
+// No case analysis per addition.  An exceptional addition (the operand has the accumulator's x: P + P or P - P) makes P = U2 - X1 == 0,
+// hence ZZ3 = ZZ * P^2 == 0 -- and ZZ then STAYS 0 through every later addition of the run (a product with a zero factor), while a run
+// without one keeps ZZ != 0 (a product of non-zero field elements).  So one zero test of ZZ at the END of a run tells whether any of its
+// additions was exceptional, and only then is the run summed again by the exact form above (adversarial inputs only: equal or opposite
+// points in one bucket).  Besides the two zero tests this drops the sequential carry passes (P and R only need a weak normalisation as
+// inputs of the squarings) and pays ONE reduction for Y3 = R (Q - X3) - Y1 PPP (fe_muladd).  Static count of round 1's loop body: 1 956 ->
+// 1 5xx VALU instructions per bucket addition.
+// Magnitudes: a.x, a.y, a.zz, a.zzz 1 on entry and on exit; b.x 1, b.y <= 2.
+S2K_HD void gez_add_ge_lean(gez& a, const ge& b) {
+    fe u2, s2, p, r;
+    fe_mul2(u2, b.x, a.zz, s2, b.y, a.zzz);
+    fe_neg(p, a.x, 1); fe_add(p, u2); fe_norm_weak(p);          // P = U2 - X1      (3 -> 1)
+    fe_neg(r, a.y, 1); fe_add(r, s2); fe_norm_weak(r);          // R = S2 - Y1      (3 -> 1)
+    fe pp, rr, ppp, q;
+    fe_sqr2(pp, p, rr, r);
+    fe_mul2(ppp, p, pp, q, a.x, pp);
+    fe x3, nq, t1, ny;
+    fe_neg(x3, ppp, 1); fe_neg(nq, q, 1);
+    fe_add(x3, nq); fe_add(x3, nq); fe_add(x3, rr);             // X3 = R^2 - PPP - 2Q (7)
+    fe_norm_weak(x3);
+    fe_neg(t1, x3, 1); fe_add(t1, q);                           // Q - X3           (3)
+    fe_neg(ny, a.y, 1);                                         // -Y1              (2)
+    fe_muladd<false, false>(a.y, r, t1, ny, ppp);               // Y3 = R (Q - X3) - Y1 PPP: 1*3 + 2*1 = 5 <= 7, one reduction
+    fe_mul2(a.zz, a.zz, pp, a.zzz, a.zzz, ppp);
+    a.x = x3;
+}
+// the operand a bucket reference names: (x or beta*x, +-y) of its term record
+S2K_HD void msm_ref_point(ge& p, u32 r, const u32* term_data) {
+    const u32* t = term_data + (size_t)(r >> 2) * MSM_TERM_WORDS;
+    const u32* tx = t + ((r >> 1) & 1u) * 9u;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p.x.n[i] = tx[i]; p.y.n[i] = t[18 + i]; }
+    if (r & 1u) fe_neg(p.y, p.y, 1);
+}
+// returns 1 with the run's sum in `out`; 0 when the run met an exceptional addition (the caller sums it again with msm_sum_refs)
+S2K_HD int msm_sum_refs_lean(gej& out, const u32* refs, size_t start, size_t end, const u32* term_data) {
+    if (start >= end) { gej_set_infinity(out); return 1; }
+    gez acc; acc.inf = 0;
+    { ge p; msm_ref_point(p, refs[start], term_data); fe_norm_weak(p.y); acc.x = p.x; acc.y = p.y; fe_set_int(acc.zz, 1); fe_set_int(acc.zzz, 1);
+      // (opaque to the optimiser: knowing that ZZ = ZZZ = 1 on entry, ROCm 7.2's clang specialises the loop's accumulator chains on the
+      //  zero limbs of the first trip and the WHOLE loop body grows from 1 595 to 1 983 instructions -- 126 more multiply-accumulates
+      //  and 270 more moves per addition, found with tools/static_count/loops.py)
+#pragma unroll
+      for (int i = 0; i < 9; i++) { S2K_OPAQUE(acc.zz.n[i]); S2K_OPAQUE(acc.zzz.n[i]); } }
+    // the operand of addition j + 1 is requested before the arithmetic of addition j
+    ge nxt; u32 have = 0;
+    if (start + 1 < end) { msm_ref_point(nxt, refs[start + 1], term_data); have = 1; }
+    for (size_t j = start + 1; j < end; j++) {
+        const ge cur = nxt;
+        if (j + 1 < end) msm_ref_point(nxt, refs[j + 1], term_data);
+        gez_add_ge_lean(acc, cur);
+    }
+    (void)have;
+    if (fe_normalizes_to_zero(acc.zz)) return 0;
+    gej_set_gez(out, acc);
+    return 1;
+}
 // weight * acc, weight < 2^16  (the bucket's index)
 S2K_HD void msm_scale(gej& out, const gej& in, u32 weight) {
     gej r; gej_set_infinity(r);

@@ -271,6 +271,8 @@ int emu_schnorr_verify(const unsigned char* sig64, const unsigned char* msg, siz
 
 // the bucket MSM of msm.h run sequentially (force_c > 0 overrides the window width) for share `part` of `parts` of the windows;
 // leaves the share's Jacobian partial in out28
+static unsigned long g_msm_lean_refused = 0;       // runs the lean accumulation handed back (exceptional additions) since the library was loaded
+unsigned long emu_msm_lean_refused(void) { return g_msm_lean_refused; }
 static int emu_msm_core(u32* out28, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* inf, size_t n, int force_c,
                         u32 part, u32 parts) {
     const size_t nt = n + (g_sc ? 1 : 0);
@@ -307,7 +309,13 @@ static int emu_msm_core(u32* out28, const unsigned char* g_sc, const unsigned ch
         const u32 w = pl.w0 + wl;
         gej s; gej_set_infinity(s);
         for (u32 b = 1; b < pl.nb; b++) {
-            gej v, o; msm_sum_refs(v, refs.data(), off[w * pl.nb + b], off[w * pl.nb + b + 1], term.data()); msm_scale(o, v, b);
+            gej v, o;
+            // the lean form first, the exact form when it reports an exceptional addition -- as k_msm_round1 does; and the two must agree
+            // on every run the lean form accepts
+            const int lean_ok = msm_sum_refs_lean(v, refs.data(), off[w * pl.nb + b], off[w * pl.nb + b + 1], term.data());
+            { gej v2; msm_sum_refs(v2, refs.data(), off[w * pl.nb + b], off[w * pl.nb + b + 1], term.data());
+              if (lean_ok) { gej nv2 = v2, d; if (!v2.inf) { fe_norm_weak(nv2.y); fe_neg(nv2.y, nv2.y, 1); fe_norm_weak(nv2.y); } gej_add_var(d, v, nv2); if (!d.inf || v.inf != v2.inf) return -3; } else { g_msm_lean_refused++; v = v2; } }
+            msm_scale(o, v, b);
             gej t; gej_add_var(t, s, o); s = t;
         }
         gej_store28_h(wsum.data() + 28 * wl, s);

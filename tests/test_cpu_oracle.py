@@ -305,6 +305,27 @@ def test_emu_msm(emu, ref):
         assert i1 == i2 and r1.tobytes() == out.raw, (n, g, c)
 
 
+def test_emu_msm_lean_accumulation_hands_back_exceptional_runs(emu, ref):
+    """the lean bucket accumulation (msm.h: no case analysis per addition, one zero test of ZZ per run) must refuse exactly the runs that
+    meet P + P or P - P -- equal / opposite points with equal digits in one bucket -- and the exact form then gives the reference's sum"""
+    rng = np.random.default_rng(77)
+    emu.emu_msm_lean_refused.restype = ctypes.c_ulong
+    P_FIELD = P
+    A = np.frombuffer(ref.rand_point(rng), np.uint8); Q = np.frombuffer(ref.rand_point(rng), np.uint8)
+    negA = A.copy(); y = (P_FIELD - int.from_bytes(A[32:].tobytes(), "big")) % P_FIELD; negA[32:] = np.frombuffer(y.to_bytes(32, "big"), np.uint8)
+    k = rng.integers(0, 256, 32, dtype=np.uint8); k2 = rng.integers(0, 256, 32, dtype=np.uint8)
+    for pts, scs in (([A, A, Q], [k, k, k2]), ([A, negA, Q], [k, k, k2]), ([A, A, A, negA, Q, Q], [k, k, k, k, k2, k2]), ([A, negA], [k, k])):
+        n = len(pts)
+        Pn = np.stack(pts); S = np.stack(scs)
+        r1, i1 = ref.ecmult_multi(S, Pn, None, np.zeros(n, np.uint8))
+        for c in (0, 4, 9):
+            before = emu.emu_msm_lean_refused()
+            out = ctypes.create_string_buffer(64)
+            i2 = emu.emu_msm(out, None, S.tobytes(), Pn.tobytes(), bytes(n), ctypes.c_size_t(n), c)
+            assert i2 >= 0 and i1 == i2 and (i1 or r1.tobytes() == out.raw), (n, c, i2)
+            assert emu.emu_msm_lean_refused() > before, "equal / opposite points in one bucket must be handed back to the exact form"
+
+
 def test_msm_digit_forms_agree(emu):
     """msm.h's three ways to the signed window digits of a half-scalar (carry recurrence; one window from its own constant; all windows
     from one addition, the binning pass's form) give the same digits for every width the plans use, and the digits add up to the value."""
