@@ -550,6 +550,13 @@ def main():
     from secp256k1_zkp_amd import Engine
     eng = Engine(local)
     torch.cuda.set_device(local)
+    # the device's fixed-base table of G, built now (first use) so that its cost is a line of the record rather than part of a warm-up step
+    import ctypes
+    t_tab = time.perf_counter(); tab_sz = ctypes.c_size_t(0)
+    assert eng._lib.s2k_engine_gtable(eng._h, ctypes.byref(tab_sz)), "no generator table"
+    tables = {"digit_bits": int(eng._lib.s2k_engine_gtable_bits(eng._h)), "bytes_per_table": int(tab_sz.value),
+              "first_use_ms_incl_allocation": (time.perf_counter() - t_tab) * 1e3,
+              "note": "table of G: allocated and built on the device by the first call that needs it (csrc/gtable.h: seeds + one affine addition per entry with shared inversions)"}
     n = args.batch
     dev = torch.device("cuda", local)
     if world > 1 and n % world == 0:
@@ -864,6 +871,7 @@ def main():
         # (input signing by the reference, table builds, the CPU baselines) -- a GPU-busy sampler around the whole process sees mostly idle
         out["timing"] = {"timed_region_s": dt, "timed_region_serialized_calls_s": dt_ser, "timed_steps": args.steps,
                          "process_wall_s_until_headline": time.time() - t_process}
+        out["tables"] = tables
         if msm:
             out["msm"] = msm
         if dropin:

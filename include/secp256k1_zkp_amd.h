@@ -71,7 +71,7 @@ S2K_API void s2k_clear_status(void);
  *   underneath the point-lifting kernel (0: on the device; same verdicts).
  * S2K_OPT_SYNC_SPLIT (default 1): a lone synchronous host-buffer rangeproof call that finds both staging sets free goes as two halves.
  * Environment: only start-up defaults are read from it, once, when an engine (or the device's table pool) is created: S2K_DEVICE,
- * S2K_GEN_CACHE, S2K_GEN_CACHE_MIN, S2K_STAGE_THREADS.  Nothing on a call path reads the environment. */
+ * S2K_GEN_CACHE, S2K_GEN_CACHE_MIN, S2K_STAGE_THREADS, S2K_GTAB_BITS.  Nothing on a call path reads the environment. */
 #define S2K_OPT_RP_INPUTS_READY 1
 #define S2K_OPT_RP_SPLIT 2
 #define S2K_OPT_GEN_CACHE_SLOTS 3
@@ -97,6 +97,12 @@ S2K_API int s2k_engine_reserve(s2k_engine* e, size_t n_items);
 S2K_API int s2k_engine_sync(s2k_engine* e);
 /* Device pointer + size (bytes) of the generator table, for tests. */
 S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
+/* Digit width D of the device's fixed-base tables (entry (w, v) = v * 2^(D w) * G for the magnitudes v of a signed D-bit digit): 26 =
+ * 21.5 GB per table and 10 additions per fixed-base multiplication (the default, $S2K_GTAB_BITS at start-up), 24 / 22 / 20 = 5.9 / 1.6 /
+ * 0.44 GB with 11 / 12 / 13 additions.  The first call that needs the table of G allocates the widest one that fits, from the wanted
+ * width down, so an engine also exists on a partitioned or shared GPU; rangeproof generator tables take the same width.  Results do not
+ * depend on the width.  The reference's knob of this kind is ECMULT_WINDOW_SIZE (src/ecmult.h:14-38). */
+S2K_API int s2k_engine_gtable_bits(s2k_engine* e);
 /* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
  * `which`: 0 = whole call, 1 = dominant kernel only; 16 + k = dominant kernel of the k-th most recent rangeproof call (k < 32:
  * several calls may be in flight, see S2K_OPT_RP_INPUTS_READY).  Valid after s2k_engine_sync(). */

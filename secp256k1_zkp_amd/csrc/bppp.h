@@ -264,14 +264,15 @@ S2K_HD void bpc_v_scalar(u32 v8[8], const unsigned char* n_vec32, u32 g_len, con
     }
     for (int k = 0; k < 8; k++) v8[k] = v.d[k];
 }
-// k * G through the generator table (gtable.h): S2K_GTAB_WINDOWS additions, no doubling
+// k * G through the generator table (gtable.h): one addition per window of the table, no doubling
 S2K_HD void bpc_gmul(gej& out, const u32* gtab, const u32* k8) {
     gej acc; gej_set_infinity(acc);
-    u32 kr[S2K_GTAB_SWORDS]; gtab_recode(kr, k8);                    // signed fixed-base digits (ecmult.h)
-    for (int w = 0; w < (int)S2K_GTAB_WINDOWS; w++) {
-        const int word = (w * S2K_GTAB_BITS) >> 5;
+    const gtab_geom GG = gtab_geometry(gtab);
+    u32 kr[S2K_GTAB_SWORDS]; gtab_recode(kr, k8, gtab);              // signed fixed-base digits (ecmult.h)
+    for (int w = 0; w < (int)GG.W; w++) {
+        const int word = (int)(((u32)w * GG.D) >> 5);
         const u32* rec = gtab; int neg = 0;
-        if (gtab_locate(rec, neg, gtab, w, kr[word], word + 1 < S2K_GTAB_SWORDS ? kr[word + 1] : 0u)) {
+        if (gtab_locate(rec, neg, gtab, GG, w, kr[word], word + 1 < S2K_GTAB_SWORDS ? kr[word + 1] : 0u)) {
             u32 raw[16];
             for (int i = 0; i < 16; i++) raw[i] = rec[i];
             ge p; fe_from_words(p.x, raw); fe_from_words(p.y, raw + 8);

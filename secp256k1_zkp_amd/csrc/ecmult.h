@@ -36,49 +36,65 @@
 // Slot (w, v) = (w << (D-1)) + v: v = 2^(D-1) lands on slot (w+1, 0), which no window ever reads (a zero digit adds nothing).
 // One entry = one aligned 64-byte sector of canonical words (x[8], y[8], least significant first), the same record format as the
 // per-lane tables below, so that the main loops have a single operand pipeline.  (The host emulation builds D = 12.)
+// Round 5: the width D is a property of the TABLE, not of the code -- the engine builds D = 26 where 21.5 GB are to be had and falls back to
+// narrower tables where they are not (24: 5.9 GB, 22: 1.6 GB, 20: 0.44 GB; one more addition per multiplication for every step down; the
+// reference's knob of the same kind is ECMULT_WINDOW_SIZE, src/ecmult.h:14-38).  Slot (0, 0) -- the only slot no digit ever addresses and
+// no entry is stored in -- is the table's header: word 0 = D, word 1 = the number of windows, words 2..10 = the recoding constant K.
+// Every routine below takes its geometry from there (one uniform load per multiplication); S2K_GTAB_BITS is only the DEFAULT width.
 #ifndef S2K_GTAB_BITS
 #define S2K_GTAB_BITS 26
 #endif
-#define S2K_GTAB_HALF (1u << (S2K_GTAB_BITS - 1))
-#define S2K_GTAB_WINDOWS ((256 + S2K_GTAB_BITS - 1) / S2K_GTAB_BITS)
-#define S2K_GTAB_TOP_BITS (256 - S2K_GTAB_BITS * (S2K_GTAB_WINDOWS - 1))      /* the top window's value is at most 2^TOP_BITS (its bits + the carry) */
+#define S2K_GTAB_MAX_BITS 26
 #define S2K_GTAB_ENTRY_WORDS 16
-#define S2K_GTAB_SLOT(w, v) (((size_t)(w) << (S2K_GTAB_BITS - 1)) + (size_t)(v))
-#define S2K_GTAB_SLOTS (S2K_GTAB_SLOT(S2K_GTAB_WINDOWS, 0) + 1)
-#define S2K_GTAB_WORDS (S2K_GTAB_SLOTS * S2K_GTAB_ENTRY_WORDS)
 #define S2K_GTAB_SWORDS 9           /* words of a recoded scalar */
-static_assert(S2K_GTAB_TOP_BITS >= 1 && S2K_GTAB_TOP_BITS < S2K_GTAB_BITS - 1, "the top window must fit the table");
+#define S2K_GTAB_MAX_WINDOWS 32     /* D >= 8 */
+struct gtab_geom { u32 D, W; };     // digit width, number of windows
+S2K_HD u32 gtab_windows_for(u32 D) { return (256u + D - 1u) / D; }
+S2K_HD u32 gtab_top_bits_for(u32 D) { return 256u - D * (gtab_windows_for(D) - 1u); }      // the top window's value is at most 2^TOP_BITS (its bits + the carry)
+S2K_HD int gtab_bits_ok(u32 D) { return D >= 8u && D <= S2K_GTAB_MAX_BITS && gtab_top_bits_for(D) >= 1u && gtab_top_bits_for(D) < D - 1u; }      // the top window must fit the table
+S2K_HD size_t gtab_slot(u32 D, u32 w, u32 v) { return ((size_t)w << (D - 1u)) + (size_t)v; }
+S2K_HD size_t gtab_slots_for(u32 D) { return gtab_slot(D, gtab_windows_for(D), 0) + 1; }
+S2K_HD size_t gtab_words_for(u32 D) { return gtab_slots_for(D) * S2K_GTAB_ENTRY_WORDS; }
+S2K_HD gtab_geom gtab_geometry(const u32* tab) { gtab_geom g; g.D = tab[0]; g.W = tab[1]; return g; }
+// the header of a table of width D (written once, by the kernel that builds the window bases)
+S2K_HD void gtab_write_header(u32* tab, u32 D) {
+    const u32 W = gtab_windows_for(D);
+    tab[0] = D; tab[1] = W;
+    for (int i = 0; i < S2K_GTAB_SWORDS; i++) {
+        u32 k = 0;
+        for (u32 w = 0; w + 1 < W; w++) { const u32 bit = D - 1u + D * w; if ((bit >> 5) == (u32)i) k |= 1u << (bit & 31u); }
+        tab[2 + i] = k;
+    }
+    for (int i = 2 + S2K_GTAB_SWORDS; i < S2K_GTAB_ENTRY_WORDS; i++) tab[i] = 0;
+}
 
 S2K_HD void gtab_load(ge& r, const u32* gtab, u32 window, u32 v) {
-    const u32* p = gtab + S2K_GTAB_SLOT(window, v) * S2K_GTAB_ENTRY_WORDS;
+    const u32* p = gtab + gtab_slot(gtab[0], window, v) * S2K_GTAB_ENTRY_WORDS;
     u32 w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = p[i];
     fe_from_words(r.x, w); fe_from_words(r.y, w + 8);
 }
-// s (8 little-endian words) -> s' = s + K (9 words)
-S2K_HD void gtab_recode(u32 out[S2K_GTAB_SWORDS], const u32 s[8]) {
+// s (8 little-endian words) -> s' = s + K (9 words), K from the header of the table the digits will index
+S2K_HD void gtab_recode(u32 out[S2K_GTAB_SWORDS], const u32 s[8], const u32* tab) {
     u64 cy = 0;
 #pragma unroll
     for (int i = 0; i < S2K_GTAB_SWORDS; i++) {
-        u32 k = 0;
-#pragma unroll
-        for (int w = 0; w + 1 < S2K_GTAB_WINDOWS; w++) { const int bit = S2K_GTAB_BITS - 1 + S2K_GTAB_BITS * w; if ((bit >> 5) == i) k |= 1u << (bit & 31); }
-        cy += (u64)(i < 8 ? s[i] : 0u) + k;
+        cy += (u64)(i < 8 ? s[i] : 0u) + tab[2 + i];
         out[i] = (u32)cy; cy >>= 32;
     }
 }
 // window g of a recoded scalar, given the two words that hold its bits (lo = word (D g) >> 5, hi = the next one or 0): the table record to
 // add (returns 0: the digit is zero) and whether its y has to be negated
-S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, int g, u32 lo, u32 hi) {
-    const int b = g * S2K_GTAB_BITS;
+S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, const gtab_geom& G, int g, u32 lo, u32 hi) {
+    const u32 b = (u32)g * G.D;
     const u64 pair = (u64)lo | ((u64)hi << 32);
-    const u32 t = (u32)(pair >> (b & 31)) & ((1u << S2K_GTAB_BITS) - 1u);
+    const u32 t = (u32)(pair >> (b & 31u)) & ((1u << G.D) - 1u);
     u32 v;
-    if (g + 1 < S2K_GTAB_WINDOWS) { const int d = (int)t - (int)S2K_GTAB_HALF; neg = d < 0; v = (u32)(d < 0 ? -d : d); }
+    if ((u32)g + 1u < G.W) { const int d = (int)t - (int)(1u << (G.D - 1u)); neg = d < 0; v = (u32)(d < 0 ? -d : d); }
     else { neg = 0; v = t; }
     if (!v) return 0;
-    addr = tab + S2K_GTAB_SLOT(g, v) * S2K_GTAB_ENTRY_WORDS;
+    addr = tab + gtab_slot(G.D, (u32)g, v) * S2K_GTAB_ENTRY_WORDS;
     return 1;
 }
 
@@ -282,7 +298,7 @@ S2K_HD u32 digit_reg_pop(digit_reg& r) {
 
 #define S2K_ADDS_P 66            // 33 digit positions x 2 halves
 #define S2K_ADD_G0 S2K_ADDS_P
-#define S2K_ADDS_TOTAL (S2K_ADD_G0 + S2K_GTAB_WINDOWS)
+#define S2K_ADDS_MAX (S2K_ADD_G0 + S2K_GTAB_MAX_WINDOWS)
 
 // R = na*A + ng*G for this lane.  A is Jacobian (A.inf allowed), ng may be absent (has_ng = 0).
 // gtab: generator table; ptab: this lane's private S2K_PTAB_WORDS-word slice of scratch memory.
@@ -315,18 +331,19 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
         }
     }
+    const gtab_geom GG = gtab_geometry(gtab);
     {
-        u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d);
+        u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d, gtab);
 #pragma unroll
         for (int i = 0; i < S2K_GTAB_SWORDS; i++) dig[(9 + i) * S2K_DIG_STRIDE] = ngr[i];
     }
 
     S2K_PROF_MARK(2);
-    // per-lane micro-program: additions a = 0..S2K_ADDS_TOTAL-1, with 4 doublings in front of every even a in [2, 66)
+    // per-lane micro-program: additions a = 0..a_end-1, with 4 doublings in front of every even a in [2, 66)
     int a = p_active ? 0 : S2K_ADD_G0;
     int zfixed = !p_active;
     int dbl_left = 0, pending = 0;
-    const int a_end = g_active ? S2K_ADDS_TOTAL : S2K_ADD_G0;
+    const int a_end = g_active ? S2K_ADD_G0 + (int)GG.W : S2K_ADD_G0;
     // Operand pipeline.  Every operand -- an odd multiple from this lane's table or a generator-table entry -- is one aligned
     // 64-byte record of canonical words (x, y).  `op_locate` turns an addition index into (record address, use it?, negate y?);
     // the record of addition a+1 is *requested* (16 words into `raw`, no use of the data) before the arithmetic of addition a
@@ -343,8 +360,8 @@ S2K_HD void ecmult_lane(gej& R, const gej& A, const scalar& na, const scalar& ng
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
             addr = ptab + e * S2K_PTAB_ENTRY_WORDS + ((h && S2K_PTAB_TWINS) ? 16 : 0); lam = h && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
-            const int g = idx - S2K_ADD_G0, w = (g * S2K_GTAB_BITS) >> 5;
-            valid = gtab_locate(addr, neg, gtab, g, dig[(9 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(10 + w) * S2K_DIG_STRIDE] : 0u);
+            const int g = idx - S2K_ADD_G0, w = (int)(((u32)g * GG.D) >> 5);
+            valid = gtab_locate(addr, neg, gtab, GG, g, dig[(9 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(10 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
@@ -502,7 +519,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #pragma unroll
         for (int i = 0; i < 8; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
         {
-            u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d);
+            u32 ngr[S2K_GTAB_SWORDS]; gtab_recode(ngr, ng.d, gtab);
 #pragma unroll
             for (int i = 0; i < S2K_GTAB_SWORDS; i++) dig[(8 + i) * S2K_DIG_STRIDE] = ngr[i];
         }
@@ -518,8 +535,9 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #pragma unroll
         for (int i = 0; i < 9; i++) ptab[S2K_PTAB_ZISO + i] = ziso.n[i];
     }
+    const gtab_geom GG = gtab_geometry(gtab);
     const int a_g0 = S2K_SPLIT_ADDS_P;
-    const int a_end = g_active ? a_g0 + S2K_GTAB_WINDOWS : a_g0;
+    const int a_end = g_active ? a_g0 + (int)GG.W : a_g0;
     auto op_locate = [&](const u32*& addr, int& valid, int& neg, int& lam, int idx) {
         addr = ptab; valid = 0; neg = 0; lam = 0;
         if (idx < a_g0) {
@@ -531,8 +549,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
             const u32 e = (v < 8u) ? (7u - v) : (v - 8u);
             addr = ptab + (st >> 1) * S2K_PTAB_TABLE_WORDS + e * S2K_PTAB_ENTRY_WORDS + (((st & 1) && S2K_PTAB_TWINS) ? 16 : 0); lam = (st & 1) && !S2K_PTAB_TWINS;
         } else if (idx < a_end) {
-            const int g = idx - a_g0, w = (g * S2K_GTAB_BITS) >> 5;
-            valid = gtab_locate(addr, neg, gtab, g, dig[(8 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(9 + w) * S2K_DIG_STRIDE] : 0u);
+            const int g = idx - a_g0, w = (int)(((u32)g * GG.D) >> 5);
+            valid = gtab_locate(addr, neg, gtab, GG, g, dig[(8 + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(9 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {
@@ -606,7 +624,7 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 //     pieces of sc_split_pieces are odd and below 2^65.  ecmult_lane_split's 4-bit digits need a fixed 17th digit because 16 of them
 //     only reach 2^64.)  So a step is 12 x 5 doublings and 52 additions, the first of which just takes its operand;
 //   * no "key <- key + B", "T <- T + 2^64*B" updates between the steps;
-//   * + S2K_GTAB_WINDOWS additions from H's table on the steps with j > 0.
+//   * + W (the table's number of windows) additions from H's table on the steps with j > 0.
 // Per ring: 1 chain + 2 tables + 4 x (60 doublings + 52 additions) + 77 table additions, against 4 x (64 doublings + 68 + 11 additions
 // + 2 tables + a chain quarter + 2 key updates) for ecmult_lane_split.
 // Lane memory: `rtab`, S2K_RTAB_WORDS words of HBM: 32 finished 64-byte sectors back to back (2 KB: all the main loop touches) and the Z
@@ -671,13 +689,14 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         }
 #pragma unroll
         for (int i = 0; i < 9; i++) dig[i * S2K_DIG_STRIDE] = dw[i];
-        u32 sr[S2K_GTAB_SWORDS], fr[S2K_GTAB_SWORDS]; gtab_recode(sr, s.d); gtab_recode(fr, f.d);
+        u32 sr[S2K_GTAB_SWORDS], fr[S2K_GTAB_SWORDS]; gtab_recode(sr, s.d, gtab); gtab_recode(fr, f.d, has_f ? htab : gtab);
 #pragma unroll
         for (int i = 0; i < S2K_GTAB_SWORDS; i++) { dig[(9 + i) * S2K_DIG_STRIDE] = sr[i]; dig[(18 + i) * S2K_DIG_STRIDE] = fr[i]; }
     }
     S2K_PROF_MARK(1);
-    const int a_g0 = S2K_RING_ADDS_P, a_h0 = a_g0 + S2K_GTAB_WINDOWS;
-    const int a_end = has_f ? a_h0 + S2K_GTAB_WINDOWS : a_h0;
+    const gtab_geom GG = gtab_geometry(gtab), GH = gtab_geometry(has_f ? htab : gtab);      // (the generator's table may have another width than G's)
+    const int a_g0 = S2K_RING_ADDS_P, a_h0 = a_g0 + (int)GG.W;
+    const int a_end = has_f ? a_h0 + (int)GH.W : a_h0;
     auto op_locate = [&](const u32*& addr, int& valid, int& neg, int idx) {
         addr = rtab; valid = 0; neg = 0;
         if (idx < a_g0) {
@@ -689,8 +708,8 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
             addr = rtab + (st >> 1) * S2K_RTAB_TABLE_WORDS + en * 16;
         } else if (idx < a_end) {
             const int second = idx >= a_h0;
-            const int g = idx - (second ? a_h0 : a_g0), base = second ? 18 : 9, w = (g * S2K_GTAB_BITS) >> 5;
-            valid = gtab_locate(addr, neg, second ? htab : gtab, g, dig[(base + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(base + 1 + w) * S2K_DIG_STRIDE] : 0u);
+            const int g = idx - (second ? a_h0 : a_g0), base = second ? 18 : 9, w = (int)(((u32)g * (second ? GH.D : GG.D)) >> 5);
+            valid = gtab_locate(addr, neg, second ? htab : gtab, second ? GH : GG, g, dig[(base + w) * S2K_DIG_STRIDE], w + 1 < S2K_GTAB_SWORDS ? dig[(base + 1 + w) * S2K_DIG_STRIDE] : 0u);
         }
     };
     auto op_decode = [&](ge& o, const u32 raw[16], int neg, int lam) {

@@ -63,24 +63,42 @@ int engine_workspace(s2k_engine* e, size_t bytes) {
 // ------------------------------------------------------------------------------------------------------------
 // generator table construction (engine creation)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_gtab_base(u32* gtab) {
+// (gtable.h: window bases -> seeds -> one affine addition per remaining entry with a shared inversion per run of rows)
+__global__ void k_gtab_base(u32* gtab, u32 D) {
     const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < S2K_GTAB_WINDOWS) gtab_build_base(gtab, w);
+    if (w == 0) gtab_write_header(gtab, D);
+    if (w < gtab_windows_for(D)) gtab_build_base(gtab, D, w);
 }
 __global__ void __launch_bounds__(256)
-k_gtab_entries(u32* gtab) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 w = t >> (S2K_GTAB_BITS - 1), v = (t & (S2K_GTAB_HALF - 1u)) + 1u;          // v = 1 .. 2^(D-1): the magnitudes of a signed D-bit digit
-    // the top window only ever sees the bits that are left of a 256-bit scalar, plus the carry of the recoding
-    if (w < S2K_GTAB_WINDOWS && v >= 2 && (w + 1 < S2K_GTAB_WINDOWS || v <= (1u << S2K_GTAB_TOP_BITS) + 1u)) gtab_build_entry(gtab, w, v);
+k_gtab_seeds(u32* gtab, gtab_fill_plan p) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, per = gtab_seeds_per_window(p);
+    const u32 w = t / per;
+    if (w < p.W) gtab_build_seed(gtab, p, w, t % per);
+}
+// block = 256 consecutive columns of one (window, run of rows)
+__global__ void __launch_bounds__(256, 2)
+k_gtab_fill(u32* gtab, gtab_fill_plan p, u32 runs) {
+    const u32 b = blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
+    if (b >= 1u && b < p.Kc) gtab_fill_run(gtab, p, w, b, run * GTAB_FILL_RUN);
+}
+// the three launches; `base_done`: the window bases (and the header) are already there (a generator's table: k_gen_base wrote them)
+static int launch_table_build(hipStream_t st, u32* tab, u32 D, int base_done) {
+    const gtab_fill_plan p = gtab_make_fill_plan(D);
+    if (!base_done) hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, tab, D);
+    const u32 seeds = p.W * gtab_seeds_per_window(p);
+    hipLaunchKernelGGL(k_gtab_seeds, dim3((seeds + 255) / 256), dim3(256), 0, st, tab, p);
+    const u32 runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
+    hipLaunchKernelGGL(k_gtab_fill, dim3((p.Kc + 255) / 256, p.W * runs), dim3(256), 0, st, tab, p, runs);
+    return hipGetLastError() == hipSuccess;
 }
 
 // fixed-base table of another point than G (a rangeproof generator): window bases from the 64 generator bytes, then k_gtab_entries
-__global__ void k_gen_base(u32* tab, const unsigned char* gen64) {
+__global__ void k_gen_base(u32* tab, const unsigned char* gen64, u32 D) {
     const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= S2K_GTAB_WINDOWS) return;
+    if (w == 0) gtab_write_header(tab, D);
+    if (w >= gtab_windows_for(D)) return;
     ge g; rp_load_generator(g, gen64);
-    gtab_build_base(tab, w, &g);
+    gtab_build_base(tab, D, w, &g);
 }
 // x of j * 4^ring * 10^exp * H for j = 1..3 (rp_ring_suspect): one multiplication per lane
 __global__ void __launch_bounds__(256, 2)
@@ -172,6 +190,8 @@ static s2k_dev_pool* pool_acquire(int device) {
     p->device = device; p->refs = 1; p->gtab = nullptr; p->ev_gtab = nullptr; p->gtab_state = 0; p->gen_keys = nullptr;
     for (int i = 0; i < RP_GEN_SLOTS; i++) { auto& g2 = p->gen[i]; g2.tab = nullptr; g2.xmul = nullptr; g2.valid = 0; g2.stamp = 0; g2.pinned = 0; g2.ev_ready = nullptr; g2.done = 0; }
     p->gen_slots = 2; p->gen_clock = 0; p->gen_min = size_t(1) << 16; p->gen_h = 1;
+    p->gtab_bits = S2K_GTAB_BITS;
+    if (const char* gb = getenv("S2K_GTAB_BITS")) { const int v = atoi(gb); if (v >= 20 && v <= S2K_GTAB_MAX_BITS && gtab_bits_ok((u32)v)) p->gtab_bits = (u32)v; }
     if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); p->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
     if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) p->gen_min = (size_t)strtoull(gm, nullptr, 10);
 #ifdef S2K_DIAG
@@ -210,13 +230,16 @@ const u32* engine_gtab(s2k_engine* e, hipStream_t st) {
     std::lock_guard<std::recursive_mutex> lock(p->mu);
     if (p->gtab_state == 2) return p->gtab;
     if (p->gtab_state == 0) {
-        if (hipMalloc((void**)&p->gtab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); p->gtab = nullptr; s2k_fail("engine_gtab", "no memory for the generator table (21.5 GB of HBM)"); return nullptr; }
-        int ok = hipMemsetAsync(p->gtab, 0, sizeof(u32) * S2K_GTAB_WORDS, st) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, p->gtab);
-            hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << (S2K_GTAB_BITS - 1)) / 256)), dim3(256), 0, st, p->gtab);
-            ok = hipGetLastError() == hipSuccess && hipEventRecord(p->ev_gtab, st) == hipSuccess;
+        // The widest table the device has room for, from the wanted width down (26 bits = 21.5 GB, 24 = 5.9 GB, 22 = 1.6 GB, 20 = 0.44 GB):
+        // a partitioned or shared GPU still gets an engine, with one more addition per fixed-base multiplication for every step down.
+        p->gtab = nullptr;
+        for (u32 D = p->gtab_bits; D >= 20u; D -= 2u) {
+            if (!gtab_bits_ok(D)) continue;
+            if (hipMalloc((void**)&p->gtab, sizeof(u32) * gtab_words_for(D)) == hipSuccess) { p->gtab_bits = D; break; }
+            (void)hipGetLastError(); p->gtab = nullptr;
         }
+        if (!p->gtab) { s2k_fail("engine_gtab", "no memory for the generator table (0.44 GB of HBM at the narrowest width)"); return nullptr; }
+        const int ok = launch_table_build(st, p->gtab, p->gtab_bits, 0) && hipEventRecord(p->ev_gtab, st) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); hipFree(p->gtab); p->gtab = nullptr; s2k_fail("engine_gtab", "generator table build failed"); return nullptr; }
         p->gtab_state = 1;
         return p->gtab;
@@ -273,15 +296,15 @@ int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key, int
     // device is idle (an eviction is a 0.3 s table build anyway)
     if (g.tab && hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
     if (!g.tab) {
-        if (hipMalloc((void**)&g.tab, sizeof(u32) * S2K_GTAB_WORDS) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }
+        if (hipMalloc((void**)&g.tab, sizeof(u32) * gtab_words_for(p->gtab_bits)) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }      // (the width of the table of G)
         if (hipMalloc((void**)&g.xmul, sizeof(u32) * RP_XMUL_WORDS) != hipSuccess) { (void)hipGetLastError(); hipFree(g.tab); g.tab = nullptr; g.xmul = nullptr; return -1; }
     }
     if (!engine_ptab(e, 2048)) return -1;
     g.valid = 0;
     memcpy(g.key, key, 64);
     if (hipMemcpyAsync(p->gen_keys + 64 * slot, g.key, 64, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, p->gen_keys + 64 * slot);
-    hipLaunchKernelGGL(k_gtab_entries, dim3((unsigned)(((size_t)S2K_GTAB_WINDOWS << (S2K_GTAB_BITS - 1)) / 256)), dim3(256), 0, st, g.tab);
+    hipLaunchKernelGGL(k_gen_base, dim3(1), dim3(64), 0, st, g.tab, p->gen_keys + 64 * slot, p->gtab_bits);
+    if (!launch_table_build(st, g.tab, p->gtab_bits, 1)) { (void)hipGetLastError(); return -1; }
     hipLaunchKernelGGL(k_gen_xmul, dim3((RP_XMUL_EXPS * RP_MAX_RINGS * 3 + 255) / 256), dim3(256), 0, st, g.xmul, p->gen_keys + 64 * slot, gtab, e->ptab);
     if (hipGetLastError() != hipSuccess || hipEventRecord(g.ev_ready, st) != hipSuccess) { (void)hipGetLastError(); return -1; }
     g.valid = 1; g.done = 0; g.pinned = pinned; g.stamp = ++p->gen_clock;
@@ -478,14 +501,20 @@ extern "C" int s2k_engine_sync(s2k_engine* e) {
     return 1;
 }
 extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
-    if (bytes) *bytes = sizeof(u32) * S2K_GTAB_WORDS;
+    if (bytes) *bytes = 0;
     if (!e) return nullptr;
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     if (hipSetDevice(e->device) != hipSuccess) return nullptr;
     const u32* t = engine_gtab(e, e->stream);                  // (built now if no call has needed it yet)
     if (!t || hipStreamSynchronize(e->stream) != hipSuccess) return nullptr;
     e->gtab = const_cast<u32*>(t);
+    if (bytes) *bytes = sizeof(u32) * gtab_words_for(e->pool->gtab_bits);
     return t;
+}
+extern "C" int s2k_engine_gtable_bits(s2k_engine* e) {
+    if (!e) return 0;
+    std::lock_guard<std::recursive_mutex> lock(e->pool->mu);
+    return (int)e->pool->gtab_bits;                            // the width wanted until the table exists, the width it has afterwards
 }
 extern "C" int s2k_engine_last_msm_fallback(s2k_engine* e) {
     if (!e) return 0;

@@ -58,7 +58,7 @@ struct s2k_dev_pool;
 struct s2k_engine {
     int device;
     hipStream_t stream;
-    u32* gtab;                 // the device pool's generator table (S2K_GTAB_WORDS words) once a call of this engine has needed it (engine_gtab)
+    u32* gtab;                 // the device pool's generator table once a call of this engine has needed it (engine_gtab)
     unsigned char* ws;         // growable HBM workspace
     size_t ws_bytes;
     u32* ptab;                 // per-lane odd-multiples tables (S2K_PTAB_WORDS words per lane), grown on demand
@@ -186,6 +186,7 @@ struct s2k_dev_pool {
     int device; int refs;
     std::recursive_mutex mu;
     u32* gtab; hipEvent_t ev_gtab; int gtab_state;           // 0: not built, 1: build queued (ev_gtab behind it), 2: known to be complete
+    u32 gtab_bits;                                            // digit width of the device's tables: wanted ($S2K_GTAB_BITS, default 26) until the table of G exists, then what fitted
     // Fixed-base tables of rangeproof generators: a small cache keyed by the 64 generator bytes.  Slot tables have the layout of gtab
     // (allocated when a slot is first used and then reused by whatever generator takes the slot); xmul is the x-table of the ring-base
     // multiples (RP_XMUL_WORDS).  gen_keys (device) is what k_rp_header matches a proof's generator against; gen_seen counts the VERIFIED

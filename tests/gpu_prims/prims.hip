@@ -37,7 +37,7 @@ __global__ void k_prim(int op, unsigned char* out, int* flag, const unsigned cha
     case 8: { scalar s, t; sc_set_b32(s, a + 32 * i, nullptr); sc_set_b32(t, b + 32 * i, nullptr); sc_mul(s, s, t); sc_get_b32(out + 32 * i, s); } break;
     case 9: { scalar s, r1, r2; sc_set_b32(s, a + 32 * i, nullptr); sc_split_lambda(r1, r2, s); sc_get_b32(out + 64 * i, r1); sc_get_b32(out + 64 * i + 32, r2); } break;
     case 10: { sha256_stream h; sha256_stream_init(h); sha256_stream_write(h, a + 100 * i, 100); sha256_stream_finalize(h, out + 32 * i); } break;
-    case 11: { const u32 wv = ((const u32*)a)[i]; ge g; gtab_load(g, gtab, wv >> S2K_GTAB_BITS, wv & ((1u << S2K_GTAB_BITS) - 1u)); fe_normalize(g.x); fe_normalize(g.y); fe_get_b32(out + 64 * i, g.x); fe_get_b32(out + 64 * i + 32, g.y); } break;
+    case 11: { const u32 wv = ((const u32*)a)[i]; ge g; gtab_load(g, gtab, wv >> S2K_GTAB_MAX_BITS, wv & ((1u << S2K_GTAB_MAX_BITS) - 1u));      /* (window, magnitude) packed at 26 bits whatever the table's width */ fe_normalize(g.x); fe_normalize(g.y); fe_get_b32(out + 64 * i, g.x); fe_get_b32(out + 64 * i + 32, g.y); } break;
     case 20: {   // intermediates of gej_double for debugging: Z3, S, L, T, X3, S2, (X3+T), Y3pre
         ge p; fe_set_b32_mod(p.x, a + 64 * i); fe_set_b32_mod(p.y, a + 64 * i + 32);
         fe X = p.x, Y = p.y, l, s, t, rx, ry, rz, one; fe_set_int(one, 1);

@@ -90,12 +90,17 @@ static u32 g_dig[S2K_DIG_WORDS];
 static const lane_mem g_lm{g_ptab, g_dig};
 // Host-only construction of the window table (this library is compiled with -DS2K_GTAB_BITS=12 to keep it small): same entries as gtable.h's device kernels, but built by running
 // sums + Montgomery batch inversion so that a CPU test does not spend a minute on a million inversions.
+#ifndef S2K_EMU_GTAB_BITS
+#define S2K_EMU_GTAB_BITS 12
+#endif
 static void table_host(std::vector<u32>& g_gtab, const ge* point) {
     {
-        g_gtab.assign(S2K_GTAB_WORDS, 0);
-        const u32 NV = S2K_GTAB_HALF + 1u; std::vector<gej> acc(NV); std::vector<fe> pre(NV);      // magnitudes 1 .. 2^(D-1) of a signed digit
-        for (u32 w = 0; w < S2K_GTAB_WINDOWS; w++) {
-            gtab_build_base(g_gtab.data(), w, point);
+        const u32 D = S2K_EMU_GTAB_BITS, W = gtab_windows_for(D), HALF = 1u << (D - 1u);
+        g_gtab.assign(gtab_words_for(D), 0);
+        gtab_write_header(g_gtab.data(), D);
+        const u32 NV = HALF + 1u; std::vector<gej> acc(NV); std::vector<fe> pre(NV);      // magnitudes 1 .. 2^(D-1) of a signed digit
+        for (u32 w = 0; w < W; w++) {
+            gtab_build_base(g_gtab.data(), D, w, point);
             ge base; gtab_load(base, g_gtab.data(), w, 1);
             gej_set_ge(acc[1], base);
             for (u32 v = 2; v < NV; v++) {
@@ -110,10 +115,43 @@ static void table_host(std::vector<u32>& g_gtab, const ge* point) {
                 fe zi, zi2, zi3; fe_mul(zi, inv, pre[v]); fe_mul(inv, inv, acc[v].z);
                 fe_sqr(zi2, zi); fe_mul(zi3, zi2, zi);
                 ge a; fe_mul(a.x, acc[v].x, zi2); fe_mul(a.y, acc[v].y, zi3); fe_normalize(a.x); fe_normalize(a.y);
-                gtab_store(g_gtab.data(), w, v, a);
+                gtab_store(g_gtab.data(), D, w, v, a);
             }
         }
     }
+}
+// the device's table construction (gtable.h: window bases, seeds, one affine addition per remaining entry with a shared inversion per run
+// of rows) run sequentially for a table of width D, against the running-sum construction above: returns the number of entries that differ
+// (-1: an entry the device construction leaves out is one a digit can address)
+int emu_gtab_seeded_construction(unsigned D, const unsigned char* point64) {
+    if (!gtab_bits_ok(D) || D > 16) return -2;
+    ge pt; const ge* point = nullptr;
+    if (point64) { ge_from_b64(pt, point64); fe_norm_weak(pt.x); fe_norm_weak(pt.y); point = &pt; }
+    const gtab_fill_plan p = gtab_make_fill_plan(D);
+    std::vector<u32> tab(gtab_words_for(D), 0xFFFFFFFFu);
+    gtab_write_header(tab.data(), D);
+    for (u32 w = 0; w < p.W; w++) gtab_build_base(tab.data(), D, w, point);
+    for (u32 w = 0; w < p.W; w++) for (u32 t = 0; t < gtab_seeds_per_window(p); t++) gtab_build_seed(tab.data(), p, w, t);
+    const u32 runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
+    for (u32 w = 0; w < p.W; w++) for (u32 run = 0; run < runs; run++) for (u32 b = 1; b < p.Kc; b++) gtab_fill_run(tab.data(), p, w, b, run * GTAB_FILL_RUN);
+    // reference: v * base by repeated addition
+    int bad = 0;
+    for (u32 w = 0; w < p.W; w++) {
+        ge base; gtab_load(base, tab.data(), w, 1);
+        gej acc; gej_set_ge(acc, base);
+        const u32 vmax = (w + 1 < p.W) ? (1u << (D - 1)) : (1u << gtab_top_bits_for(D)) + 1u;
+        for (u32 v = 1; v <= vmax; v++) {
+            if (v > 1) { gej t; int f = gej_add_ge(t, acc, base); if (f == GEJ_ADD_NEEDS_DOUBLE) { gej u; gej_double(u, t); t = u; } acc = t; }
+            ge a; ge_set_gej(a, acc);
+            u32 wx[8], wy[8]; fe_to_words(wx, a.x); fe_to_words(wy, a.y);
+            const u32* q = tab.data() + gtab_slot(D, w, v) * S2K_GTAB_ENTRY_WORDS;
+            int same = 1, unset = 1;
+            for (int i = 0; i < 8; i++) { same &= (q[i] == wx[i]) & (q[8 + i] == wy[i]); unset &= (q[i] == 0xFFFFFFFFu) & (q[8 + i] == 0xFFFFFFFFu); }
+            if (unset) return -1;
+            bad += !same;
+        }
+    }
+    return bad;
 }
 static const u32* gtab_host() {
     if (g_gtab.empty()) table_host(g_gtab, nullptr);
@@ -121,7 +159,6 @@ static const u32* gtab_host() {
 }
 // spot-check entry (w, v) of the host table against the device construction path
 int emu_gtab_entry(unsigned char* r64, unsigned w, unsigned v) {
-    std::vector<u32> t(S2K_GTAB_WORDS / S2K_GTAB_WINDOWS * 0 + 1);
     ge g; gtab_load(g, gtab_host(), w, v); fe_normalize(g.x); fe_normalize(g.y); fe_get_b32(r64, g.x); fe_get_b32(r64 + 32, g.y); return 0;
 }
 // z32 != NULL: present A in Jacobian form with that Z

@@ -455,3 +455,13 @@ def test_header_is_plain_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "examples", "rangeproof_verify.c"),
                     "-o", str(tmp_path / "e.o")], check=True)
+
+
+def test_emu_seeded_table_construction(emu, ref):
+    """the device's fixed-base table construction (csrc/gtable.h: window bases, seeds, ONE affine addition per remaining entry with a
+    shared inversion per run of rows) run sequentially at small widths, for G and for another point: every entry a digit can address equals
+    v * 2^(D w) * point, and none is left unwritten"""
+    rng = np.random.default_rng(5)
+    for D in (9, 10, 11, 12, 13):
+        assert emu.emu_gtab_seeded_construction(D, None) == 0, D
+    assert emu.emu_gtab_seeded_construction(12, ref.rand_point(rng)) == 0

@@ -127,23 +127,29 @@ def test_sha256(prims):
         assert got[i].tobytes() == hashlib.sha256(m[i].tobytes()).digest()
 
 
-def _gtab_bits():
-    import re
-    src = open(os.path.join(os.path.dirname(HERE), "secp256k1_zkp_amd", "csrc", "ecmult.h")).read()
-    return int(re.search(r"#define S2K_GTAB_BITS (\d+)", src).group(1))
+def _gtab_bits(engine):
+    return int(engine._lib.s2k_engine_gtable_bits(engine._h))         # the width of the table this device got (26 unless memory was short)
 
 
-def test_generator_table(prims, ref):
+def test_generator_table(prims, ref, engine):
     """entries (w, v) of the device-built window table equal v*2^(B w)*G computed by the reference's ecmult (role of
     test_pre_g_table, src/tests.c:4543-4615): every window's edge values plus a random sample.  The table holds the magnitudes
     v = 1 .. 2^(B-1) of a signed B-bit digit; the top window what is left of a 256-bit scalar plus the recoding's carry."""
     rng = np.random.default_rng(16)
-    B = _gtab_bits(); W = (256 + B - 1) // B; top = 256 - B * (W - 1)
+    B = _gtab_bits(engine); W = (256 + B - 1) // B; top = 256 - B * (W - 1)
     nv = lambda w: (1 << (B - 1)) + 1 if w + 1 < W else (1 << top) + 2
     idx = [(w, v) for w in range(W) for v in (1, 2, 3, 255, 256, 257, nv(w) // 2 - 1, nv(w) // 2, nv(w) - 2, nv(w) - 1)]
-    idx += [(w, int(rng.integers(1, nv(w)))) for w in rng.integers(0, W, 4000)]
+    idx += [(w, int(rng.integers(1, nv(w)))) for w in rng.integers(0, W, 12000)]
+    # the seeded construction's own edges (csrc/gtable.h): v = a * Kc + b with Kc = 2^(B // 2) columns, rows in runs of 16
+    Kc = 1 << (B // 2)
+    for w in range(W):
+        for a in (1, 2, 15, 16, 17, 31, 32, (nv(w) - 1) // Kc - 1, (nv(w) - 1) // Kc):
+            for b in (0, 1, 2, 63, 64, 255, 256, Kc - 1):
+                v = a * Kc + b
+                if 1 <= v < nv(w):
+                    idx.append((w, v))
     n = len(idx)
-    sel = np.array([(int(w) << B) | v for (w, v) in idx], np.uint32)
+    sel = np.array([(int(w) << 26) | v for (w, v) in idx], np.uint32)
     got, _ = prims(11, n, 64, sel.view(np.uint8))
     ng = np.stack([np.frombuffer(_b((v << (B * int(w))) % N), np.uint8) for (w, v) in idx])      # (the top window's largest entries exceed 2^256: mod n)
     g = np.frombuffer(G_XY * n, np.uint8).reshape(-1, 64)

@@ -128,7 +128,7 @@ def test_signed_fixed_base_digit_edges(engine, ref):
     without a variable point, as the generator term of the MSM, and through BIP-340's s*G via crafted-but-invalid signatures"""
     from tests.test_cpu_oracle import fixed_base_edge_scalars
     rng = np.random.default_rng(64)
-    D = int(__import__("re").search(r"#define S2K_GTAB_BITS (\d+)", open(os.path.join(os.path.dirname(HERE), "secp256k1_zkp_amd", "csrc", "ecmult.h")).read()).group(1))
+    D = int(engine._lib.s2k_engine_gtable_bits(engine._h))
     sc = fixed_base_edge_scalars(D, rng, 512)
     n = len(sc)
     ng = np.stack([np.frombuffer(_b(v), np.uint8) for v in sc])
