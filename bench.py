@@ -735,6 +735,31 @@ def main():
         msm["sharding"] = (("terms over ranks, all-gather of %d x 112 B Jacobian partials + local sum" % world) if msm_fn is parallel.msm_sharded
                            else ("bucket windows over ranks, all-gather of per-window Jacobian sums + local Horner, %d ranks" % world))
         msm["verified"] = checker is not None
+        if rank == 0:
+            # memory-side traffic and issued instructions of the MSM kernels: committed rocprofv3 passes (tools/profile_msm.sh), used only when the
+            # file is stamped with this library's binary or sources (same rule as the ring kernel's counters below)
+            import hashlib
+            from secp256k1_zkp_amd import _native as _nat
+            _lib = hashlib.sha256(open(_nat.LIB_PATH, "rb").read()).hexdigest(); _src = _nat.sources_sha256()
+            mc = None
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*msm_counters.json")), reverse=True):
+                try:
+                    jj = json.load(open(f))
+                except Exception:
+                    continue
+                if jj.get("so_sha256") == _lib or (_src and jj.get("src_sha256") == _src):
+                    mc = (f, jj); break
+            for blk, key in ((msm, "1048576"),):
+                if mc and key in mc[1]:
+                    pc = mc[1][key]["per_call"]
+                    blk["roofline"]["traffic"] = pc["hbm_bytes_raw"]; blk["roofline"]["traffic_unit"] = "HBM-side bytes per call (FETCH_SIZE + WRITE_SIZE over every kernel of the call, incl. Infinity-Cache hits)"
+                    blk["roofline"]["traffic_source"] = os.path.relpath(mc[0], ROOT)
+                    if pc.get("int64_wave_instructions"):
+                        blk["roofline"]["issued"] = {"int64_wave_instructions_per_call": pc["int64_wave_instructions"], "valu_wave_instructions_per_call": pc["valu_wave_instructions"],
+                                                     "int64_lane_ops_per_s": pc["int64_wave_instructions"] * 64 / (ms * 1e-3), "frac_of_peak": pc["int64_wave_instructions"] * 64 / (ms * 1e-3) / MAD32_PEAK}
+                else:
+                    blk["roofline"]["traffic"] = None; blk["roofline"]["traffic_source"] = "no profiles/*msm_counters.json stamped with this library (tools/profile_msm.sh)"
+            msm["_counters_file"] = mc[0] if mc else None
         msm["result_check"] = ("== (sum s_i*k_i mod n)*G by " + checker) if checker else ("unverified (oracle/_ref not present)" if rank == 0 else "rank 0")
         # CPU baseline for this half of the metric: the reference's secp256k1_ecmult_multi_var (what bench_ecmult times,
         # src/bench_ecmult.c:278-307 -- its largest size is 32768) on one host core, same box, same inputs
@@ -756,6 +781,14 @@ def main():
             ks_h, scs_h, scs, pts = msm_inputs(nb, 199)
             ms, xy, minf = msm_time(scs, pts)
             big = block(nb, ms, xy)
+            if rank == 0 and msm.get("_counters_file"):
+                jj = json.load(open(msm["_counters_file"]))
+                if "16777216" in jj:
+                    pc = jj["16777216"]["per_call"]
+                    big["roofline"]["traffic"] = pc["hbm_bytes_raw"]; big["roofline"]["traffic_source"] = os.path.relpath(msm["_counters_file"], ROOT)
+                    if pc.get("int64_wave_instructions"):
+                        big["roofline"]["issued"] = {"int64_wave_instructions_per_call": pc["int64_wave_instructions"], "valu_wave_instructions_per_call": pc["valu_wave_instructions"],
+                                                     "int64_lane_ops_per_s": pc["int64_wave_instructions"] * 64 / (ms * 1e-3), "frac_of_peak": pc["int64_wave_instructions"] * 64 / (ms * 1e-3) / MAD32_PEAK}
             if rank == 0:
                 # the same identity, evaluated in 64 slices so that the Python integers stay short-lived
                 tot = 0
@@ -873,6 +906,7 @@ def main():
                          "process_wall_s_until_headline": time.time() - t_process}
         out["tables"] = tables
         if msm:
+            msm.pop("_counters_file", None)
             out["msm"] = msm
         if dropin:
             out["dropin"] = dropin

@@ -56,6 +56,8 @@ SIGNATURES = {
     "secp256k1_surjectionproof_verify_batch_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "secp256k1_bppp_norm_product_verify_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp, _sz]),
     "secp256k1_schnorrsig_aggverify_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int, _vp, _sz, _vp, _sz]),
+    "secp256k1_schnorrsig_aggverify_dev_chain": (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int, _vp, _sz, _vp, _sz, _vp]),
+    "s2k_halfagg_chain_states": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _sz, _vp]),
     "secp256k1_pedersen_verify_tally_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_rangeproof_rewind_batch_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "secp256k1_bppp_commit_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp, _sz]),

@@ -80,7 +80,7 @@ static void ha_host_chain(u32* states, const ha_host_src& h, size_t nblocks) {
 // hash chain is then walked on the host underneath the point-lifting kernel and its states uploaded (the device chain is 2.4 us per
 // block on one wavefront: 118 ms for 2^15 signatures against ~2.6 ms here); nullptr: the device chain.
 static int ha_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res, const unsigned char* d_pk, int pk_format, const unsigned char* d_msg, size_t n,
-                     const unsigned char* d_agg, const ha_host_src* host = nullptr) {
+                     const unsigned char* d_agg, const ha_host_src* host = nullptr, const u32* d_states_in = nullptr) {
     const size_t nblocks = (3 * n) >> 1;
     unsigned char* d_pts = c.take<unsigned char>(128 * n + 64);
     unsigned char* d_pkx = c.take<unsigned char>(32 * n + 64); u32* d_wk = c.take<u32>(nblocks * 64 + 16); u32* d_states = c.take<u32>(nblocks * 8 + 16);
@@ -98,7 +98,9 @@ static int ha_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res
     HIPCHK(hipEventRecord(e->ev[0], st));
     const unsigned bn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_ha_points, dim3(bn), dim3(256), 0, st, d_pts, d_pkx, d_flags, d_agg, d_pk, pk_format, n);
-    if (nblocks && host) {
+    if (nblocks && d_states_in) {
+        d_states = const_cast<u32*>(d_states_in);              // the caller has walked the chain (secp256k1_schnorrsig_aggverify_dev_chain)
+    } else if (nblocks && host) {
         HIPCHK(hipGetLastError());
         ha_host_chain(e->ha_pin, *host, nblocks);              // the GPU lifts the points meanwhile
         HIPCHK(hipMemcpyAsync(d_states, e->ha_pin, nblocks * 8 * sizeof(u32), hipMemcpyHostToDevice, st));
@@ -129,6 +131,35 @@ extern "C" int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, i
     if (!engine_workspace(e, ha_ws_bytes(e, n))) return 0;
     ws_carver c{e->ws, 0};
     return ha_launch(e, st, c, result_dev, pubkeys, pk_format, msgs32, n, aggsig);
+}
+// The `_dev` form with the randomizer hash's chain states supplied by the caller.  z_i hashes the whole prefix r_0|x(P_0)|m_0|...|r_i|x(P_i)|m_i
+// (src/modules/schnorrsig_halfagg/main_impl.h:153-163): a Merkle-Damgard chain of 1.5 blocks per signature that no second lane can help
+// with -- 118 ms on the device for 2^15 signatures, 2.6 ms of SHA extensions on one host core.  A caller whose inputs are in HBM usually
+// still HAS them on the host (it received them there): it walks the chain with s2k_halfagg_chain_states (or its own SHA-256), uploads the
+// 32 bytes per block, and the device only finalises every z_i in parallel.  chain_states: ((3 n) >> 1) x 8 words in HBM, state after every
+// full 64-byte block of the tagged hash's input behind the tag midstate; NULL: the device walks the chain itself (the plain `_dev` form).
+// A wrong state array gives a wrong verdict for THIS aggregate only -- it is input data of the caller, like the keys.
+extern "C" int secp256k1_schnorrsig_aggverify_dev_chain(s2k_engine* e, void* stream, int32_t* result_dev, const unsigned char* pubkeys, int pk_format,
+                                                        const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len,
+                                                        const uint32_t* chain_states) {
+    if (!e) return s2k_fail("secp256k1_schnorrsig_aggverify_dev_chain", "null engine");
+    if (!result_dev || !aggsig || ((!pubkeys || !msgs32) && n)) return s2k_fail_arg("secp256k1_schnorrsig_aggverify_dev_chain", "illegal argument (ARG_CHECK)");
+    std::lock_guard<std::recursive_mutex> lock(e->mu);
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    stream_guard sg(e, st);
+    if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) { HIPCHK(hipMemsetAsync(result_dev, 0, 4, st)); return 1; }     // main_impl.h:122-125
+    if (!engine_workspace(e, ha_ws_bytes(e, n))) return 0;
+    ws_carver c{e->ws, 0};
+    return ha_launch(e, st, c, result_dev, pubkeys, pk_format, msgs32, n, aggsig, nullptr, chain_states);
+}
+// host helper for the call above: the chain states of one aggregate, from HOST copies of its inputs (SHA extensions when the CPU has them)
+extern "C" int s2k_halfagg_chain_states(uint32_t* states_out, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32, size_t n,
+                                        const unsigned char* aggsig) {
+    if (!states_out || ((!pubkeys || !msgs32 || !aggsig) && n)) return s2k_fail_arg("s2k_halfagg_chain_states", "illegal argument (ARG_CHECK)");
+    const ha_host_src h{aggsig, pubkeys, pk_format, msgs32};
+    ha_host_chain(states_out, h, (3 * n) >> 1);
+    return 1;
 }
 extern "C" int secp256k1_schnorrsig_aggverify_amd(s2k_engine* e, int32_t* result, const unsigned char* pubkeys, int pk_format, const unsigned char* msgs32,
                                                   size_t n, const unsigned char* aggsig, size_t aggsig_len) {

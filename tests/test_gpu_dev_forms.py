@@ -66,6 +66,17 @@ def test_halfagg_tally_rewind_dev(engine, ref):
         assert L.secp256k1_schnorrsig_aggverify_dev(engine._h, None, _p(r), _p(dpk), 0, _p(dm), n, _p(da), len(a)) == 1
         assert L.s2k_engine_sync(engine._h) == 1
         assert int(r[0].item()) == exp == (0 if mutate else 1)
+        # the same with the randomizer hash's chain walked on the host (s2k_halfagg_chain_states) and only its states uploaded
+        states = np.zeros(((3 * n) >> 1, 8), np.uint32)
+        assert L.s2k_halfagg_chain_states(states.ctypes.data, pks.ctypes.data, 0, msgs.ctypes.data, n, a) == 1
+        dst = torch.tensor(states.view(np.int32)).cuda(); r2 = torch.full((4,), 9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert L.secp256k1_schnorrsig_aggverify_dev_chain(engine._h, None, _p(r2), _p(dpk), 0, _p(dm), n, _p(da), len(a), _p(dst)) == 1
+        assert L.s2k_engine_sync(engine._h) == 1 and int(r2[0].item()) == exp
+        if not mutate:                                  # states of ANOTHER aggregate: the randomizers are wrong, the equation fails
+            dst2 = dst.clone(); dst2[3, 2] ^= 1; torch.cuda.synchronize()
+            assert L.secp256k1_schnorrsig_aggverify_dev_chain(engine._h, None, _p(r2), _p(dpk), 0, _p(dm), n, _p(da), len(a), _p(dst2)) == 1
+            assert L.s2k_engine_sync(engine._h) == 1 and int(r2[0].item()) == 0
     r = torch.full((4,), 9, dtype=torch.int32, device="cuda")
     assert L.secp256k1_schnorrsig_aggverify_dev(engine._h, None, _p(r), _p(dpk), 0, _p(dm), n, _p(da), len(a) - 1) == 1      # wrong length: verdict 0
     assert L.s2k_engine_sync(engine._h) == 1 and int(r[0].item()) == 0
