@@ -137,6 +137,9 @@ S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, const gtab_ge
 #ifndef S2K_NT_PARK
 #define S2K_NT_PARK 1
 #endif
+#ifndef S2K_NT_GTAB_SPLIT
+#define S2K_NT_GTAB_SPLIT 0      /* the same hint on the generator part of ecmult_lane_split (general form of the rings kernel): A/B in profiles/r05*_ab_* */
+#endif
 #ifndef S2K_NT_GTAB
 #define S2K_NT_GTAB 1
 #endif
@@ -595,8 +598,17 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); }             // back to the real curve
     // generator part: a zero window adds nothing (per lane), so these additions are committed by select
     while (au < a_end) {
+#if S2K_NT_GTAB_SPLIT && defined(__HIP_DEVICE_COMPILE__)
+        {   // (the fixed-base operands are touched once: a non-temporal request keeps them from displacing the per-lane tables)
+            typedef unsigned int s2k_u32x4 __attribute__((ext_vector_type(4)));
+            const s2k_u32x4* q = (const s2k_u32x4*)nxt_addr;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const s2k_u32x4 v = __builtin_nontemporal_load(q + k); raw[4 * k] = v.x; raw[4 * k + 1] = v.y; raw[4 * k + 2] = v.z; raw[4 * k + 3] = v.w; }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
+#endif
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);
         if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
         if (cur_valid) R = t;

@@ -95,14 +95,14 @@ S2K_HD void gtab_fill_run(u32* gtab, const gtab_fill_plan& p, u32 w, u32 b, u32 
     const u32 rows = (w + 1u < p.W) ? p.NA : p.top_rows;
     ge c; gtab_load_d(c, gtab, p.D, w, b);
     fe ncx, ncy; fe_neg(ncx, c.x, 1); fe_neg(ncy, c.y, 1);          // -x(C), -y(C)   (2)
-    fe pre[GTAB_FILL_RUN];
+    fe pre[GTAB_FILL_RUN];                                          // (rolled loops: the prefix products live in the lane's scratch, 576 B that never leave the caches)
     fe run; fe_set_int(run, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int i = 0; i < 9; i++) S2K_OPAQUE(run.n[i]);               // (see msm_sum_refs_lean: a known constant start value pessimises the chain)
 #endif
     // up: pre[j] = d_0 ... d_(j-1), d_j = x(R[a0 + j]) - x(C)   (rows outside 1 .. rows-1: d_j = 1)
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < GTAB_FILL_RUN; j++) {
         const u32 a = a0 + (u32)j;
         pre[j] = run;
@@ -114,7 +114,7 @@ S2K_HD void gtab_fill_run(u32* gtab, const gtab_fill_plan& p, u32 w, u32 b, u32 
     }
     fe inv; fe_inv(inv, run);
     // down: 1 / d_j = inv * pre[j]; inv <- inv * d_j
-#pragma unroll
+#pragma unroll 1
     for (int j = GTAB_FILL_RUN - 1; j >= 0; j--) {
         const u32 a = a0 + (u32)j;
         if (a >= 1u && a < rows) {

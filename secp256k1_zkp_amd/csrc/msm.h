@@ -33,7 +33,16 @@
 
 #define MSM_SMALL_N 32
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
-#define MSM_TERM_WORDS 28           // x[9], beta*x[9], y[9], flags
+// Term record (round 5): two aligned 64-byte sectors of canonical words, [ x | y ] and [ beta*x | y ] -- the operand record format of the
+// rest of the engine (ecmult.h) -- so that a bucket reference gathers exactly ONE sector (the 28-word limb record of rounds 1-4 put the 72
+// bytes an addition needs across two or three sectors: round 1's gathers were ~190 B per addition, and with the leaner addition of this
+// round the kernel had become sensitive to them).  The y copy costs 32 B per term; the unpacking ~40 instructions per operand.
+#define MSM_TERM_WORDS 32
+S2K_HD void msm_store_term(u32* term, const ge& P, const fe& bx_in) {          // P.x, P.y, beta*x: any magnitude <= 2
+    fe x = P.x, y = P.y, bx = bx_in; fe_normalize(x); fe_normalize(y); fe_normalize(bx);
+    u32 wx[8], wy[8], wb[8]; fe_to_words(wx, x); fe_to_words(wy, y); fe_to_words(wb, bx);
+    for (int i = 0; i < 8; i++) { term[i] = wx[i]; term[8 + i] = wy[i]; term[16 + i] = wb[i]; term[24 + i] = wy[i]; }
+}
 
 // nb = buckets per window = 2^(c-1) + 1 (bucket 0 unused).  [w0, w0 + wn) is the range of digit windows this launch owns:
 // all of them on one GPU; a contiguous share when one MSM's bucket windows are spread over the GPUs of a node (SURVEY 8e,
@@ -180,8 +189,7 @@ S2K_HD void msm_prep_term(u32* term, u32* halves, const unsigned char* sc32, con
     else { fe_set_b32_mod(P.x, pt64); fe_set_b32_mod(P.y, pt64 + 32); fe_norm_weak(P.x); fe_norm_weak(P.y); }
     const int active = (!pt_inf) & (!sc_is_zero(k));
     fe beta, bx; fe_set_beta(beta); fe_mul(bx, P.x, beta);
-    for (int i = 0; i < 9; i++) { term[i] = P.x.n[i]; term[9 + i] = bx.n[i]; term[18 + i] = P.y.n[i]; }
-    term[27] = (u32)active;
+    msm_store_term(term, P, bx);
     scalar k1s, k2s; half_scalar h0, h1;
     sc_split_lambda(k1s, k2s, k);
     sc_to_half(h0, k1s); sc_to_half(h1, k2s);
@@ -201,7 +209,7 @@ S2K_HD u32 msm_key_at(const u32* halves, int half, u32 w, const msm_wconst& wc, 
 }
 
 // ---- pass 1 (exact counting-sort form, used by the host emulation and kept as the reference for msm_digit_at) ------------------------------------------------------------------------------
-// term_data[i] : 28 words (x, beta x, y limbs, flags bit0 = active)
+// term_data[i] : MSM_TERM_WORDS words (msm_store_term)
 // keys[(2*i + h) * W + w] = bucket key (w*nb + |d|) << 1 | sign  (0 = no contribution)
 S2K_HD void msm_prep(u32* term, u32* keys, u32* hist, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g,
                      const msm_plan& pl) {
@@ -213,8 +221,7 @@ S2K_HD void msm_prep(u32* term, u32* keys, u32* hist, const unsigned char* sc32,
     else { fe_set_b32_mod(P.x, pt64); fe_set_b32_mod(P.y, pt64 + 32); fe_norm_weak(P.x); fe_norm_weak(P.y); }
     const int active = (!pt_inf) & (!sc_is_zero(k));
     fe beta, bx; fe_set_beta(beta); fe_mul(bx, P.x, beta);
-    for (int i = 0; i < 9; i++) { term[i] = P.x.n[i]; term[9 + i] = bx.n[i]; term[18 + i] = P.y.n[i]; }
-    term[27] = (u32)active;
+    msm_store_term(term, P, bx);
     scalar k1s, k2s; half_scalar h[2];
     sc_split_lambda(k1s, k2s, k);
     sc_to_half(h[0], k1s); sc_to_half(h[1], k2s);
@@ -283,14 +290,11 @@ S2K_HD void gej_set_gez(gej& r, const gez& a) {    // (X*ZZ, Y*ZZZ, ZZ) is the s
     r.z = a.zz;
 }
 // refs[j] = term_index << 2 | half << 1 | neg
+S2K_HD void msm_ref_point(ge& p, u32 r, const u32* term_data);
 S2K_HD void msm_sum_refs(gej& out, const u32* refs, size_t start, size_t end, const u32* term_data) {
     gez acc; acc.inf = 1; fe_set_zero(acc.x); fe_set_zero(acc.y); fe_set_zero(acc.zz); fe_set_zero(acc.zzz);
     for (size_t j = start; j < end; j++) {
-        const u32 r = refs[j];
-        const u32* t = term_data + (size_t)(r >> 2) * MSM_TERM_WORDS;
-        ge p; const int half = (r >> 1) & 1, neg = r & 1;
-        for (int i = 0; i < 9; i++) { p.x.n[i] = half ? t[9 + i] : t[i]; p.y.n[i] = t[18 + i]; }
-        if (neg) { fe_neg(p.y, p.y, 1); }
+        ge p; msm_ref_point(p, refs[j], term_data);
         gez_add_ge(acc, p);
     }
     gej_set_gez(out, acc);
@@ -324,10 +328,17 @@ S2K_HD void gez_add_ge_lean(gez& a, const ge& b) {
 }
 // the operand a bucket reference names: (x or beta*x, +-y) of its term record
 S2K_HD void msm_ref_point(ge& p, u32 r, const u32* term_data) {
-    const u32* t = term_data + (size_t)(r >> 2) * MSM_TERM_WORDS;
-    const u32* tx = t + ((r >> 1) & 1u) * 9u;
+    const u32* t = term_data + (size_t)(r >> 2) * MSM_TERM_WORDS + ((r >> 1) & 1u) * 16u;      // one aligned 64-byte sector: [ x | y ] or [ beta*x | y ]
+    u32 w[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int msm_u32x4 __attribute__((ext_vector_type(4)));
+    const msm_u32x4* q = (const msm_u32x4*)t;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { p.x.n[i] = tx[i]; p.y.n[i] = t[18 + i]; }
+    for (int k = 0; k < 4; k++) { const msm_u32x4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+#else
+    for (int k = 0; k < 16; k++) w[k] = t[k];
+#endif
+    fe_from_words(p.x, w); fe_from_words(p.y, w + 8);
     if (r & 1u) fe_neg(p.y, p.y, 1);
 }
 // returns 1 with the run's sum in `out`; 0 when the run met an exceptional addition (the caller sums it again with msm_sum_refs)
