@@ -291,6 +291,25 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
                         "ms": sec * 1e3, "batch": nb, "g_len": 64, "h_len": 8, "verified": True,
                         "result_check": "== secp256k1_bppp_rangeproof_norm_product_verify of the reference on the 64 distinct proofs (61 valid, 3 broken), tiled %d times" % reps,
                         "roofline": roof(MAC64_PER_MSM_TERM_SMALL * terms, nb, sec, "algorithmic %d terms x 10.6e3 MAC64 per term per proof (SURVEY 8d, the 1 024-term schedule)" % terms)}
+    # the same batches through TWO engines on the device (each its own stream and scratch; the tables of G are the device's): a call is a chain of
+    # latency-bound stages -- 13 full double multiplications per proof on ~40 % of the lane slots -- so what a verifier with two submitting
+    # threads sees is two chains side by side
+    eng_b = Engine(eng.device)
+    try:
+        res_b = torch.zeros(nb, dtype=torch.int32, device=dev)
+        call_b = lambda: eng_b.bppp_norm_product_verify_batch_dev(res_b, d_pr, pr.shape[1], d_tr, d_rho, d_gens, gens, base[4], d_cv, base[5].shape[1], d_cm, nb)
+        call(); call_b(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call(); call_b()
+        torch.cuda.synchronize()
+        sec2 = (time.perf_counter() - t0) / (2 * steps)
+        assert np.array_equal(res_b.cpu().numpy(), np.tile(want, reps)) and np.array_equal(res.cpu().numpy(), np.tile(want, reps)), "BP++ verdicts differ with two engines"
+        out["bppp_2p12"]["two_engines"] = {"value": nb / sec2, "ms_per_batch": sec2 * 1e3, "verified": True,
+                                           "roofline_frac": 4 * MAC64_PER_MSM_TERM_SMALL * terms * nb / sec2 / MAD32_PEAK,
+                                           "note": "batches submitted alternately to two engines on the device (two streams); per-batch time = wall / batches"}
+    finally:
+        eng_b.close()
     if with_cpu:
         k = 256
         idx = np.arange(k) % 64
