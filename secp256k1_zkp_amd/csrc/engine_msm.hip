@@ -413,7 +413,10 @@ __global__ void k_msm_counts(u32* cnt_out, u32* cnt_clamped, const u32* cnt_in, 
         cnt_out[k] = (c + T - 1) / T;
     }
 }
-__global__ void __launch_bounds__(256, 2)
+#ifndef MSM_R1_WAVES
+#define MSM_R1_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, MSM_R1_WAVES)
 k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* cnt_in, msm_layout L, msm_plan pl, const u32* off_out, const u32* term, u32 nk, u32 T) {
     const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= off_out[nk]) return;
@@ -602,7 +605,19 @@ static u32 msm_run_len(const s2k_engine* e, size_t E, const msm_plan& pl, const 
     // (measured at 2^20 terms: T = 24 2.17 ms, T = 128 2.33 ms; at 2^22: T = 48 7.26 ms, T = 128 7.38 ms)
     u32 T = (u32)(E / 786432); if (T < 8) T = 8; if (T > 64) T = 64; return T;
 }
-#define MSM_T2 8u
+#define MSM_T2 8u                        /* run length of the later rounds: the smallest that the sizes below assume */
+#define MSM_T2_MAX 12u
+// Run length of the later partial-sum rounds.  The NUMBER of rounds follows from the bucket-region capacity (nothing is read back): T, T T2,
+// T T2^2, ... until the fullest region is covered, and a round is three launches (counts, scan, sums) of latency.  At 2^20 terms the top
+// window's regions (capacity 2 516, sized for its non-uniform values) made that four rounds with T2 = 8 where 10 covers them in three: the
+// smallest T2 in [8, 12] that gives the fewest rounds is taken (a lane of a later round then adds up to T2 Jacobian partials).
+static u32 msm_later_run_len(const s2k_engine* e, u32 T, u32 maxcap) {
+    if (e->msm_diag.T2 >= (int)MSM_T2 && e->msm_diag.T2 <= 64) return (u32)e->msm_diag.T2;      // diagnostic override (-DS2K_DIAG builds)
+    auto rounds_for = [&](u32 t2) { int r = 1; size_t reach = T; while (reach < maxcap) { reach *= t2; r++; } return r; };
+    u32 best = MSM_T2; int br = rounds_for(MSM_T2);
+    for (u32 t2 = MSM_T2 + 1; t2 <= MSM_T2_MAX; t2++) { const int r = rounds_for(t2); if (r < br) { br = r; best = t2; } }
+    return best;
+}
 #define MSM_DIRECT_LANES 16384u          /* lanes of the bucket-free exact path (each walks its terms with a stride) */
 msm_plan engine_msm_plan(const s2k_engine* e, size_t nt) { return msm_make_plan(nt, e->msm_diag.c); }
 size_t msm_ws_bytes(const s2k_engine* e, size_t nt, const msm_plan& pl) {
@@ -669,7 +684,7 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
     const size_t E = nt * 2 * pl.wn;                           // upper bound on this share's bucket references
     const msm_layout L = msm_make_layout(nt, pl);
     const msm_plan full = engine_msm_plan(e, nt);              // (run length as msm_ws_bytes sized the buffers for: from the whole plan, not the share)
-    const u32 T = msm_run_len(e, nt * 2 * pl.windows, full, L), T2 = MSM_T2;
+    const u32 T = msm_run_len(e, nt * 2 * pl.windows, full, L);
     const size_t bound1 = (size_t)nk + E / T + 2;
     u32* term = c.take<u32>(nt * MSM_TERM_WORDS); u32* halves = c.take<u32>(nt * MSM_HALF_WORDS);
     u32* gcnt = c.take<u32>(nk + 1); u32* gclamp = c.take<u32>(nk + 1); u32* spare = c.take<u32>(nk + 1);
@@ -719,6 +734,7 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
     // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
     const int has_top = (pl.w0 + pl.wn == pl.windows);
     const u32 maxcap = std::max(pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, has_top ? L.cap_top : 0u);
+    const u32 T2 = msm_later_run_len(e, T, maxcap);
     int rounds = 1; { size_t reach = T; while (reach < maxcap) { reach *= T2; rounds++; } }
     // round 1: references -> partial sums (at most T references each)
     launch_scan(st, offA, nullptr, tile_sum, cntA, nk);
