@@ -465,3 +465,20 @@ def test_emu_seeded_table_construction(emu, ref):
     for D in (9, 10, 11, 12, 13):
         assert emu.emu_gtab_seeded_construction(D, None) == 0, D
     assert emu.emu_gtab_seeded_construction(12, ref.rand_point(rng)) == 0
+
+
+def test_emu_msm_exhaustive_edge_group(emu, ref):
+    """the shape of the reference's test_exhaustive_ecmult_multi (src/tests_exhaustive.c:198-227) through the host build of the bucket pipeline
+    (tests/exhaustive_msm.py; the full edge lists run on the device, tests/test_gpu_msm_exhaustive.py): every i*P_x + j*P_y + k*G over a
+    sub-list of the edge scalars and points, at the plan's window width and at a forced narrow one"""
+    from tests import exhaustive_msm as xm
+    S = [0, 1, 2, N - 1, xm.LAMBDA, (1 << 128) - 1]; Pm = [0, 1, N - 1, 2, xm.LAMBDA]
+    pxy, pinf = xm.group_points(ref, Pm)
+    combos = list(xm.cases(S, range(len(Pm))))
+    want = xm.expected_points(ref, [(i * Pm[x] + j * Pm[y] + k) % N for (i, j, k, x, y) in combos])
+    out = ctypes.create_string_buffer(64)
+    for t, (i, j, k, x, y) in enumerate(combos):
+        sc = np.stack([xm._b(i), xm._b(j)]); pts = np.stack([pxy[x], pxy[y]]); inf = np.array([pinf[x] != 0, pinf[y] != 0], np.uint8)
+        rinf = emu.emu_msm(out, bytes(xm._b(k)), sc.tobytes(), pts.tobytes(), inf.tobytes(), ctypes.c_size_t(2), 4 if t % 2 else 0)
+        exy, einf = want[(i * Pm[x] + j * Pm[y] + k) % N]
+        assert rinf >= 0 and bool(rinf) == einf and (einf or out.raw == exy), (hex(i), hex(j), hex(k), x, y)
