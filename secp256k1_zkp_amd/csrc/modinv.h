@@ -37,8 +37,10 @@ struct ds_modulus { int32_t w[DS_LIMBS]; u32 inv; };    // modulus in that form 
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DS_WAVE_ANY(p) (__any(p))
+#define DS_WAVE_ALL(p) (__all(p))
 #else
 #define DS_WAVE_ANY(p) (p)
+#define DS_WAVE_ALL(p) (p)
 #endif
 
 S2K_HD int ds_ctz32(u32 x) { return __builtin_ctz(x | 0x80000000u); }         // <= 31 also for x = 0
@@ -119,6 +121,15 @@ S2K_HD void ds_inverse_words(u32 o[8], const u32 w[8], const ds_modulus md) {
         zeta = ds_batch(zeta, (u32)f.w[0], (u32)g.w[0], t);
         ds_apply<true>(d, e, t, md);
         ds_apply<false>(f, g, t, md);
+        // 590 steps is the worst case; random inputs are through after 501..531 of them (18 batches).  Once g = 0 a further batch leaves f
+        // and d as they are (its matrix is diag(2^30, 1): d <- (2^30 d + 0 m) / 2^30), so stopping when EVERY lane of the wavefront has
+        // g = 0 gives bit for bit the result of running all 20 batches.
+        if (it >= DS_BATCHES - 5) {
+            int32_t gz = 0;
+#pragma unroll
+            for (int i = 0; i < DS_LIMBS; i++) gz |= g.w[i];
+            if (DS_WAVE_ALL(gz == 0)) break;
+        }
     }
     // now g = 0, f = +-gcd = +-1 (or f = +-m when the input was 0, with d = 0), and d * input == f (mod m), |d| < 21 m.
     // r = d + 32 m > 0; quotient estimate q = r >> 256 (m = 2^256 - c, c < 2^129, so r - q m = (r mod 2^256) + q c < 2 m)
