@@ -111,6 +111,8 @@ def sources_sha256():
     try:
         h = hashlib.sha256()
         for f in sorted(os.listdir(csrc)):
+            if not f.endswith((".h", ".hip")):          # (object directories of build_lib.py live next to the sources)
+                continue
             h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
         h.update(open(hdr, "rb").read())
         return h.hexdigest()

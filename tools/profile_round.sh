@@ -74,3 +74,5 @@ grep -c "W" gpurun_out/$TAG/power_clock.txt; sort -t: -k5 gpurun_out/$TAG/power_
 # the MSM alone: through the device entry point at a range of sizes, and its per-kernel times at 1 024, 2^20 and 2^24 terms
 timeout 300 python tools/msm_bare.py 33 64 256 1024 4096 16384 65536 262144 1048576 4194304 16777216 > gpurun_out/$TAG/msm_bare.txt 2>/dev/null; cat gpurun_out/$TAG/msm_bare.txt
 bash tools/msm_breakdown.sh $TAG/x 1024 1048576 16777216 2>/dev/null; ls gpurun_out/$TAG/
+# round 5: counters of the MSM kernels (stamped like the files above)
+S2K_GIT_HEAD=${S2K_GIT_HEAD:-unknown} bash tools/profile_msm.sh $TAG 1048576 16777216 2>&1 | tail -6
