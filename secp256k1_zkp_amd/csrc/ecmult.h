@@ -137,6 +137,13 @@ S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, const gtab_ge
 #ifndef S2K_NT_PARK
 #define S2K_NT_PARK 1
 #endif
+// S2K_XYZZ_TABLE_PART: the run of fixed-base additions at the end of a multiplication (W from G's table, W more from the generator's in the
+// ring form) has no doubling in between, so its accumulator can stay in extended Jacobian form (X, Y, ZZ, ZZZ: group.h): an addition then
+// costs 8M + 2S instead of 8M + 3S, and the same-x test of every addition becomes ONE zero test of ZZ behind the run (an exceptional
+// addition zeroes ZZ for good; additions of zero digits are not committed, so they cannot).  In: ZZ = Z^2, ZZZ = Z ZZ; out: (X ZZ, Y ZZZ, ZZ).
+#ifndef S2K_XYZZ_TABLE_PART
+#define S2K_XYZZ_TABLE_PART 0
+#endif
 #ifndef S2K_NT_GTAB_SPLIT
 #define S2K_NT_GTAB_SPLIT 0      /* the same hint on the generator part of ecmult_lane_split (general form of the rings kernel): A/B in profiles/r05*_ab_* */
 #endif
@@ -597,6 +604,10 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
     }
     { fe zi; ptab_load_ziso(zi, ptab); fe_mul(R.z, R.z, zi); }             // back to the real curve
     // generator part: a zero window adds nothing (per lane), so these additions are committed by select
+#if S2K_XYZZ_TABLE_PART
+    gez acc4; acc4.inf = 0; acc4.x = R.x; acc4.y = R.y;
+    fe_sqr(acc4.zz, R.z); fe_mul(acc4.zzz, acc4.zz, R.z);
+#endif
     while (au < a_end) {
 #if S2K_NT_GTAB_SPLIT && defined(__HIP_DEVICE_COMPILE__)
         {   // (the fixed-base operands are touched once: a non-temporal request keeps them from displacing the per-lane tables)
@@ -609,13 +620,24 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
 #endif
+#if S2K_XYZZ_TABLE_PART
+        {
+            gez t = acc4; gez_add_ge_lean(t, cur);
+            fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid);
+        }
+#else
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);
         if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
         if (cur_valid) R = t;
+#endif
         au++;
         op_decode(cur, raw, nxt_neg, nxt_lam); cur_valid = nxt_valid;
         op_locate(nxt_addr, nxt_valid, nxt_neg, nxt_lam, au + 1);
     }
+#if S2K_XYZZ_TABLE_PART
+    if (S2K_WAVE_ANY(fe_normalizes_to_zero(acc4.zz))) return 0;
+    gej_set_gez(R, acc4);
+#endif
     S2K_PROF_MARK(10);
 #ifdef S2K_ON_SPLIT_DONE
     S2K_ON_SPLIT_DONE();                                                                      // host test build: count completed split runs
@@ -769,6 +791,10 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
         fe_mul(R.z, R.z, zi);
     }
     // table part (G, then H): a zero window adds nothing (per lane), so these additions are committed by select
+#if S2K_XYZZ_TABLE_PART
+    gez acc4; acc4.inf = 0; acc4.x = R.x; acc4.y = R.y;
+    fe_sqr(acc4.zz, R.z); fe_mul(acc4.zzz, acc4.zz, R.z);
+#endif
     while (au < a_end) {
 #if S2K_NT_GTAB && defined(__HIP_DEVICE_COMPILE__)
         {
@@ -781,13 +807,24 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
 #pragma unroll
         for (int k = 0; k < 16; k++) raw[k] = nxt_addr[k];
 #endif
+#if S2K_XYZZ_TABLE_PART
+        {
+            gez t = acc4; gez_add_ge_lean(t, cur);
+            fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid);
+        }
+#else
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);
         if (S2K_WAVE_ANY(same_x & cur_valid)) return 0;
         if (cur_valid) R = t;
+#endif
         au++;
         op_decode(cur, raw, nxt_neg, 0); cur_valid = nxt_valid;
         op_locate(nxt_addr, nxt_valid, nxt_neg, au + 1);
     }
+#if S2K_XYZZ_TABLE_PART
+    if (S2K_WAVE_ANY(fe_normalizes_to_zero(acc4.zz))) return 0;      // some committed addition met an operand with the accumulator's own x
+    gej_set_gez(R, acc4);
+#endif
     S2K_PROF_MARK(10);
 #ifdef S2K_ON_RING_STEP_DONE
     S2K_ON_RING_STEP_DONE();

@@ -206,3 +206,69 @@ S2K_HD int ge_is_valid(const ge& a) {
     fe y2, c; fe_sqr(y2, a.y); ge_curve_rhs(c, a.x); fe_norm_weak(c);
     return fe_equal(y2, c);
 }
+
+// ---- extended Jacobian ("XYZZ") accumulators: bucket sums of the MSM (msm.h) and the table parts of the double multiplications (ecmult.h) ----
+// Bucket accumulator in extended Jacobian ("XYZZ") coordinates: x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2.  Adding an affine point
+// costs 8M + 2S (one squaring less than the Jacobian mixed addition) and all ten products go out as lockstep pairs.
+// Magnitudes: X <= 1, Y <= 3, ZZ, ZZZ 1.
+struct gez { fe x, y, zz, zzz; int inf; };
+S2K_HD void gez_add_ge(gez& a, const ge& b) {
+    if (a.inf) { a.x = b.x; a.y = b.y; fe_set_int(a.zz, 1); fe_set_int(a.zzz, 1); a.inf = 0; return; }
+    fe u2, s2, p, r;
+    fe_mul2(u2, b.x, a.zz, s2, b.y, a.zzz);
+    fe_neg(p, a.x, 1); fe_add(p, u2);              // P = U2 - X1      (3)
+    fe_neg(r, a.y, 3); fe_add(r, s2);              // R = S2 - Y1      (5)
+    fe_norm_seq(p); fe_norm_seq(r);
+    if (fe_seq_is_zero(p)) {
+        if (!fe_seq_is_zero(r)) { a.inf = 1; return; }                 // b == -a
+        gej t, d; gej_set_ge(t, b); gej_double(d, t);                  // b == a: 2b, back to XYZZ
+        a.x = d.x; a.y = d.y; fe_norm_weak(a.x); fe_norm_weak(a.y);
+        fe_sqr(a.zz, d.z); fe_mul(a.zzz, a.zz, d.z);
+        return;
+    }
+    fe pp, rr, ppp, q;
+    fe_sqr2(pp, p, rr, r);
+    fe_mul2(ppp, p, pp, q, a.x, pp);
+    fe x3, t1, nq, y3a, y3b;
+    fe_neg(x3, ppp, 1); fe_neg(nq, q, 1);
+    fe_add(x3, nq); fe_add(x3, nq); fe_add(x3, rr); // X3 = R^2 - PPP - 2Q (7)
+    fe_norm_weak(x3);
+    fe_neg(t1, x3, 1); fe_add(t1, q);              // Q - X3           (3)
+    fe_mul2(y3a, r, t1, y3b, a.y, ppp);            // (1*3), (3*1)
+    fe_mul2(a.zz, a.zz, pp, a.zzz, a.zzz, ppp);
+    fe_neg(y3b, y3b, 1); fe_add(y3a, y3b);         // Y3               (3)
+    a.x = x3; a.y = y3a;
+}
+S2K_HD void gej_set_gez(gej& r, const gez& a) {    // (X*ZZ, Y*ZZZ, ZZ) is the same point in Jacobian coordinates
+    r.inf = a.inf;
+    if (a.inf) { fe_set_zero(r.x); fe_set_zero(r.y); fe_set_zero(r.z); return; }
+    fe_mul2(r.x, a.x, a.zz, r.y, a.y, a.zzz);
+    r.z = a.zz;
+}
+// ---- the lean form of the same accumulation (round 5) --------------------------------------------------------------------------------
+// No case analysis per addition.  An exceptional addition (the operand has the accumulator's x: P + P or P - P) makes P = U2 - X1 == 0,
+// hence ZZ3 = ZZ * P^2 == 0 -- and ZZ then STAYS 0 through every later addition of the run (a product with a zero factor), while a run
+// without one keeps ZZ != 0 (a product of non-zero field elements).  So one zero test of ZZ at the END of a run tells whether any of its
+// additions was exceptional, and only then is the run summed again by the exact form above (adversarial inputs only: equal or opposite
+// points in one bucket).  Besides the two zero tests this drops the sequential carry passes (P and R only need a weak normalisation as
+// inputs of the squarings) and pays ONE reduction for Y3 = R (Q - X3) - Y1 PPP (fe_muladd).  Static count of round 1's loop body: 1 956 ->
+// 1 5xx VALU instructions per bucket addition.
+// Magnitudes: a.x, a.y, a.zz, a.zzz 1 on entry and on exit; b.x 1, b.y <= 2.
+S2K_HD void gez_add_ge_lean(gez& a, const ge& b) {
+    fe u2, s2, p, r;
+    fe_mul2(u2, b.x, a.zz, s2, b.y, a.zzz);
+    fe_neg(p, a.x, 1); fe_add(p, u2); fe_norm_weak(p);          // P = U2 - X1      (3 -> 1)
+    fe_neg(r, a.y, 1); fe_add(r, s2); fe_norm_weak(r);          // R = S2 - Y1      (3 -> 1)
+    fe pp, rr, ppp, q;
+    fe_sqr2(pp, p, rr, r);
+    fe_mul2(ppp, p, pp, q, a.x, pp);
+    fe x3, nq, t1, ny;
+    fe_neg(x3, ppp, 1); fe_neg(nq, q, 1);
+    fe_add(x3, nq); fe_add(x3, nq); fe_add(x3, rr);             // X3 = R^2 - PPP - 2Q (7)
+    fe_norm_weak(x3);
+    fe_neg(t1, x3, 1); fe_add(t1, q);                           // Q - X3           (3)
+    fe_neg(ny, a.y, 1);                                         // -Y1              (2)
+    fe_muladd<false, false>(a.y, r, t1, ny, ppp);               // Y3 = R (Q - X3) - Y1 PPP: 1*3 + 2*1 = 5 <= 7, one reduction
+    fe_mul2(a.zz, a.zz, pp, a.zzz, a.zzz, ppp);
+    a.x = x3;
+}
