@@ -574,8 +574,9 @@ def main():
     t_tab = time.perf_counter(); tab_sz = ctypes.c_size_t(0)
     assert eng._lib.s2k_engine_gtable(eng._h, ctypes.byref(tab_sz)), "no generator table"
     tables = {"digit_bits": int(eng._lib.s2k_engine_gtable_bits(eng._h)), "bytes_per_table": int(tab_sz.value),
-              "first_use_ms_incl_allocation": (time.perf_counter() - t_tab) * 1e3,
-              "note": "table of G: allocated and built on the device by the first call that needs it (csrc/gtable.h: seeds + one affine addition per entry with shared inversions)"}
+              "first_use_ms_incl_allocation": (time.perf_counter() - t_tab) * 1e3, "build_ms_device": float(eng._lib.s2k_engine_gtable_build_ms(eng._h)),
+              "note": "table of G: allocated and built on the device by the first call that needs it (csrc/gtable.h: seeds + one affine addition per entry with shared inversions); "
+                      "build_ms_device = the construction kernels by HIP events; the wall figure also holds the allocation, which takes seconds when another process has just freed tens of GB on the device"}
     n = args.batch
     dev = torch.device("cuda", local)
     if world > 1 and n % world == 0:

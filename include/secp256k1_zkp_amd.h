@@ -103,6 +103,8 @@ S2K_API const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes);
  * width down, so an engine also exists on a partitioned or shared GPU; rangeproof generator tables take the same width.  Results do not
  * depend on the width.  The reference's knob of this kind is ECMULT_WINDOW_SIZE (src/ecmult.h:14-38). */
 S2K_API int s2k_engine_gtable_bits(s2k_engine* e);
+/* Device time (ms, HIP events) the construction of the table of G took on this device; negative before the table exists. */
+S2K_API float s2k_engine_gtable_build_ms(s2k_engine* e);
 /* Wall-clock of the most recent launch group on this engine as measured with hipEvents on its stream (ms);
  * `which`: 0 = whole call, 1 = dominant kernel only; 16 + k = dominant kernel of the k-th most recent rangeproof call (k < 32:
  * several calls may be in flight, see S2K_OPT_RP_INPUTS_READY).  Valid after s2k_engine_sync(). */

@@ -27,6 +27,7 @@ SIGNATURES = {
     "s2k_engine_generator_cached": (_c.c_int, [_vp, _vp]),
     "s2k_engine_gtable": (_vp, [_vp, _c.POINTER(_sz)]),
     "s2k_engine_gtable_bits": (_c.c_int, [_vp]),
+    "s2k_engine_gtable_build_ms": (_c.c_float, [_vp]),
     "s2k_engine_last_ms": (_c.c_float, [_vp, _c.c_int]),
     "s2k_engine_last_msm_fallback": (_c.c_int, [_vp]),
     "s2k_engine_rp_handback": (_c.c_int, [_vp, _vp]),

@@ -141,8 +141,10 @@ S2K_HD int gtab_locate(const u32*& addr, int& neg, const u32* tab, const gtab_ge
 // ring form) has no doubling in between, so its accumulator can stay in extended Jacobian form (X, Y, ZZ, ZZZ: group.h): an addition then
 // costs 8M + 2S instead of 8M + 3S, and the same-x test of every addition becomes ONE zero test of ZZ behind the run (an exceptional
 // addition zeroes ZZ for good; additions of zero digits are not committed, so they cannot).  In: ZZ = Z^2, ZZZ = Z ZZ; out: (X ZZ, Y ZZZ, ZZ).
+// A/B on one box, three alternating rounds (profiles/r05x_ab_xyzz_table_part.txt): general form (every proof its own generator) +0.9 % in
+// every round, shared-generator form +0.3 % (inside its noise), BIP-340 (ecmult_lane: its table part is not a loop of its own) unchanged.
 #ifndef S2K_XYZZ_TABLE_PART
-#define S2K_XYZZ_TABLE_PART 0
+#define S2K_XYZZ_TABLE_PART 1
 #endif
 #ifndef S2K_NT_GTAB_SPLIT
 #define S2K_NT_GTAB_SPLIT 0      /* the same hint on the generator part of ecmult_lane_split (general form of the rings kernel): A/B in profiles/r05*_ab_* */
@@ -623,7 +625,8 @@ S2K_HD int ecmult_lane_split(gej& R, const gej& A, const gej& T, const scalar& n
 #if S2K_XYZZ_TABLE_PART
         {
             gez t = acc4; gez_add_ge_lean(t, cur);
-            fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid);
+            if (S2K_WAVE_ALL(cur_valid)) acc4 = t;               // (a zero digit -- one window value in 2^D -- is the only reason for the selects)
+            else { fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid); }
         }
 #else
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);
@@ -810,7 +813,8 @@ S2K_HD int ecmult_ring_step(gej& R, const u32* rtab, const scalar& e, const scal
 #if S2K_XYZZ_TABLE_PART
         {
             gez t = acc4; gez_add_ge_lean(t, cur);
-            fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid);
+            if (S2K_WAVE_ALL(cur_valid)) acc4 = t;               // (a zero digit -- one window value in 2^D -- is the only reason for the selects)
+            else { fe_cmov(acc4.x, t.x, cur_valid); fe_cmov(acc4.y, t.y, cur_valid); fe_cmov(acc4.zz, t.zz, cur_valid); fe_cmov(acc4.zzz, t.zzz, cur_valid); }
         }
 #else
         gej t; const int same_x = gej_add_ge_lean(t, R, cur);

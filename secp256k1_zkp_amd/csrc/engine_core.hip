@@ -198,12 +198,15 @@ static s2k_dev_pool* pool_acquire(int device) {
     if (const char* gh = getenv("S2K_GEN_CACHE_H")) p->gen_h = atoi(gh) != 0;
 #endif
     int ok = hipEventCreateWithFlags(&p->ev_gtab, hipEventDisableTiming) == hipSuccess;
+    p->ev_build[0] = p->ev_build[1] = nullptr;
+    ok = ok && hipEventCreate(&p->ev_build[0]) == hipSuccess && hipEventCreate(&p->ev_build[1]) == hipSuccess;
     for (int i = 0; ok && i < RP_GEN_SLOTS; i++) ok = hipEventCreateWithFlags(&p->gen[i].ev_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&p->gen_keys, 64 * RP_GEN_SLOTS) == hipSuccess && hipMemset(p->gen_keys, 0, 64 * RP_GEN_SLOTS) == hipSuccess;
     if (!ok) {
         s2k_fail("s2k_engine_create", "cannot create the device's table pool");
         (void)hipGetLastError();
         if (p->ev_gtab) hipEventDestroy(p->ev_gtab);
+        for (int i = 0; i < 2; i++) if (p->ev_build[i]) hipEventDestroy(p->ev_build[i]);
         for (int i = 0; i < RP_GEN_SLOTS; i++) if (p->gen[i].ev_ready) hipEventDestroy(p->gen[i].ev_ready);
         if (p->gen_keys) hipFree(p->gen_keys);
         delete p; return nullptr;
@@ -220,6 +223,7 @@ static void pool_release(s2k_dev_pool* p) {
     pool_free_tables(p);
     if (p->gen_keys) hipFree(p->gen_keys);
     if (p->ev_gtab) hipEventDestroy(p->ev_gtab);
+    for (int i = 0; i < 2; i++) if (p->ev_build[i]) hipEventDestroy(p->ev_build[i]);
     for (int i = 0; i < RP_GEN_SLOTS; i++) if (p->gen[i].ev_ready) hipEventDestroy(p->gen[i].ev_ready);
     delete p;
 }
@@ -239,7 +243,8 @@ const u32* engine_gtab(s2k_engine* e, hipStream_t st) {
             (void)hipGetLastError(); p->gtab = nullptr;
         }
         if (!p->gtab) { s2k_fail("engine_gtab", "no memory for the generator table (0.44 GB of HBM at the narrowest width)"); return nullptr; }
-        const int ok = launch_table_build(st, p->gtab, p->gtab_bits, 0) && hipEventRecord(p->ev_gtab, st) == hipSuccess;
+        const int ok = hipEventRecord(p->ev_build[0], st) == hipSuccess && launch_table_build(st, p->gtab, p->gtab_bits, 0) &&
+                       hipEventRecord(p->ev_build[1], st) == hipSuccess && hipEventRecord(p->ev_gtab, st) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); hipFree(p->gtab); p->gtab = nullptr; s2k_fail("engine_gtab", "generator table build failed"); return nullptr; }
         p->gtab_state = 1;
         return p->gtab;
@@ -510,6 +515,16 @@ extern "C" const void* s2k_engine_gtable(s2k_engine* e, size_t* bytes) {
     e->gtab = const_cast<u32*>(t);
     if (bytes) *bytes = sizeof(u32) * gtab_words_for(e->pool->gtab_bits);
     return t;
+}
+// device time of the construction of the table of G (the three kernels of gtable.h, by HIP events on the building stream), in ms; < 0 when
+// the table does not exist yet or the events are not available (another process's pool built nothing here)
+extern "C" float s2k_engine_gtable_build_ms(s2k_engine* e) {
+    if (!e) return -1.0f;
+    std::lock_guard<std::recursive_mutex> lock(e->pool->mu);
+    float ms = -1.0f;
+    if (e->pool->gtab_state == 0 || hipSetDevice(e->device) != hipSuccess) return ms;
+    if (hipEventSynchronize(e->pool->ev_build[1]) != hipSuccess || hipEventElapsedTime(&ms, e->pool->ev_build[0], e->pool->ev_build[1]) != hipSuccess) { (void)hipGetLastError(); ms = -1.0f; }
+    return ms;
 }
 extern "C" int s2k_engine_gtable_bits(s2k_engine* e) {
     if (!e) return 0;

@@ -186,6 +186,7 @@ struct s2k_dev_pool {
     int device; int refs;
     std::recursive_mutex mu;
     u32* gtab; hipEvent_t ev_gtab; int gtab_state;           // 0: not built, 1: build queued (ev_gtab behind it), 2: known to be complete
+    hipEvent_t ev_build[2];                                   // around the construction kernels of the table of G (s2k_engine_gtable_build_ms)
     u32 gtab_bits;                                            // digit width of the device's tables: wanted ($S2K_GTAB_BITS, default 26) until the table of G exists, then what fitted
     // Fixed-base tables of rangeproof generators: a small cache keyed by the 64 generator bytes.  Slot tables have the layout of gtab
     // (allocated when a slot is first used and then reused by whatever generator takes the slot); xmul is the x-table of the ring-base
