@@ -8,6 +8,9 @@
  * The table's members have exactly the C ABI of include/secp256k1_zkp_amd.h, so an application registers the engine with
  *
  *     s2k_engine *e = s2k_engine_create(0);
+ *     s2k_engine_reserve(e, 16384);        (warm-up: the device's fixed-base tables are allocated and built NOW, so that a memory
+ *                                           shortage shows here -- as a narrower table, s2k_engine_gtable_bits(e), or as a failure --
+ *                                           and not as a latency spike or a CPU fallback inside the first verification)
  *     secp256k1_amd_backend b = {0};
  *     b.engine = e;
  *     b.rangeproof_verify_batch = (secp256k1_amd_rangeproof_verify_batch_fn)secp256k1_rangeproof_verify_batch;
