@@ -269,7 +269,7 @@ int emu_rangeproof_verify_shared(unsigned long long* min_value, unsigned long lo
 }
 unsigned long long emu_ring_step_count(void) { return g_ring_steps_done; }
 
-// verification with the challenges kept, then rangeproof_rewind.h and the commitment check of k_rp_rewind (engine.hip)
+// verification with the challenges kept, then rangeproof_rewind.h and the commitment check of k_rp_rewind (engine_rangeproof.hip)
 int emu_rangeproof_rewind(unsigned char* blind_out, unsigned long long* value_out, unsigned char* msg_out, unsigned long long* outlen, const unsigned char* nonce32,
                           unsigned long long* min_value, unsigned long long* max_value, const unsigned char* commit33, const unsigned char* proof, size_t plen,
                           const unsigned char* gen64) {
@@ -450,7 +450,7 @@ int emu_surjection_verify(const unsigned char* proof, size_t plen, const unsigne
     return sj_verify_lane(proof, plen, in_tags64, n_tags, out_tag64, 1, gtab_host(), g_lm);
 }
 
-// the kernel sequence of secp256k1_schnorrsig_aggverify_amd (engine.hip) run sequentially: points, schedules, chain, scalars, MSM
+// the kernel sequence of secp256k1_schnorrsig_aggverify_amd (engine_halfagg.hip) run sequentially: points, schedules, chain, scalars, MSM
 int emu_halfagg_verify(const unsigned char* pks, int pk_format, const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len) {
     if ((aggsig_len / 32) == 0 || (aggsig_len / 32) - 1 != n || (aggsig_len % 32) != 0) return 0;
     const size_t nblocks = (3 * n) >> 1;
