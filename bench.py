@@ -269,6 +269,24 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
                           "verified": True, "result_check": "every verdict as constructed (%d broken signatures / keys rejected), %d items compared with the reference's secp256k1_schnorrsig_verify" % (int(bad.sum()), chk.size),
                           "roofline": roof(MAC64_PER_SCHNORR, n, sec, "algorithmic %.1fe3 MAC64 per signature (SURVEY 8d: ~45 k for the double multiplication + one inversion + the key's square root)" % (MAC64_PER_SCHNORR / 1e3)),
                           "hbm_roofline": {"achieved": 160.0 * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * n / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_signature": 160}}
+    # the same batches through TWO engines on the device (two streams): 2^16 signatures are 1 024 wavefronts -- exactly ONE per SIMD, where a
+    # wavefront issues an instruction every ~7.6 cycles whatever it is -- so a second batch in flight runs in the issue slots the first leaves
+    # free.  What a verifier with two submitting threads (an engine each) gets at this batch size; `value` above stays the one-engine figure.
+    eng_s = Engine(eng.device)
+    try:
+        res_s = torch.zeros(n, dtype=torch.int32, device=dev)
+        eng_s.schnorrsig_verify_batch_dev(res_s, d[0], d[1], d[2]); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.schnorrsig_verify_batch_dev(res, d[0], d[1], d[2]); eng_s.schnorrsig_verify_batch_dev(res_s, d[0], d[1], d[2])
+        torch.cuda.synchronize()
+        sec_s = (time.perf_counter() - t0) / (2 * steps)
+        assert np.array_equal(res_s.cpu().numpy(), got) and np.array_equal(res.cpu().numpy(), got), "BIP-340 verdicts differ with two engines"
+        out["bip340_2p16"]["two_engines"] = {"value": n / sec_s, "ms_per_batch": sec_s * 1e3, "verified": True,
+                                             "roofline_frac": 4 * MAC64_PER_SCHNORR * n / sec_s / MAD32_PEAK,
+                                             "note": "batches submitted alternately to two engines on the device (two streams); per-batch time = wall / batches"}
+    finally:
+        eng_s.close()
     del d, res
     # ---- config 4: 2^12 BP++ norm arguments (g_len 64, h_len 8): 64 distinct proofs by the reference's prover, tiled; three of the 64 broken
     nb = 1 << 12
