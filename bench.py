@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the hosts only support dmabuf IPC: RCCL between the ranks fails without it
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
