@@ -70,6 +70,10 @@ S2K_API void s2k_clear_status(void);
  * S2K_OPT_HALFAGG_HOST_CHAIN (default 1): the host-buffer half-aggregate verifier walks the randomizer hash chain on the host
  *   underneath the point-lifting kernel (0: on the device; same verdicts).
  * S2K_OPT_SYNC_SPLIT (default 1): a lone synchronous host-buffer rangeproof call that finds both staging sets free goes as two halves.
+ * S2K_OPT_MSM_MAX_TERMS (default 0 = 238 609 293, what 32-bit bucket references index at nine digit windows): s2k_ecmult_multi[_dev] and
+ *   s2k_ecmult_multi_partial_dev run a sum with more terms than this as consecutive launches over slices of the term arrays and add the
+ *   partial sums -- the reference's own treatment of a sum that exceeds its scratch space (src/ecmult_impl.h:804-820, :856-865).  The
+ *   result does not depend on the value; tests lower it to walk the loop at small sizes.
  * Environment: only start-up defaults are read from it, once, when an engine (or the device's table pool) is created: S2K_DEVICE,
  * S2K_GEN_CACHE, S2K_GEN_CACHE_MIN, S2K_STAGE_THREADS, S2K_GTAB_BITS.  Nothing on a call path reads the environment. */
 #define S2K_OPT_RP_INPUTS_READY 1
@@ -81,6 +85,7 @@ S2K_API void s2k_clear_status(void);
 #define S2K_OPT_STAGE_THREADS 7
 #define S2K_OPT_HALFAGG_HOST_CHAIN 8
 #define S2K_OPT_SYNC_SPLIT 9
+#define S2K_OPT_MSM_MAX_TERMS 10
 S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
 /* Rangeproof generator tables.  The four public keys of a Borromean ring differ by multiples of the proof's generator
  * (secp256k1_rangeproof_pub_expand, src/modules/rangeproof/rangeproof_impl.h:19-51), so when the engine holds a fixed-base table of that

@@ -123,7 +123,8 @@ struct s2k_engine {
     int sync_split;            // S2K_OPT_SYNC_SPLIT: a lone synchronous host-buffer rangeproof call goes as two halves
     int stage_log;             // diagnostic builds: phase times of a host-buffer call on stderr
     // diagnostic overrides of the MSM launcher (-DS2K_DIAG builds read them from the environment ONCE, at engine creation; 0 = the plan's choice)
-    struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small, T2; } msm_diag;
+    struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small, T2, old_tail, slice_r, slice_lds, slice_maxc; } msm_diag;
+    size_t msm_max_terms_opt;  // S2K_OPT_MSM_MAX_TERMS: sums with more terms go as several launches whose partial sums add (0: the 32-bit reference limit)
     u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
     std::recursive_mutex mu;
 };
@@ -216,11 +217,14 @@ int rp_ptrs_check(const char* who, int32_t* results, uint64_t* min_value, uint64
 // side: where the gated exact path runs (with its fork / join events); arena: which MSM_DIRECT_LANES-sized region of the engine's table
 // arena its lanes use (0: the engine's own calls; 1, 2: the two pipelined slots)
 struct msm_ctx { hipStream_t side; hipEvent_t fork, join; unsigned arena; };
+// where the last kernel of a launch also writes the result: the affine point (r_xy 64 bytes, r_inf) and / or a copy of the Jacobian record
+struct msm_out { unsigned char* r_xy; int32_t* r_inf; u32* out28; };
+size_t msm_max_terms(const s2k_engine* e);
 msm_plan engine_msm_plan(const s2k_engine* e, size_t nt);
 size_t msm_ws_bytes(const s2k_engine* e, size_t nt, const msm_plan& pl);
 // core of every MSM entry point: leaves the Jacobian result (28 words) at *result28 (device), stream-ordered, nothing read back
 int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
-               const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1, const msm_ctx* ctx = nullptr);
+               const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part = 0, u32 parts = 1, const msm_ctx* ctx = nullptr, const msm_out* out = nullptr);
 // segmented tree sum of Jacobian records, ping-ponging between two scratch buffers; returns where the nseg results are
 const u32* launch_gej_reduce(hipStream_t st, const u32* in, u32* bufA, u32* bufB, u32 nseg, u32 seg_len, const u32* gate = nullptr);
 void launch_set_word(hipStream_t st, u32* p, u32 v);

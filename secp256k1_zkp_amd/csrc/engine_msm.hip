@@ -4,8 +4,12 @@
 // multi-scalar multiplication (msm.h)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf, size_t n, size_t nt) {
+k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf, size_t n, size_t nt,
+           u32* zero_a, u32 words_a, u32* zero_b, u32 words_b) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the bucket counters and the flag words of this call are cleared here (they were two fill launches in front of every call)
+    for (size_t z = i; z < words_a; z += (size_t)gridDim.x * blockDim.x) zero_a[z] = 0u;
+    for (size_t z = i; z < words_b; z += (size_t)gridDim.x * blockDim.x) zero_b[z] = 0u;
     if (i >= nt) return;
     const int isg = (i == n);       // only when g_sc != NULL (nt == n + 1)
     msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
@@ -509,20 +513,243 @@ k_gej_reduce(u32* out28, const u32* in28, u32 seg_len, u32 per_block, u32 nchunk
     }
     if (t == 0) for (int i = 0; i < 28; i++) out28[(size_t)blockIdx.x * 28 + i] = sh[i];
 }
+// ---- the latency tail (round 6): bucket sums -> window sums without a per-bucket multiplication ------------------------------------------
+// The reference's window total is a running sum (ecmult_impl.h:581-588: 2 * 2^(c-1) dependent additions); rounds 2-5 of this engine gave
+// every bucket its own double-and-add by its weight (k_msm_finish) and then summed the window in trees (k_gej_reduce) -- ~20 + 12 + 6
+// DEPENDENT per-lane point operations of ~7 us each on a machine that is empty by then (a lone wavefront issues one instruction per
+// ~7.6 cycles), 0.34 ms of a 2 ms call at 2^20 terms.  Here the weights never multiply a point:
+//     sum_b b B_b  =  sum_j 2^j T_j,   T_j = sum of the buckets whose weight has bit j
+// k_msm_slices: one workgroup per (chunk of buckets, bit j, window) adds up its share of T_j -- the same masked tree for every bit, all bits
+//   side by side (the machine has the lanes: 13 slices x 10 windows x 4 chunks x 256), depth R - 1 + 8 additions;
+// k_msm_window_sums: one workgroup per window, one WAVEFRONT per bit, in the wave-cooperative arithmetic (cofield.h: a point addition
+//   in ~2 us, a doubling in ~1 us): wave j adds the chunks of T_j, doubles the sum j times, and a four-level tree over the wavefronts
+//   leaves the window sum.  ~25 us where the bucket weights + the second tree level took 0.25 ms.
+// `off_last` non-null: bucket k's partial sum is record off_last[k] of in28 if off_last[k + 1] > off_last[k] (the partial-sum rounds'
+// packed output); null: record k (k_msm_bucket_sums), infinity flagged in the record.
+// record (28 words) of a cooperative point; every lane of the wavefront calls it
+S2K_D void cgej_store28(u32* p28, const cgej& a, int inf) {
+    const u32 l = co_abs();
+    cfe y = a.y; cfe_norm_weak(y);
+    if (l < 9) { p28[l] = inf ? 0u : a.x.v; p28[9 + l] = inf ? 0u : y.v; p28[18 + l] = inf ? 0u : a.z.v; }
+    if (l == 0) p28[27] = (u32)inf;
+}
+// acc <- acc + v with the infinity flags carried beside the cooperative points (all wave-uniform)
+S2K_D void cgej_acc(cgej& acc, int& acc_inf, const cgej& v, int v_inf) {
+    if (v_inf) return;
+    if (acc_inf) { acc = v; acc_inf = 0; return; }
+    acc_inf = cgej_add(acc, v);
+}
+#define MSM_SLICE_MAX 16                 /* weights are below 2^16 (c <= 16) */
+template <int R, int BS>
+__global__ void __launch_bounds__(BS)
+k_msm_slices(u32* q28, const u32* in28, const u32* off_last, msm_plan pl, msm_layout L, u32 nchunks, u32 nslices) {
+    __shared__ u32 sh[BS * 28];
+    const u32 chunk = blockIdx.x, j = blockIdx.y, w = blockIdx.z, t = threadIdx.x;
+    gej acc; gej_set_infinity(acc);
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        const u32 b = 1u + (chunk * (u32)R + (u32)r) * (u32)BS + t;
+        int take = 0; size_t rec = 0;
+        if (b < pl.nb) {
+            const u32 k = w * pl.nb + b;
+            take = (int)((msm_bucket_weight(L, pl, k) >> j) & 1u);
+            if (off_last) { rec = off_last[k]; take &= (off_last[k + 1] > off_last[k]); } else rec = k;
+        }
+        gej v; gej_set_infinity(v);
+        if (take) gej_load28(v, in28 + rec * 28);
+        if (r == 0) acc = v;
+        else if (__any(!v.inf)) { gej s; gej_add_var(s, acc, v); acc = s; }
+    }
+    gej_store28(sh + t * 28, acc);
+    __syncthreads();
+    // the tree: per lane while a level has at least a wavefront's worth... and the last sixteen partial sums in the wave-cooperative
+    // arithmetic (a level of <= 8 additions costs the same ~8 us per lane as a full one, a cooperative addition ~3 us): wavefront v adds
+    // up records v, v + 4, v + 8, v + 12, wavefront 0 the four results.
+    u32* const dst = q28 + (((size_t)w * nslices + j) * nchunks + chunk) * 28;
+    if (BS == 256) {
+        for (u32 d = BS / 2; d >= 16; d >>= 1) {
+            if (t < d) {
+                gej a, c, r; gej_load28(a, sh + t * 28); gej_load28(c, sh + (t + d) * 28);
+                gej_add_var(r, a, c);
+                gej_store28(sh + t * 28, r);
+            }
+            __syncthreads();
+        }
+        const u32 wave = t >> 6;
+        cgej cacc; int cinf = 1; cacc.x.v = cacc.y.v = cacc.z.v = 0;
+#pragma unroll 1
+        for (u32 i = 0; i < 4; i++) { cgej v; const int vi = cgej_load28(v, sh + (wave + 4u * i) * 28); cgej_acc(cacc, cinf, v, vi); }
+        __syncthreads();
+        cgej_store28(sh + wave * 28, cacc, cinf);
+        __syncthreads();
+        if (wave == 0) {
+            cinf = 1;
+#pragma unroll 1
+            for (u32 i = 0; i < 4; i++) { cgej v; const int vi = cgej_load28(v, sh + i * 28); cgej_acc(cacc, cinf, v, vi); }
+            cgej_store28(dst, cacc, cinf);
+        }
+    } else {
+        for (u32 d = BS / 2; d >= 1; d >>= 1) {
+            if (t < d) {
+                gej a, c, r; gej_load28(a, sh + t * 28); gej_load28(c, sh + (t + d) * 28);
+                gej_add_var(r, a, c);
+                gej_store28(sh + t * 28, r);
+            }
+            __syncthreads();
+        }
+        if (t < 28) dst[t] = sh[t];
+    }
+}
+__global__ void __launch_bounds__(1024)
+k_msm_window_sums(u32* wsum28, const u32* q28, u32 nchunks, u32 nslices) {
+    __shared__ u32 sh[MSM_SLICE_MAX * 28];
+    const u32 w = blockIdx.x, wave = threadIdx.x >> 6;
+    cgej acc; int acc_inf = 1;
+    acc.x.v = acc.y.v = acc.z.v = 0;
+    if (wave < nslices) {
+        const u32* src = q28 + ((size_t)w * nslices + wave) * nchunks * 28;
+        // (the record of chunk ch + 1 is requested before the addition of chunk ch)
+        cgej nx; int nxi = cgej_load28(nx, src);
+        for (u32 ch = 0; ch < nchunks; ch++) {
+            const cgej v = nx; const int vi = nxi;
+            if (ch + 1 < nchunks) nxi = cgej_load28(nx, src + (size_t)(ch + 1) * 28);
+            cgej_acc(acc, acc_inf, v, vi);
+        }
+        if (!acc_inf) {
+#pragma unroll 1
+            for (u32 k = 0; k < wave; k++) cgej_double(acc);
+        }
+    }
+    for (u32 d = MSM_SLICE_MAX / 2; d >= 1; d >>= 1) {
+        if (wave >= d && wave < 2 * d) cgej_store28(sh + wave * 28, acc, acc_inf);
+        __syncthreads();
+        if (wave < d) { cgej v; const int vi = cgej_load28(v, sh + (wave + d) * 28); cgej_acc(acc, acc_inf, v, vi); }
+    }
+    if (wave == 0) cgej_store28(wsum28 + (size_t)w * 28, acc, acc_inf);
+}
+// small inputs: the bucket sums alone (one lane per bucket walks its whole region), records in bucket order
+__global__ void __launch_bounds__(256)
+k_msm_bucket_sums(u32* out28, const u32* refs, const u32* gcnt, const u32* term, msm_plan pl, msm_layout L) {
+    const u32 w = blockIdx.y, b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= pl.nb) return;
+    gej o; gej_set_infinity(o);
+    const u32 k = w * pl.nb + b;
+    if (b) {
+        const int top = (pl.w0 + w + 1 == pl.windows);
+        const u32 cap = top ? (b < L.top_used ? L.cap_top : 0u) : L.cap;
+        u32 cnt = gcnt[k]; cnt = cnt < cap ? cnt : cap;            // (an overflowing region raised the flag: the result comes from the exact path)
+        if (cnt) {
+            const size_t first = msm_region(L, pl, w, b);
+            if (!msm_sum_refs_lean(o, refs, first, first + cnt, term)) msm_sum_refs(o, refs, first, first + cnt, term);
+        }
+    }
+    gej_store28(out28 + (size_t)k * 28, o);
+}
+// counts -> run counts -> their exclusive prefix, in ONE launch of one workgroup (it was three: k_msm_counts, k_scan_tiles, k_scan_fix; the
+// arrays have 10^4 .. 3 10^5 entries and the three launches were ~5 us each plus their gaps, per partial-sum round).  Wavefront v owns the
+// contiguous segment [v seg, (v + 1) seg) and walks it 256 entries a step (one 16-byte load per lane, consecutive lanes on consecutive
+// entries); first sweep: segment totals, second: the running prefix.  Only the top window (the share's last, if it has it) has other
+// capacities than L.cap, so no entry needs a division.
+// (ceil(c / T) through the reciprocal M = floor(2^32 / T) + 1 and one correction step: a 32-bit division is ~40 instructions, and four
+//  of them per step per lane were most of this kernel's 43 us)
+__device__ __forceinline__ u32 msm_run_count(u32 c, u32 k, u32 T, u32 M, u32 top_first, const msm_layout& L, u32* clamped) {
+    if (clamped) {
+        const u32 cap = k >= top_first ? ((k - top_first) < L.top_used ? L.cap_top : 0u) : L.cap;
+        c = c < cap ? c : cap; clamped[k] = c;
+    }
+    if (T <= 1u) return c;
+    const u32 x = c + T - 1u;
+    u32 q = __umulhi(x, M);
+    q -= (q * T > x) ? 1u : 0u;
+    q += ((q + 1u) * T <= x) ? 1u : 0u;
+    return q;
+}
+// Full steps (all 256 entries inside the segment: every step but the array's last) move whole 16-byte vectors and carry no bounds tests:
+// with a test per entry the kernel was ~1 500 instructions and 130 branches per 2 048 entries, 43 us for 41 000 entries on its one CU.
+typedef unsigned int msm_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(1024)
+k_msm_counts_scan(u32* cnt_out, u32* cnt_clamped, u32* off_out, const u32* cnt_in, u32 nk, u32 T, msm_layout L, msm_plan pl) {
+    __shared__ u32 s_wave[17];
+    const u32 t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+    const u32 seg = (((nk + 15u) / 16u) + 255u) & ~255u, lo = wave * seg, hi = min(lo + seg, nk);
+    const u32 top_first = (pl.w0 + pl.wn == pl.windows) ? (pl.wn - 1u) * pl.nb : 0xFFFFFFFFu;
+    const u32 M = 0xFFFFFFFFu / (T > 1u ? T : 2u) + 1u;        // >= 2^32 / T: the estimate is floor(x / T) or one more
+    u32 sum = 0;
+    // (the vector of step s + 1 is requested before step s is worked on: a step is otherwise one exposed L2 round trip)
+    msm_u4 nxt; nxt.x = nxt.y = nxt.z = nxt.w = 0u;
+    if (lo + 256u <= hi) nxt = *(const msm_u4*)(cnt_in + lo + 4u * lane);
+    for (u32 k0 = lo; k0 < hi; k0 += 256u) {
+        const u32 k = k0 + 4u * lane;
+        u32 c[4], r[4];
+        if (k0 + 256u <= hi) {
+            const msm_u4 v = nxt;
+            if (k0 + 512u <= hi) nxt = *(const msm_u4*)(cnt_in + k + 256u);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (cnt_clamped) { const u32 kk = k + (u32)q; const u32 cap = kk >= top_first ? ((kk - top_first) < L.top_used ? L.cap_top : 0u) : L.cap; c[q] = c[q] < cap ? c[q] : cap; }
+                r[q] = msm_run_count(c[q], 0u, T, M, 0u, L, nullptr); sum += r[q];
+            }
+            if (cnt_clamped) { msm_u4 o; o.x = c[0]; o.y = c[1]; o.z = c[2]; o.w = c[3]; *(msm_u4*)(cnt_clamped + k) = o; }
+            msm_u4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3]; *(msm_u4*)(cnt_out + k) = o;
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) if (k + q < hi) { const u32 rr = msm_run_count(cnt_in[k + q], k + q, T, M, top_first, L, cnt_clamped); cnt_out[k + q] = rr; sum += rr; }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sum += (u32)__shfl_xor((int)sum, d, 64);
+    if (lane == 0) s_wave[wave] = sum;
+    __syncthreads();
+    if (t == 0) { u32 run = 0; for (int q = 0; q < 16; q++) { const u32 x = s_wave[q]; s_wave[q] = run; run += x; } s_wave[16] = run; }
+    __syncthreads();
+    u32 carry = s_wave[wave];
+    if (lo + 256u <= hi) nxt = *(const msm_u4*)(cnt_out + lo + 4u * lane);
+    for (u32 k0 = lo; k0 < hi; k0 += 256u) {
+        const u32 k = k0 + 4u * lane;
+        const int full = (k0 + 256u <= hi);
+        u32 v[4];
+        if (full) { const msm_u4 x = nxt; if (k0 + 512u <= hi) nxt = *(const msm_u4*)(cnt_out + k + 256u); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+        else {
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) v[q] = (k + q < hi) ? cnt_out[k + q] : 0u;
+        }
+        const u32 s4 = v[0] + v[1] + v[2] + v[3];
+        u32 inc = s4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 x = (u32)__shfl_up((int)inc, d, 64); if (lane >= (u32)d) inc += x; }
+        const u32 run = carry + inc - s4;
+        if (full) { msm_u4 o; o.x = run; o.y = run + v[0]; o.z = run + v[0] + v[1]; o.w = run + v[0] + v[1] + v[2]; *(msm_u4*)(off_out + k) = o; }
+        else {
+            u32 rr = run;
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) { if (k + q < hi) off_out[k + q] = rr; rr += v[q]; }
+        }
+        carry += (u32)__shfl((int)inc, 63, 64);
+    }
+    if (t == 0) off_out[nk] = s_wave[16];
+}
 // Horner over the share's windows (~c*windows sequential doublings: the latency floor of one MSM).  One wavefront, all 64 lanes
 // running the same point through msm_combine: the runs of doublings spread each field element over the lanes (cofield.h), the
 // additions in between are the serial code executed redundantly.  Its own launch bounds so that the point state stays in registers.
+// ... and the end of the call in the same launch: when the binning pass overflowed a bucket region the exact path's result (side stream,
+// joined before this launch) is published instead; the flag goes to the engine's status word; `copy28` (optional) receives the Jacobian
+// record, r_xy / r_inf (optional) the affine result -- the inversion used to be a launch of its own (k_gej_finish) behind a third one
+// (k_msm_pick).
 __global__ void __launch_bounds__(64)
-k_msm_combine(u32* out28, const u32* wsum28, msm_plan pl) {
+k_msm_combine(u32* out28, u32* copy28, unsigned char* r_xy, int32_t* r_inf, const u32* wsum28, msm_plan pl, const u32* flags, const u32* exact28, u32* dev_flags) {
     if (blockIdx.x) return;
-    gej r; msm_combine(r, wsum28, pl);
-    if (threadIdx.x == 0) gej_store28(out28, r);
-}
-// exact path: final <- exact result when the binning pass overflowed a bucket region; the flag goes to the engine's status word
-__global__ void k_msm_pick(u32* final28, const u32* exact28, const u32* flags, u32* dev_flags) {
-    if (threadIdx.x == 0) dev_flags[0] = flags[0];
-    if (flags[0] == 0) return;
-    for (int i = threadIdx.x; i < 28; i += blockDim.x) final28[i] = exact28[i];
+    const u32 over = flags[0];
+    gej r;
+    if (over) gej_load28(r, exact28); else msm_combine(r, wsum28, pl);
+    if (threadIdx.x) return;
+    dev_flags[0] = over;
+    gej_store28(out28, r);
+    if (copy28) gej_store28(copy28, r);
+    if (r_xy) {
+        if (r.inf) { for (int k = 0; k < 64; k++) r_xy[k] = 0; } else { ge a; ge_set_gej(a, r); ge_store_b64(r_xy, a); }
+        *r_inf = r.inf;
+    }
 }
 // Bucket-free form: lane l sums (share of k_i)*P_i over the terms i = l, l + lanes, ... with one full double-and-add each
 // (ecmult.h); the term with index n carries g_sc*G.  Two uses: small inputs (n < MSM_SMALL_N, the analogue of the reference
@@ -603,30 +830,44 @@ static u32 msm_run_len(const s2k_engine* e, size_t E, const msm_plan& pl, const 
     if (maxcap <= MSM_ONE_ROUND_CAP) return maxcap;
     // ~6 lanes per resident lane slot (131 072) at the largest sizes, so that the last, partly filled round of workgroups is a small share
     // (measured at 2^20 terms: T = 24 2.17 ms, T = 128 2.33 ms; at 2^22: T = 48 7.26 ms, T = 128 7.38 ms)
-    u32 T = (u32)(E / 786432); if (T < 8) T = 8; if (T > 64) T = 64; return T;
+    // (round 6, profiles/r06f_msm_tsweep.txt: from 2^17 terms a floor of 16 instead of 8 -- 2^18 terms 0.92 -> 0.85 ms, 2^17 0.68 -> 0.66: half
+    //  as many partial sums for the later rounds, which are pure latency there)
+    const u32 lo = E >= (size_t(1) << 17) * 2 * 11 ? 16u : 8u;
+    u32 T = (u32)(E / 786432); if (T < lo) T = lo; if (T > 64) T = 64; return T;
 }
-#define MSM_T2 8u                        /* run length of the later rounds: the smallest that the sizes below assume */
+#define MSM_T2 4u                        /* run length of the later rounds: the smallest that the buffer sizes below assume */
 #define MSM_T2_MAX 12u
 // Run length of the later partial-sum rounds.  The NUMBER of rounds follows from the bucket-region capacity (nothing is read back): T, T T2,
-// T T2^2, ... until the fullest region is covered, and a round is three launches (counts, scan, sums) of latency.  At 2^20 terms the top
-// window's regions (capacity 2 516, sized for its non-uniform values) made that four rounds with T2 = 8 where 10 covers them in three: the
-// smallest T2 in [8, 12] that gives the fewest rounds is taken (a lane of a later round then adds up to T2 Jacobian partials).
+// T T2^2, ... until the fullest region is covered, and a round is two launches (counts + scan, sums) of latency: the fewest rounds that
+// T2 <= 12 allows are taken (2^20 terms: the top window's regions, capacity 2 516, need T2 = 11 for two later rounds).  WITHIN that number
+// of rounds the smallest sufficient T2 is taken (round 6; it used to be at least 8): a lane of a later round adds up to T2 Jacobian
+// partials one after the other at ~8 us each on a machine that is mostly empty by then, so 2^17 terms (capacity 256, T = 8: two later
+// rounds need T2^2 >= 32) run 6 + 6 dependent additions instead of 8 + 8.
 static u32 msm_later_run_len(const s2k_engine* e, u32 T, u32 maxcap) {
     if (e->msm_diag.T2 >= (int)MSM_T2 && e->msm_diag.T2 <= 64) return (u32)e->msm_diag.T2;      // diagnostic override (-DS2K_DIAG builds)
     auto rounds_for = [&](u32 t2) { int r = 1; size_t reach = T; while (reach < maxcap) { reach *= t2; r++; } return r; };
-    u32 best = MSM_T2; int br = rounds_for(MSM_T2);
-    for (u32 t2 = MSM_T2 + 1; t2 <= MSM_T2_MAX; t2++) { const int r = rounds_for(t2); if (r < br) { br = r; best = t2; } }
-    return best;
+    const int fewest = rounds_for(MSM_T2_MAX);
+    for (u32 t2 = MSM_T2; t2 < MSM_T2_MAX; t2++) if (rounds_for(t2) == fewest) return t2;
+    return MSM_T2_MAX;
 }
 #define MSM_DIRECT_LANES 16384u          /* lanes of the bucket-free exact path (each walks its terms with a stride) */
 msm_plan engine_msm_plan(const s2k_engine* e, size_t nt) { return msm_make_plan(nt, e->msm_diag.c); }
+// the slice tail (k_msm_slices / k_msm_window_sums) serves the plans up to this width; the widest windows (from 2^22 terms, where the tail
+// is a few percent of the call) keep the per-bucket multiplication: 2^15 buckets x 16 slices per window is more tree work than it saves
+#define MSM_SLICE_TAIL_MAX_C 13u
+static size_t msm_slice_words(const msm_plan& pl) { return (size_t)pl.windows * MSM_SLICE_MAX * ((pl.nb + 63) / 64 + 1) * 28; }
+// one launch indexes its bucket references with 32 bits (term << 2 | half << 1 | sign): the largest sum that fits
+size_t msm_max_terms(const s2k_engine* e) {
+    if (e->msm_max_terms_opt) return e->msm_max_terms_opt;
+    return ((size_t(1) << 32) - 1) / (2 * 9) - 1;             // 9 windows (c = 16) from 2^22 terms on: 238 609 293
+}
 size_t msm_ws_bytes(const s2k_engine* e, size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
     const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(e, E, pl, L);
     return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
                     msm_refs_words(pl, L) * 4, nk * 28 * 4, msm_pairs_words(e, nt, pl, L) * 8, (size_t)pl.windows * 520 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
-                    (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2}) + 32 * 256;
+                    (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2, msm_slice_words(pl) * 4, (size_t)pl.windows * 28 * 4}) + 32 * 256;
 }
 static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const u32* in, u32 nk) {
     const u32 tiles = (nk + 1023) / 1024;
@@ -641,33 +882,67 @@ static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const
 __global__ void k_set_word(u32* p, u32 v) { *p = v; }
 void launch_set_word(hipStream_t st, u32* p, u32 v) { hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, p, v); }
 __global__ void k_msm_flag_copy(u32* persist, const u32* flags) { persist[0] = flags[0]; }
+// what a launch does with its result besides leaving the Jacobian record in the workspace: the affine result (r_xy 64 bytes + r_inf) and /
+// or a copy of the record, written by the last kernel of the chain
+static int msm_emit(hipStream_t st, const msm_out* out, const u32* res28) {
+    if (!out) return 1;
+    if (out->r_xy) hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, out->r_xy, out->r_inf, res28);
+    if (out->out28) HIPCHK(hipMemcpyAsync(out->out28, res28, 28 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    return 1;
+}
+// k_msm_slices: BS lanes per workgroup, R buckets per lane (a serial addition there costs a tree level, ~7 us; a chunk more ~3 us in
+// k_msm_window_sums)
+struct msm_slice_cfg { u32 R, BS; };
+static msm_slice_cfg msm_slice_config(const s2k_engine* e, u32 nb) {
+    msm_slice_cfg g{4u, 256u};           // (measured, profiles/r06b_msm_variants.txt: the kernel is bound by its tree levels' issue slots -- fewer, fuller workgroups win at every size)
+    const int v = e->msm_diag.slice_r;          // diagnostic override (-DS2K_DIAG builds): R + 16 * (64-lane workgroups)
+    if (v > 0) { g.R = (u32)(v & 15); g.BS = (v & 16) ? 64u : 256u; if (g.R != 1 && g.R != 2 && g.R != 4 && g.R != 8) g.R = 4; }
+    return g;
+}
+static u32 msm_slice_chunks(u32 nb, const msm_slice_cfg& g) { return (nb - 1u + g.BS * g.R - 1u) / (g.BS * g.R); }
+static int msm_new_tail(const s2k_engine* e, const msm_plan& pl) { return !e->msm_diag.old_tail && pl.c <= (e->msm_diag.slice_maxc ? (u32)e->msm_diag.slice_maxc : MSM_SLICE_TAIL_MAX_C); }
+// bucket sums (one record per bucket: in28[k], or in28[off_last[k]] where the partial-sum rounds packed them) -> window sums
+static const u32* launch_window_sums(s2k_engine* e, hipStream_t st, u32* q28, u32* wsum28, const u32* in28, const u32* off_last, const msm_plan& pl, const msm_layout& L) {
+    const msm_slice_cfg g = msm_slice_config(e, pl.nb);
+    const u32 nchunks = msm_slice_chunks(pl.nb, g), nslices = pl.c;      // weights are at most 2^(c-1)
+    const dim3 grid(nchunks, nslices, pl.wn);
+    const u32 lds = (u32)e->msm_diag.slice_lds;          // diagnostic: unused dynamic LDS, to limit the workgroups per CU
+#define S2K_SLICES(R_, BS_) hipLaunchKernelGGL((k_msm_slices<R_, BS_>), grid, dim3(BS_), lds, st, q28, in28, off_last, pl, L, nchunks, nslices)
+    if (g.BS == 256u) { if (g.R == 1) S2K_SLICES(1, 256); else if (g.R == 2) S2K_SLICES(2, 256); else if (g.R == 4) S2K_SLICES(4, 256); else S2K_SLICES(8, 256); }
+    else { if (g.R == 1) S2K_SLICES(1, 64); else if (g.R == 2) S2K_SLICES(2, 64); else if (g.R == 4) S2K_SLICES(4, 64); else S2K_SLICES(8, 64); }
+#undef S2K_SLICES
+    hipLaunchKernelGGL(k_msm_window_sums, dim3(pl.wn), dim3(1024), 0, st, wsum28, (const u32*)q28, nchunks, nslices);
+    return wsum28;
+}
 int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, const unsigned char* g_sc, const unsigned char* sc,
-               const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part, u32 parts, const msm_ctx* ctx) {
+               const unsigned char* pt, const unsigned char* pt_inf, size_t n, u32 part, u32 parts, const msm_ctx* ctx, const msm_out* out) {
     const msm_ctx dflt{e->stream2, e->ev_msm_fork, e->ev_msm_join, 0u};
     const msm_ctx& X = ctx ? *ctx : dflt;
     const size_t nt = n + (g_sc ? 1 : 0);
     if (parts == 0 || part >= parts) return s2k_fail_arg("s2k_ecmult_multi", "window share out of range");
     ENGINE_GTAB(e, st);                                        // (the bucket-free exact path multiplies by G through the table)
     msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
-    // term references are packed as (u32)(term << 2 | half << 1 | sign): refuse what those cannot index instead of wrapping silently
-    if (nt >= (size_t(1) << 30) || nt * 2 * pl.windows >= (size_t(1) << 32))
-        return s2k_fail("s2k_ecmult_multi", "too many terms for 32-bit bucket references (2 * windows * n >= 2^32): split the sum, partial sums add");
+    // term references are packed as (u32)(term << 2 | half << 1 | sign): the entry points split larger sums (msm_max_terms)
+    if (nt > msm_max_terms(e) || nt >= (size_t(1) << 30) || nt * 2 * pl.windows >= (size_t(1) << 32))
+        return s2k_fail("s2k_ecmult_multi", "too many terms for 32-bit bucket references (2 * windows * n >= 2^32) in one launch");
     msm_plan_share(pl, part, parts);
     u32* final28 = c.take<u32>(28);
     *result28 = final28;
     u32* flags = c.take<u32>(16);                              // flags[0]: a bucket region overflowed
     u32* lanes = c.take<u32>((size_t)MSM_DIRECT_LANES * 28); u32* dbufA = c.take<u32>(64 * 28); u32* dbufB = c.take<u32>(64 * 28);
-    HIPCHK(hipMemsetAsync(flags, 0, 64, st));
     if (nt == 0 || pl.wn == 0) {                               // empty sum / empty share: infinity
+        HIPCHK(hipMemsetAsync(flags, 0, 64, st));
         HIPCHK(hipMemsetAsync(final28, 0, 27 * 4, st));
         hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, final28 + 27, 1u);
         hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
         HIPCHK(hipGetLastError());
-        return 1;
+        return msm_emit(st, out, final28);
     }
     if (nt < MSM_SMALL_N) {
         const unsigned dl = (unsigned)(((nt + 255) / 256) * 256);
         if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
+        HIPCHK(hipMemsetAsync(flags, 0, 64, st));
         HIPCHK(hipEventRecord(e->ev[2], st));
         hipLaunchKernelGGL(k_msm_direct, dim3(dl / 256), dim3(256), 0, st, lanes, (const u32*)nullptr, g_sc, sc, pt, pt_inf, e->gtab,
                            e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS, n, nt, pl);
@@ -676,7 +951,7 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
         HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
         HIPCHK(hipGetLastError());
-        return 1;
+        return msm_emit(st, out, final28);
     }
     if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
     u32* const direct_ptab = e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS;
@@ -694,9 +969,9 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
     unsigned long long* pairs = c.take<unsigned long long>(msm_pairs_words(e, nt, pl, L)); u32* ccnt = c.take<u32>((size_t)pl.windows * 520);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
     u32* bufA = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28); u32* bufB = c.take<u32>(((size_t)nk / 1024 + pl.windows + 64) * 28);
-    HIPCHK(hipMemsetAsync(gcnt, 0, (nk + 1) * 4, st));
+    u32* q28 = c.take<u32>(msm_slice_words(full)); u32* wsum_new = c.take<u32>((size_t)pl.windows * 28);
     const unsigned bt = (unsigned)((nt + 255) / 256), bk = (nk + 255) / 256;
-    hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt);
+    hipLaunchKernelGGL(k_msm_prep, dim3(bt), dim3(256), 0, st, term, halves, g_sc, sc, pt, pt_inf, n, nt, flags, 16u, gcnt, nk + 1u);
     u32 chunk = 8192; while (chunk > 1024 && (nt + chunk - 1) / chunk * pl.wn < 1024) chunk >>= 1;       // enough workgroups to fill 256 CUs
     { const int v = e->msm_diag.chunk; if (v == 1024 || v == 2048 || v == 4096 || v == 8192) chunk = (u32)v; }      // diagnostic override (-DS2K_DIAG builds)
     u32 bin_dbg = 0;
@@ -720,43 +995,49 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
     hipLaunchKernelGGL(k_msm_direct, dim3(MSM_DIRECT_LANES / 256), dim3(256), 0, X.side, lanes, (const u32*)flags, g_sc, sc, pt, pt_inf, e->gtab, direct_ptab, n, nt, pl);
     const u32* ex = launch_gej_reduce(X.side, lanes, dbufA, dbufB, 1, MSM_DIRECT_LANES, flags);
     HIPCHK(hipEventRecord(X.join, X.side));
+    const int new_tail = msm_new_tail(e, pl);
+    const u32* wsum = nullptr;
     if (msm_max_cap(full, L) <= MSM_ONE_ROUND_CAP && !e->msm_diag.no_small) {
-        const u32 nchunks = (pl.nb - 1 + 255) / 256;
-        hipLaunchKernelGGL(k_msm_small_windows, dim3(nchunks, pl.wn), dim3(256), 0, st, partA, refs_cap, gcnt, term, pl, L, nchunks);
-        const u32* wsum = launch_gej_reduce(st, partA, bufA, bufB, pl.wn, nchunks);
-        hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
-        HIPCHK(hipStreamWaitEvent(st, X.join, 0));
-        hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
-        HIPCHK(hipGetLastError());
-        return 1;
+        if (new_tail) {
+            hipLaunchKernelGGL(k_msm_bucket_sums, dim3((pl.nb + 255) / 256, pl.wn), dim3(256), 0, st, buckets, refs_cap, gcnt, term, pl, L);
+            wsum = launch_window_sums(e, st, q28, wsum_new, buckets, nullptr, pl, L);
+        } else {
+            const u32 nchunks = (pl.nb - 1 + 255) / 256;
+            hipLaunchKernelGGL(k_msm_small_windows, dim3(nchunks, pl.wn), dim3(256), 0, st, partA, refs_cap, gcnt, term, pl, L, nchunks);
+            wsum = launch_gej_reduce(st, partA, bufA, bufB, pl.wn, nchunks);
+        }
+    } else {
+        // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
+        const int has_top = (pl.w0 + pl.wn == pl.windows);
+        const u32 maxcap = std::max(pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, has_top ? L.cap_top : 0u);
+        const u32 T2 = msm_later_run_len(e, T, maxcap);
+        int rounds = 1; { size_t reach = T; while (reach < maxcap) { reach *= T2; rounds++; } }
+        // round 1: references -> partial sums (at most T references each)
+        if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3(1), dim3(1024), 0, st, cntA, gclamp, offA, gcnt, nk, T, L, pl);
+        else { hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl); launch_scan(st, offA, nullptr, tile_sum, cntA, nk); }
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
+        HIPCHK(hipEventRecord(e->ev[3], st));
+        // rounds 2..R: partial sums of partial sums until every bucket holds at most one
+        u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
+        size_t bound = bound1;
+        for (int r = 2; r <= rounds; r++) {
+            bound = (size_t)nk + bound / T2 + 2;
+            if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3(1), dim3(1024), 0, st, cout, (u32*)nullptr, oout, (const u32*)cin, nk, T2, L, pl);
+            else { hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, (u32*)nullptr, cin, nk, T2, L, pl); launch_scan(st, oout, nullptr, tile_sum, cout, nk); }
+            hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T2);
+            u32* t;
+            t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
+        }
+        if (new_tail) wsum = launch_window_sums(e, st, q28, wsum_new, pin, oin, pl, L);
+        else {
+            hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl, L);
+            wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
+        }
     }
-    hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl);
-    // rounds: a bucket holds at most its region's capacity, so the capacity fixes how many rounds reach "one partial per bucket"
-    const int has_top = (pl.w0 + pl.wn == pl.windows);
-    const u32 maxcap = std::max(pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, has_top ? L.cap_top : 0u);
-    const u32 T2 = msm_later_run_len(e, T, maxcap);
-    int rounds = 1; { size_t reach = T; while (reach < maxcap) { reach *= T2; rounds++; } }
-    // round 1: references -> partial sums (at most T references each)
-    launch_scan(st, offA, nullptr, tile_sum, cntA, nk);
-    HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
-    HIPCHK(hipEventRecord(e->ev[3], st));
-    // rounds 2..R: partial sums of partial sums until every bucket holds at most one
-    u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
-    size_t bound = bound1;
-    for (int r = 2; r <= rounds; r++) {
-        bound = (size_t)nk + bound / T2 + 2;
-        hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, (u32*)nullptr, cin, nk, T2, L, pl);
-        launch_scan(st, oout, nullptr, tile_sum, cout, nk);
-        hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T2);
-        u32* t;
-        t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
-    }
-    hipLaunchKernelGGL(k_msm_finish, dim3(bk), dim3(256), 0, st, buckets, pin, oin, nk, pl, L);
-    const u32* wsum = launch_gej_reduce(st, buckets, bufA, bufB, pl.wn, pl.nb);
-    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, wsum, pl);
     HIPCHK(hipStreamWaitEvent(st, X.join, 0));
-    hipLaunchKernelGGL(k_msm_pick, dim3(1), dim3(32), 0, st, final28, ex, (const u32*)flags, e->dev_flags);
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, st, final28, out ? out->out28 : (u32*)nullptr, out ? out->r_xy : (unsigned char*)nullptr,
+                       out ? out->r_inf : (int32_t*)nullptr, wsum, pl, (const u32*)flags, ex, e->dev_flags);
     HIPCHK(hipGetLastError());
     return 1;
 }
@@ -793,13 +1074,53 @@ static int msm_pipelined(s2k_engine* e, hipStream_t st, int finish, uint32_t* ou
     const msm_ctx ctx{S.s2, S.fork, S.join, 1u + si};
     ws_carver c{S.ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], S.s));
-    if (!msm_launch(e, S.s, c, &res, g_sc, sc, pt_xy, pt_inf, n, 0, 1, &ctx)) return 0;
-    if (finish) hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, S.s, r_xy, r_inf, res);
-    else HIPCHK(hipMemcpyAsync(out28, res, 28 * 4, hipMemcpyDeviceToDevice, S.s));
-    HIPCHK(hipGetLastError());
+    const msm_out out{finish ? r_xy : nullptr, finish ? r_inf : nullptr, finish ? nullptr : out28};
+    if (!msm_launch(e, S.s, c, &res, g_sc, sc, pt_xy, pt_inf, n, 0, 1, &ctx, &out)) return 0;
     HIPCHK(hipEventRecord(e->ev[1], S.s));
     HIPCHK(hipEventRecord(S.done, S.s));
     HIPCHK(hipStreamWaitEvent(st, S.done, 0));               // the result is stream-ordered for the caller
+    return 1;
+}
+// One sum through the engine's own workspace, whatever its size.  A launch indexes its bucket references with 32 bits, so a sum of more
+// than msm_max_terms() terms goes as consecutive launches over slices of the term arrays whose Jacobian partial sums are added at the end --
+// the reference's own treatment of a sum that exceeds its scratch space (ecmult_impl.h:804-820 computes the batch size, :856-865 loops over
+// the batches and adds).  `front`: bytes of the workspace the caller has already carved (staged inputs).
+static size_t msm_run_ws_bytes(const s2k_engine* e, size_t n, int has_g) {
+    const size_t nt = n + (has_g ? 1 : 0), cap = msm_max_terms(e);
+    if (nt <= cap) return msm_ws_bytes(e, nt + 1, engine_msm_plan(e, nt ? nt : 1));
+    const size_t per = has_g ? cap - 1 : cap, pieces = (n + per - 1) / per;
+    const size_t last = n - (pieces - 1) * per + 1;            // (the last launch is shorter and may plan a different window width)
+    return ws_need({pieces * 28 * 4, (pieces / 1024 + 64) * 28 * 4, (pieces / 1024 + 64) * 28 * 4}) +
+           std::max(msm_ws_bytes(e, cap + 1, engine_msm_plan(e, cap)), msm_ws_bytes(e, last + 1, engine_msm_plan(e, last)));
+}
+static int msm_run(s2k_engine* e, hipStream_t st, size_t front, const msm_out& out, const unsigned char* g_sc, const unsigned char* sc,
+                   const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n) {
+    const size_t nt = n + (g_sc ? 1 : 0), cap = msm_max_terms(e);
+    if (!engine_workspace(e, front + msm_run_ws_bytes(e, n, g_sc != nullptr))) return 0;
+    if (nt <= cap) {
+        ws_carver c{e->ws, front}; u32* res = nullptr;
+        HIPCHK(hipEventRecord(e->ev[0], st));
+        if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n, 0, 1, nullptr, &out)) return 0;
+        HIPCHK(hipEventRecord(e->ev[1], st));
+        return 1;
+    }
+    const size_t per = g_sc ? cap - 1 : cap, pieces = (n + per - 1) / per;
+    if (pieces > (size_t(1) << 20)) return s2k_fail("s2k_ecmult_multi", "sum too large");
+    ws_carver c{e->ws, front};
+    u32* parts28 = c.take<u32>(pieces * 28); u32* bufA = c.take<u32>((pieces / 1024 + 64) * 28); u32* bufB = c.take<u32>((pieces / 1024 + 64) * 28);
+    const size_t base = c.off;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    for (size_t i = 0; i < pieces; i++) {
+        const size_t lo = i * per, cnt = std::min(per, n - lo);
+        ws_carver ci{e->ws, base}; u32* res = nullptr;
+        const msm_out oi{nullptr, nullptr, parts28 + i * 28};
+        if (!msm_launch(e, st, ci, &res, i == 0 ? g_sc : nullptr, sc + 32 * lo, pt_xy + 64 * lo, pt_inf ? pt_inf + lo : nullptr, cnt, 0, 1, nullptr, &oi)) return 0;
+    }
+    const u32* r = launch_gej_reduce(st, parts28, bufA, bufB, 1, (u32)pieces);
+    if (out.r_xy) hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, out.r_xy, out.r_inf, r);
+    if (out.out28) HIPCHK(hipMemcpyAsync(out.out28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
 }
 extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,
@@ -811,14 +1132,7 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
     if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
-    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
-    if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
-    ws_carver c{e->ws, 0}; u32* res = nullptr;
-    HIPCHK(hipEventRecord(e->ev[0], st));
-    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
-    HIPCHK(hipMemcpyAsync(r_gej28, res, 28 * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipEventRecord(e->ev[1], st));
-    return 1;
+    return msm_run(e, st, 0, msm_out{nullptr, nullptr, r_gej28}, g_sc, sc, pt_xy, pt_inf, n);
 }
 extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc, const unsigned char* sc,
                                                    const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n, uint32_t part, uint32_t parts) {
@@ -832,8 +1146,8 @@ extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, 
     if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
     ws_carver c{e->ws, 0}; u32* res = nullptr;
     HIPCHK(hipEventRecord(e->ev[0], st));
-    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n, part, parts)) return 0;
-    HIPCHK(hipMemcpyAsync(r_gej28, res, 28 * 4, hipMemcpyDeviceToDevice, st));
+    const msm_out out{nullptr, nullptr, r_gej28};
+    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n, part, parts, nullptr, &out)) return 0;
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
 }
@@ -846,15 +1160,7 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
     if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
-    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
-    if (!engine_workspace(e, msm_ws_bytes(e, nt + 1, pl))) return 0;
-    ws_carver c{e->ws, 0}; u32* res = nullptr;
-    HIPCHK(hipEventRecord(e->ev[0], st));
-    if (!msm_launch(e, st, c, &res, g_sc, sc, pt_xy, pt_inf, n)) return 0;
-    hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, r_xy, r_inf, res);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev[1], st));
-    return 1;
+    return msm_run(e, st, 0, msm_out{r_xy, r_inf, nullptr}, g_sc, sc, pt_xy, pt_inf, n);
 }
 extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count) {
     if (!e) return s2k_fail("s2k_gej_sum_dev", "null engine");
@@ -877,10 +1183,9 @@ extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
     if (!r_xy || !r_inf || (n && (!sc || !pt_xy))) return s2k_fail_arg("s2k_ecmult_multi", "illegal argument (ARG_CHECK)");
     std::lock_guard<std::recursive_mutex> lock(e->mu);
     HIPCHK(hipSetDevice(e->device));
-    const size_t nt = n + (g_sc ? 1 : 0);
-    const msm_plan pl = engine_msm_plan(e, nt ? nt : 1);
-    // the staged inputs come first in the workspace, the MSM passes carve what follows
-    if (!engine_workspace(e, ws_need({32 * n + 64, 64 * n + 64, n + 64, 64, 64, 16}) + msm_ws_bytes(e, nt + 1, pl))) return 0;
+    // the staged inputs come first in the workspace, the MSM passes carve what follows (sized here, once: growing the workspace moves it)
+    const size_t front = ws_need({32 * n + 64, 64 * n + 64, n + 64, 64, 64, 16});
+    if (!engine_workspace(e, front + msm_run_ws_bytes(e, n, g_sc != nullptr))) return 0;
     ws_carver c{e->ws, 0};
     unsigned char* d_sc = c.take<unsigned char>(32 * n + 64); unsigned char* d_pt = c.take<unsigned char>(64 * n + 64); unsigned char* d_inf = c.take<unsigned char>(n + 64);
     unsigned char* d_g = c.take<unsigned char>(64); unsigned char* d_r = c.take<unsigned char>(64); int32_t* d_ri = c.take<int32_t>(4);
@@ -892,12 +1197,7 @@ extern "C" int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_i
         if (pt_inf) HIPCHK(hipMemcpyAsync(d_inf, pt_inf, n, hipMemcpyHostToDevice, st));
     }
     if (g_sc) HIPCHK(hipMemcpyAsync(d_g, g_sc, 32, hipMemcpyHostToDevice, st));
-    u32* res = nullptr;
-    HIPCHK(hipEventRecord(e->ev[0], st));
-    if (!msm_launch(e, st, c, &res, g_sc ? d_g : nullptr, d_sc, d_pt, pt_inf ? d_inf : nullptr, n)) return 0;
-    hipLaunchKernelGGL(k_gej_finish, dim3(1), dim3(64), 0, st, d_r, d_ri, res);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev[1], st));
+    if (!msm_run(e, st, front, msm_out{d_r, d_ri, nullptr}, g_sc ? d_g : nullptr, d_sc, d_pt, pt_inf ? d_inf : nullptr, n)) return 0;
     HIPCHK(hipMemcpyAsync(r_xy, d_r, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(r_inf, d_ri, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

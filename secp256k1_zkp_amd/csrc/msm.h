@@ -324,13 +324,17 @@ S2K_HD void msm_scale(gej& out, const gej& in, u32 weight) {
 S2K_D void msm_combine_cooperative(gej& r, const u32* window_sums28, const msm_plan& pl) {
     cgej acc; int acc_inf = 1;
     acc.x.v = acc.y.v = acc.z.v = 0;
+    // (the record of window w - 1 is requested before the doublings that precede its addition: a load in the chain is ~1-2 us exposed)
+    cgej nx; int nx_inf = 1; nx.x.v = nx.y.v = nx.z.v = 0;
+    if (pl.wn) nx_inf = cgej_load28(nx, window_sums28 + 28 * (pl.wn - 1));
     for (int w = (int)pl.wn - 1; w >= 0; w--) {
+        const cgej sw = nx; const int sw_inf = nx_inf;
+        if (w > 0) nx_inf = cgej_load28(nx, window_sums28 + 28 * (w - 1));
         if (!acc_inf) {
 #pragma unroll 1
             for (u32 k = 0; k < pl.c; k++) cgej_double(acc);
         }
-        cgej sw;
-        if (!cgej_load28(sw, window_sums28 + 28 * w)) {
+        if (!sw_inf) {
             if (acc_inf) { acc = sw; acc_inf = 0; }
             else acc_inf = cgej_add(acc, sw);
         }
