@@ -146,6 +146,18 @@ S2K_API int s2k_ecmult_multi(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf,
                              const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
 S2K_API int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc,
                                  const unsigned char* sc, const unsigned char* pt_xy, const unsigned char* pt_inf, size_t n);
+/* K independent sums in one launch chain: r_k = g_sc_k * G + sum_{i in [offsets[k], offsets[k+1])} sc_i * P_i, k = 0 .. n_sums - 1 -- what a
+ * caller of the reference gets from n_sums calls of secp256k1_ecmult_multi_var, e.g. bench_ecmult's 1 024-term sums
+ * (src/bench_ecmult.c:262-276, :362-371), one per block or transaction.  ONE small sum is a chain of latency-bound launches (~0.4 ms
+ * whatever its size); many of them side by side are binned, accumulated and recombined together (csrc/engine_msm_many.hip), the GPU-natural
+ * counterpart of the reference's Strauss-batch regime (src/ecmult_impl.h:382-419).  sc / pt_xy / pt_inf: the sums' terms back to back;
+ * offsets: n_sums + 1 increasing term indices starting at 0 -- a HOST array in both forms (read before the call returns); g_sc: n_sums * 32
+ * bytes or NULL; r_xy n_sums * 64, r_inf n_sums.  Empty sums give infinity.  Sums of more than 8 192 terms take the single-sum path one
+ * after the other. */
+S2K_API int s2k_ecmult_multi_many(s2k_engine* e, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc, const unsigned char* sc,
+                                  const unsigned char* pt_xy, const unsigned char* pt_inf, const uint64_t* offsets, size_t n_sums);
+S2K_API int s2k_ecmult_multi_many_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const unsigned char* g_sc, const unsigned char* sc,
+                                      const unsigned char* pt_xy, const unsigned char* pt_inf, const uint64_t* offsets_host, size_t n_sums);
 /* Partial sums for multi-GPU sharding: writes the Jacobian partial result as 3*9 limbs + flag (28 uint32) so that
  * ranks can all-gather raw limb buffers and finish with s2k_gej_sum (EC addition is not an RCCL op). */
 S2K_API int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc,

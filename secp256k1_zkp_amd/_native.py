@@ -36,6 +36,8 @@ SIGNATURES = {
     "s2k_ecmult_multi": (_c.c_int, [_vp] + [_vp] * 6 + [_sz]),
     "s2k_ecmult_multi_dev": (_c.c_int, [_vp, _vp] + [_vp] * 6 + [_sz]),
     "s2k_ecmult_multi_partial_dev": (_c.c_int, [_vp, _vp] + [_vp] * 5 + [_sz]),
+    "s2k_ecmult_multi_many": (_c.c_int, [_vp] + [_vp] * 7 + [_sz]),
+    "s2k_ecmult_multi_many_dev": (_c.c_int, [_vp, _vp] + [_vp] * 7 + [_sz]),
     "s2k_gej_sum_dev": (_c.c_int, [_vp, _vp] + [_vp] * 3 + [_sz]),
     "s2k_ecmult_multi_window_partial_dev": (_c.c_int, [_vp, _vp] + [_vp] * 5 + [_sz, _c.c_uint32, _c.c_uint32]),
     "secp256k1_schnorrsig_verify_batch": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _c.c_int, _sz]),

@@ -144,6 +144,23 @@ class Engine:
         self._check(self._lib.s2k_ecmult_multi_dev(self._h, stream, _dp(r_xy), _dp(r_inf), _dp(g_sc), _dp(sc), _dp(pt_xy), _dp(pt_inf), n),
                     "s2k_ecmult_multi_dev")
 
+    def ecmult_multi_many(self, sc, pt_xy, offsets, g_sc=None, pt_inf=None):
+        """K independent sums in one launch chain (s2k_ecmult_multi_many): terms back to back, offsets[K + 1]; returns (K x 64 bytes, K flags)."""
+        sc = _u8(sc); pt_xy = _u8(pt_xy); off = np.ascontiguousarray(offsets, dtype=np.uint64); k = off.size - 1
+        n = int(off[-1]) if off.size else 0
+        g_sc = None if g_sc is None else _u8(g_sc); pt_inf = None if pt_inf is None else _u8(pt_inf)
+        _need("ecmult_multi_many sc", sc, 32 * n); _need("ecmult_multi_many pt_xy", pt_xy, 64 * n)
+        if g_sc is not None: _need("ecmult_multi_many g_sc", g_sc, 32 * k)
+        if pt_inf is not None: _need("ecmult_multi_many pt_inf", pt_inf, n)
+        r = np.zeros((max(k, 0), 64), np.uint8); inf = np.zeros(max(k, 0), np.int32)
+        self._check(self._lib.s2k_ecmult_multi_many(self._h, _p(r), _p(inf), _p(g_sc), _p(sc), _p(pt_xy), _p(pt_inf), _p(off), k), "s2k_ecmult_multi_many")
+        return r, inf
+
+    def ecmult_multi_many_dev(self, r_xy, r_inf, sc, pt_xy, offsets_host, g_sc=None, pt_inf=None, stream=None):
+        off = np.ascontiguousarray(offsets_host, dtype=np.uint64)
+        self._check(self._lib.s2k_ecmult_multi_many_dev(self._h, stream, _dp(r_xy), _dp(r_inf), _dp(g_sc), _dp(sc), _dp(pt_xy), _dp(pt_inf), _p(off), off.size - 1),
+                    "s2k_ecmult_multi_many_dev")
+
     def ecmult_multi_partial_dev(self, r_gej28, sc, pt_xy, g_sc=None, pt_inf=None, stream=None):
         n = sc.numel() // 32
         self._check(self._lib.s2k_ecmult_multi_partial_dev(self._h, stream, _dp(r_gej28), _dp(g_sc), _dp(sc), _dp(pt_xy), _dp(pt_inf), n),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-UNITS = ["engine_core", "engine_rangeproof", "engine_msm", "engine_bppp", "engine_halfagg"]
+UNITS = ["engine_core", "engine_rangeproof", "engine_msm", "engine_msm_many", "engine_bppp", "engine_halfagg"]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fvisibility=hidden"]
 DEFAULT_LIB = os.path.join(HERE, "libsecp256k1_zkp_amd.so")
 

@@ -85,7 +85,7 @@ static inline u32 msm_max_cap(const msm_plan& pl, const msm_layout& L) {
     const u32 a = pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, b = has_top ? L.cap_top : 0u;
     return a > b ? a : b;
 }
-static inline msm_plan msm_plan_for(u32 c) {
+S2K_HD msm_plan msm_plan_for(u32 c) {
     msm_plan p; p.c = c; p.windows = (129 + c - 1) / c; p.nb = (1u << (c - 1)) + 1u; p.w0 = 0; p.wn = p.windows;
     return p;
 }
