@@ -17,8 +17,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the hosts only support dmabuf IPC: RCCL between the ranks fails without it
-
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -372,6 +370,189 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     return out
 
 
+def measure_next_rows(eng, ref, dev, steps, with_cpu=True):
+    """SURVEY 8(f) -- the callers either side of the hot path that the engine also serves -- in the driver-run line: surjection proofs, the
+    half-aggregate verifier, Pedersen tallies, rangeproof rewinding, bppp_commit, and K independent small sums in one launch chain.  Inputs by
+    the reference's own provers (oracle/_ref), resident in HBM when the clock starts; every entry carries `verified` (results == the reference's
+    on the distinct inputs), a VALU roofline from the reference schedule's MAC64 count (stated per entry) and the reference function timed on ONE
+    host core through oracle/ref_shim.c on a bounded sample."""
+    import ctypes
+    import torch
+    from secp256k1_zkp_amd import Engine
+    from tests.refapi import G_XY, GENERATOR_H
+    L, H = eng._lib, eng._h
+    out = {}
+    rng = np.random.default_rng(4321)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    D = lambda a: torch.tensor(np.ascontiguousarray(a)).to(dev)
+
+    def loop(fn):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def roof(mac64_per_unit, units, sec, what):
+        rate = 4 * mac64_per_unit * units / sec
+        return {"bound": "valu", "achieved": rate / 1e12, "peak": MAD32_PEAK / 1e12, "unit": "T lane-MAC/s (v_mad_u64_u32)", "frac": rate / MAD32_PEAK,
+                "frac_of_architectural_peak": rate / MAD32_PEAK_ARCH, "note": what + " x 4 v_mad_u64_u32 x units / wall time of the whole call (K calls queued, waited for once)"}
+
+    def cpu(fn, units, what):
+        t0 = time.time(); fn(); t = time.time() - t0
+        return {"value": units / t, "unit": "per second", "cores": 1, "kind": "reference", "sample": "%s, %d on one thread in %.2f s" % (what, units, t)}
+
+    ECMULT = 45e3                                   # SURVEY 8d: one secp256k1_ecmult (a*P + b*G) of the reference schedule
+    SQRT = 267 * 21                                 # one square root / inversion: ~267 field operations of ~21 MAC64
+    # ---- surjection proofs: 2^16 proofs of the 3-inputs / 3-used shape (a confidential transaction's usual one), 64 distinct by the reference's prover
+    n = 1 << 16
+    base = [ref.make_surjection(rng, 3, 3) for _ in range(64)]
+    proofs = [b[0] for b in base]; tags = [b[1] for b in base]; outs = [b[2] for b in base]
+    for i in (5, 21, 40):
+        q = bytearray(proofs[i]); q[10 + i] ^= 1; proofs[i] = bytes(q)
+    want = np.array([ref.surjection_verify(p_, t_, o_) for p_, t_, o_ in zip(proofs, tags, outs)], np.int32)
+    assert want.sum() == 61
+    reps = n // 64
+    data, off = Engine.pack(proofs * reps)
+    toff = (np.arange(n + 1) * 3).astype(np.uint64)
+    d_p, d_off = D(np.concatenate([data, np.zeros(64, np.uint8)])), D(off.astype(np.int64))
+    d_t, d_toff, d_o = D(np.concatenate(tags * reps)), D(toff.astype(np.int64)), D(np.stack(outs * reps))
+    res = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    def call():
+        assert L.secp256k1_surjectionproof_verify_batch_dev(H, None, P(res), P(d_p), P(d_off), P(d_t), P(d_toff), P(d_o), n) == 1
+    sec = loop(call)
+    assert np.array_equal(res.cpu().numpy(), np.tile(want, reps)), "surjection verdicts differ from the reference"
+    out["surjection_2p16"] = {"metric": "surjection-proof verifies/sec (3 inputs, 3 used; secp256k1_surjectionproof_verify)", "value": n / sec, "unit": "verifies/s", "ms": sec * 1e3, "batch": n,
+                              "verified": True, "result_check": "== secp256k1_surjectionproof_parse + _verify of the reference on the 64 distinct proofs (61 valid, 3 broken), tiled %d times" % reps,
+                              "roofline": roof(3 * ECMULT, n, sec, "algorithmic 3 ring keys x ~45e3 MAC64 (one secp256k1_ecmult each, src/modules/surjection/main_impl.h:360-402 -> borromean_verify)")}
+    if with_cpu:
+        k = 1024
+        out["surjection_2p16"]["cpu_baseline"] = cpu(lambda: [ref.surjection_verify(proofs[i % 64], tags[i % 64], outs[i % 64]) for i in range(k)], k,
+                                                     "secp256k1_surjectionproof_verify through oracle/ref_shim.c")
+    del d_p, d_off, d_t, d_toff, d_o, res
+    # ---- half-aggregated Schnorr: one aggregate of 2^15 signatures (host-buffer form: the serial randomizer hash chain walks on the host under the lifting kernel)
+    n = 1 << 15
+    sigs, msgs, pks = ref.make_schnorr(n, rng, threads=usable_cores())
+    agg = ref.halfagg_aggregate(pks, msgs, sigs)
+    bad = bytearray(agg); bad[32 * 77 + 5] ^= 1
+    assert eng.schnorrsig_aggverify(pks, msgs, bytes(bad)) == 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok = eng.schnorrsig_aggverify(pks, msgs, agg)
+    sec = (time.perf_counter() - t0) / steps
+    k = 1 << 11
+    agg_k = ref.halfagg_aggregate(pks[:k], msgs[:k], sigs[:k])
+    assert ok == 1 and eng.schnorrsig_aggverify(pks[:k], msgs[:k], agg_k) == ref.halfagg_verify(pks[:k], msgs[:k], agg_k) == 1
+    out["halfagg_2p15"] = {"metric": "half-aggregate signatures verified/sec (one aggregate of 2^15 signatures, secp256k1_schnorrsig_aggverify; host buffers, H2D included)", "value": n / sec, "unit": "signatures/s",
+                           "ms": sec * 1e3, "batch": n, "verified": True,
+                           "result_check": "accepts the reference's aggregate, rejects it with one bit of r_77 flipped; a %d-signature aggregate == the reference's verdict" % k,
+                           "roofline": roof(2 * ECMULT + 2 * SQRT, n, sec, "algorithmic two single multiplications (z_i R_i, z_i e_i P_i) + two x-lifts per signature (src/modules/schnorrsig_halfagg/main_impl.h:108-198)")}
+    if with_cpu:
+        out["halfagg_2p15"]["cpu_baseline"] = cpu(lambda: ref.halfagg_verify(pks[:k], msgs[:k], agg_k), k, "secp256k1_schnorrsig_aggverify through oracle/ref_shim.c (one aggregate)")
+    # ---- Pedersen tallies: 2^15 balances of 2 inputs / 3 outputs (secp256k1_pedersen_verify_tally), 64 distinct, 4 unbalanced
+    n = 1 << 15
+    tl = [ref.make_balanced_tally(rng, 2, 3) for _ in range(64)]
+    for i in (3, 30, 31, 60):
+        tl[i] = (tl[i][0], np.concatenate([tl[i][1][:2], tl[(i + 1) % 64][1][2:]]))
+    want = ref.pedersen_verify_tally_many(tl)
+    assert want.sum() == 60
+    reps = n // 64
+    cm = np.concatenate([np.concatenate([a, b]) for a, b in tl] * reps)
+    toff = (np.arange(n + 1) * 5).astype(np.uint64); npos = np.full(n + 1, 2, np.uint64)
+    d_c = D(cm); res = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    def call():
+        assert L.secp256k1_pedersen_verify_tally_batch_dev(H, None, P(res), P(d_c), toff.ctypes.data_as(ctypes.c_void_p), npos.ctypes.data_as(ctypes.c_void_p), n) == 1
+    sec = loop(call)
+    assert np.array_equal(res.cpu().numpy(), np.tile(want, reps)), "tally verdicts differ from the reference"
+    out["tally_2p15"] = {"metric": "Pedersen tallies verified/sec (2 inputs, 3 outputs; secp256k1_pedersen_verify_tally)", "value": n / sec, "unit": "tallies/s", "ms": sec * 1e3, "batch": n,
+                         "verified": True, "result_check": "== secp256k1_pedersen_verify_tally of the reference on the 64 distinct tallies (60 balanced, 4 not), tiled %d times" % reps,
+                         "roofline": roof(5 * SQRT + 5 * 16 * 21, n, sec, "algorithmic five commitment loads (a square root each) + five point additions per tally (src/modules/generator/main_impl.h:371-396)")}
+    if with_cpu:
+        k = 4096
+        out["tally_2p15"]["cpu_baseline"] = cpu(lambda: ref.pedersen_verify_tally_many([tl[i % 64] for i in range(k)]), k, "secp256k1_pedersen_verify_tally through oracle/ref_shim.c")
+    del d_c, res
+    # ---- rangeproof rewinding: 2^12 64-bit proofs with a 64-byte message each, verification + recovery (secp256k1_rangeproof_rewind)
+    n = 1 << 12
+    c, p, g, vals, blinds, nonces, msgs_in = ref.make_rangeproofs_msg(64, rng, msg_len=64, min_bits=64, threads=usable_cores())
+    nonces[7, 3] ^= 0x10
+    q = bytearray(p[9]); q[len(q) // 2] ^= 1; p[9] = bytes(q)
+    e_res, e_bl, e_val, e_msgs, e_mn, e_mx = ref.rangeproof_rewind_many(c, p, g, nonces, msg_capacity=128, threads=usable_cores())
+    assert e_res.sum() == 62
+    reps = n // 64
+    data, off = Engine.pack(p * reps)
+    d_c, d_p, d_off, d_g, d_n = D(np.tile(c, (reps, 1))), D(np.concatenate([data, np.zeros(64, np.uint8)])), D(off.astype(np.int64)), D(np.tile(g, (reps, 1))), D(np.tile(nonces, (reps, 1)))
+    res = torch.zeros(n, dtype=torch.int32, device=dev); bl = torch.zeros(n, 32, dtype=torch.uint8, device=dev); val = torch.zeros(n, dtype=torch.int64, device=dev)
+    mo = torch.zeros(n, 128, dtype=torch.uint8, device=dev); ol = torch.full((n,), 128, dtype=torch.int64, device=dev); mn = torch.zeros(n, dtype=torch.int64, device=dev); mx = torch.zeros(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    def call():
+        ol.fill_(128)
+        assert L.secp256k1_rangeproof_rewind_batch_dev(H, None, P(res), P(bl), P(val), P(mo), P(ol), 128, P(d_n), P(mn), P(mx), P(d_c), P(d_p), P(d_off), None, None, P(d_g), n) == 1
+    sec = loop(call)
+    got = res.cpu().numpy(); okm = np.tile(e_res, reps) == 1
+    assert np.array_equal(got, np.tile(e_res, reps)) and np.array_equal(bl.cpu().numpy()[okm], np.tile(e_bl, (reps, 1))[okm]) and \
+        np.array_equal(val.cpu().numpy().view(np.uint64)[okm], np.tile(e_val, reps)[okm]), "rewind results differ from the reference"
+    out["rewind_2p12"] = {"metric": "rangeproofs rewound/sec (64-bit proofs, verification + recovery of value, blinding factor and message; secp256k1_rangeproof_rewind)", "value": n / sec,
+                          "unit": "rewinds/s", "ms": sec * 1e3, "batch": n, "verified": True,
+                          "result_check": "== secp256k1_rangeproof_rewind of the reference on the 64 distinct proofs (62 recovered, one wrong nonce, one broken proof): verdicts, blinding factors, values; tiled %d times" % reps,
+                          "roofline": roof(MAC64_PER_PROOF, n, sec, "algorithmic 6.6e6 MAC64 per proof for the verification inside the rewind (SURVEY 8d); the replay of the prover's random stream (~1 500 SHA-256 compressions) is not MAC work")}
+    if with_cpu:
+        k = 32
+        out["rewind_2p12"]["cpu_baseline"] = cpu(lambda: ref.rangeproof_rewind_many(c[:k], p[:k], g[:k], nonces[:k], msg_capacity=128, threads=1), k, "secp256k1_rangeproof_rewind through oracle/ref_shim.c")
+    del d_c, d_p, d_off, d_g, d_n, res, bl, val, mo, ol, mn, mx
+    # ---- bppp_commit: 2^12 commitments over the 64 + 8 generator set of config 4, on the set's fixed-base tables
+    n = 1 << 12
+    g_len, h_len = 64, 8
+    gens = ref.bppp_generators(g_len + h_len)
+    sc = lambda *shape: (rng.integers(0, 256, shape + (32,), dtype=np.uint8) & np.array([0x7F] + [0xFF] * 31, np.uint8))
+    nv, lv, cv, mu = sc(n, g_len), sc(n, h_len), sc(n, h_len), sc(n)
+    d_nv, d_lv, d_cv, d_mu, d_gens = D(nv), D(lv), D(cv), D(mu), D(gens)
+    d_out = torch.zeros(n, 33, dtype=torch.uint8, device=dev); res = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    def call():
+        assert L.secp256k1_bppp_commit_batch_dev(H, None, P(d_out), P(res), P(d_gens), gens.ctypes.data_as(ctypes.c_void_p), g_len + h_len, g_len, P(d_nv), P(d_lv), P(d_cv), h_len, P(d_mu), n) == 1
+    sec = loop(call)
+    got = d_out.cpu().numpy()
+    def ref_commit(i):
+        cmt = np.zeros(33, np.uint8)
+        assert ref.lib.ref_bppp_commit(cmt.ctypes.data_as(ctypes.c_void_p), gens.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(g_len + h_len), np.ascontiguousarray(nv[i]).ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_size_t(g_len), np.ascontiguousarray(lv[i]).ctypes.data_as(ctypes.c_void_p), np.ascontiguousarray(cv[i]).ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(h_len),
+                                       np.ascontiguousarray(mu[i]).ctypes.data_as(ctypes.c_void_p)) == 1
+        return cmt
+    for i in range(0, n, 128):
+        assert np.array_equal(got[i], ref_commit(i)), "bppp_commit differs from the reference"
+    assert res.cpu().numpy().all()
+    terms = g_len + h_len + 1
+    out["bppp_commit_2p12"] = {"metric": "BP++ commitments/sec (secp256k1_bppp_commit, g_len 64, h_len 8)", "value": n / sec, "unit": "commitments/s", "ms": sec * 1e3, "batch": n, "verified": True,
+                               "result_check": "every 128th commitment == the reference's secp256k1_bppp_commit (static, through oracle/ref_shim.c), byte for byte",
+                               "roofline": roof(MAC64_PER_MSM_TERM_SMALL * terms, n, sec, "algorithmic one %d-term secp256k1_ecmult_multi_var per commitment x 10.6e3 MAC64 per term (src/modules/bppp/bppp_norm_product_impl.h:105-151)" % terms)}
+    if with_cpu:
+        k = 128
+        out["bppp_commit_2p12"]["cpu_baseline"] = cpu(lambda: [ref_commit(i) for i in range(k)], k, "secp256k1_bppp_commit through oracle/ref_shim.c")
+    del d_nv, d_lv, d_cv, d_mu, d_out, res
+    # ---- K independent small sums in one launch chain: 256 sums of bench_ecmult's shape (1 024 terms + G each)
+    K, nm = 256, 1024
+    ks = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+    pts, pinf = ref.ecmult_batch(np.tile(np.frombuffer(G_XY, np.uint8), (nm, 1)), ks)
+    scs = rng.integers(0, 256, (K * nm, 32), dtype=np.uint8); gs = rng.integers(0, 256, (K, 32), dtype=np.uint8)
+    d_s, d_p, d_g = D(scs), D(np.tile(pts, (K, 1))), D(gs)
+    r_xy = torch.zeros(K, 64, dtype=torch.uint8, device=dev); r_inf = torch.zeros(K, dtype=torch.int32, device=dev)
+    offs = (np.arange(K + 1) * nm).astype(np.uint64)
+    torch.cuda.synchronize()
+    sec = loop(lambda: eng.ecmult_multi_many_dev(r_xy, r_inf, d_s, d_p, offs, d_g))
+    got = r_xy.cpu().numpy(); gi = r_inf.cpu().numpy()
+    for s_ in range(0, K, 37):
+        exp_xy, exp_inf = ref.ecmult_multi(scs[s_ * nm:(s_ + 1) * nm], pts, gs[s_].tobytes())
+        assert bytes(got[s_]) == exp_xy.tobytes() and int(gi[s_]) == exp_inf, "batched 1 024-term MSM differs from the reference's ecmult_multi_var"
+    out["ecmult_multi_many_256x1024"] = {"metric": "256 independent 1 024-term multi-scalar multiplications incl. G in one launch chain (s2k_ecmult_multi_many_dev; BASELINE config 1's shape, batched)",
+                                         "value": K * nm / sec / 1e6, "unit": "Mpoint-scalar/s", "ms": sec * 1e3, "sums": K, "terms_per_sum": nm, "verified": True,
+                                         "result_check": "every 37th sum == secp256k1_ecmult_multi_var of the reference on the same terms",
+                                         "roofline": roof(MAC64_PER_MSM_TERM_SMALL, K * nm, sec, "algorithmic 10.6e3 MAC64 per term (SURVEY 8d, n = 1 024)")}
+    return out
+
+
 def measure_group(devices, commits, proofs, gens, ref, steps):
     """The C-ABI engine group (s2k_group_*, include/secp256k1_zkp_amd.h) over `devices`, from ONE process: (i) replica dispatch -- `len(devices)`
     times the headline batch handed over in HOST memory, cut into one contiguous range per engine, wall clock of the whole call; (ii) one
@@ -543,7 +724,10 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
     ap.add_argument("--no-group", action="store_true", help="skip the single-process C-ABI engine-group block (rank 0 over all the run's GPUs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 1, 2 and 4 (bench_ecmult 1024 pairs, BIP-340 2^16, BP++ norm argument 2^12)")
+    ap.add_argument("--no-next", action="store_true", help="skip the SURVEY 8(f) rows (surjection, half-aggregate, tallies, rewind, bppp_commit, batched small sums)")
+    ap.add_argument("--rp-split", type=int, choices=(0, 1), default=None, help="S2K_OPT_RP_SPLIT of the engine (A/B of the two forms of the ring kernel's double multiplication: tools/profile_mem_counters.sh)")
     args = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the hosts only support dmabuf IPC: RCCL between the ranks fails without it (set here, not at import: tests import this module)
 
     import torch
     import torch.distributed as dist
@@ -559,13 +743,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become the launcher of N ranks, one per GPU (exactly the command the docstring shows);
         # rank 0's JSON line goes to this process's stdout.  Under torch.distributed.run (WORLD_SIZE set) this branch is not taken.
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: the launcher picks its own rendezvous port -- probing for a free one here and handing it over is a race when
+        #  several benches start on one node)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               os.path.abspath(__file__)] + sys.argv[1:]
         sys.stdout.flush(); sys.stderr.flush()
-        os.execvpe(cmd[0], cmd, dict(os.environ, MASTER_ADDR="127.0.0.1"))
+        os.execvpe(cmd[0], cmd, dict(os.environ))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, world))
@@ -588,6 +771,7 @@ def main():
             assert sorted(rank_devices) == list(range(world)), "ranks do not own distinct devices: %r" % (rank_devices,)
     from secp256k1_zkp_amd import Engine
     eng = Engine(local)
+    if args.rp_split is not None: eng.set_option(Engine.OPT_RP_SPLIT, args.rp_split)
     torch.cuda.set_device(local)
     # the device's fixed-base table of G, built now (first use) so that its cost is a line of the record rather than part of a warm-up step
     import ctypes
@@ -851,6 +1035,11 @@ def main():
     if rank == 0 and not args.no_secondary and ref is not None:
         torch.cuda.synchronize(); time.sleep(1.0)
         secondary = measure_secondary(eng, ref, dev, max(3, args.steps), with_cpu=not args.no_cpu_baseline)
+        if not args.no_next:
+            try:
+                secondary.update(measure_next_rows(eng, ref, dev, max(3, args.steps), with_cpu=not args.no_cpu_baseline))
+            except Exception as ex:      # noqa: BLE001  (the headline must not be lost to a failure of these extra rows)
+                secondary["next_rows_error"] = repr(ex)
 
     # The C-ABI engine group, from rank 0 alone (the other ranks wait at the barrier below, their GPUs idle): one process drives every GPU of the
     # run through s2k_group_* -- the path a C caller without torch.distributed takes.  With one GPU: two engines on it (they share the

@@ -195,61 +195,53 @@ S2K_HD int bp_term(gej& out, const bp_shape& sh, u32 t, const u32* term_sc, cons
 }
 
 // ---- fixed-base tables for a generator set -------------------------------------------------------------------------------
-#define BP_TAB_BITS 16
-#define BP_TAB_WINDOWS 16
-S2K_HD size_t bp_tab_words(size_t n_gens) { return ((n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS) * 18; }
-S2K_HD u32* bp_tab_entry(u32* tab, u32 gen, u32 w, u32 v) { return tab + ((((size_t)gen * BP_TAB_WINDOWS + w) << BP_TAB_BITS) + v) * 18; }
-// entry (gen, w, 1) = 2^(16 w) * P_gen
-S2K_HD void bp_tab_build_base(u32* tab, const u32* gens18, u32 gen, u32 w) {
-    ge p; for (int i = 0; i < 9; i++) { p.x.n[i] = gens18[18 * gen + i]; p.y.n[i] = gens18[18 * gen + 9 + i]; }
-    gej j; gej_set_ge(j, p);
-    for (u32 i = 0; i < BP_TAB_BITS * w; i++) { gej t; gej_double(t, j); j = t; }
-    ge a; ge_set_gej(a, j);
-    u32* e = bp_tab_entry(tab, gen, w, 1);
-    for (int i = 0; i < 9; i++) { e[i] = a.x.n[i]; e[9 + i] = a.y.n[i]; }
+// One table per generator in the format of the table of G (gtable.h: signed D-bit digits, 64-byte records of canonical words, the header
+// in slot 0), back to back, built by the same seeded construction (window bases -> seeds -> one affine addition per entry with a shared
+// inversion per run of rows).  Rounds 2-5 had a format of their own here -- 16 unsigned 16-bit windows of 72-byte limb records, every entry
+// its own 16-step double-and-add with its own inversion: 119 ms for the 72 generators of config 4 the first time a set is seen.  The width
+// follows the size of the set (bp_tab_bits_for): fewer, wider windows for the usual sets (13 or 15 additions per generator term instead of
+// 16), narrower ones when a large set would not fit.
+S2K_HD u32 bp_tab_bits_for(size_t n_gens) {
+    // table bytes: n_gens x W(D) x 2^(D-1) x 64 -- 20 bits: 0.44 GB per generator (13 additions), 19: 0.23 GB (14), 18: 0.13 GB (15),
+    // 17: 0.07 GB (16).  Budget ~16 GB.
+    return n_gens <= 36 ? 20u : (n_gens <= 68 ? 19u : (n_gens <= 127 ? 18u : 17u));
 }
-// entry (gen, w, v) = v * entry (gen, w, 1), v >= 2
-S2K_HD void bp_tab_build_entry(u32* tab, u32 gen, u32 w, u32 v) {
-    ge base; { const u32* e = bp_tab_entry(tab, gen, w, 1); for (int i = 0; i < 9; i++) { base.x.n[i] = e[i]; base.y.n[i] = e[9 + i]; } }
+S2K_HD size_t bp_tab_stride(u32 D) { return gtab_words_for(D); }                       // words between the tables of consecutive generators
+S2K_HD size_t bp_tab_words(size_t n_gens, u32 D) { return n_gens * bp_tab_stride(D); }
+// k * P_gen through the generator's table (k: 8 little-endian words): one addition per window, no doubling; the record of window w + 1 is
+// requested before the addition of window w.  `tab`: the generator's own table (its header gives the geometry).
+S2K_HD void bp_term_fixed(gej& out, const u32* tab, const u32* k8) {
     gej acc; gej_set_infinity(acc);
-    for (int bit = BP_TAB_BITS - 1; bit >= 0; bit--) {
-        gej t; gej_double(t, acc); acc = t;
-        if ((v >> bit) & 1u) {
-            const int f = gej_add_ge(t, acc, base); acc = t;
+    const gtab_geom GG = gtab_geometry(tab);
+    u32 kr[S2K_GTAB_SWORDS]; gtab_recode(kr, k8, tab);
+    u32 raw[16]; int have = 0, neg = 0;
+    {   const u32* rec = tab;
+        have = gtab_locate(rec, neg, tab, GG, 0, kr[0], kr[1]);
+        if (have) { for (int i = 0; i < 16; i++) raw[i] = rec[i]; } }
+    for (int w = 0; w < (int)GG.W; w++) {
+        u32 nraw[16]; int nhave = 0, nneg = 0;
+        if (w + 1 < (int)GG.W) {
+            const int word = (int)(((u32)(w + 1) * GG.D) >> 5);
+            const u32* rec = tab;
+            nhave = gtab_locate(rec, nneg, tab, GG, w + 1, kr[word], word + 1 < S2K_GTAB_SWORDS ? kr[word + 1] : 0u);
+            if (nhave) { for (int i = 0; i < 16; i++) nraw[i] = rec[i]; }
+        }
+        if (have) {
+            ge p; fe_from_words(p.x, raw); fe_from_words(p.y, raw + 8);
+            if (neg) { fe_neg(p.y, p.y, 1); fe_norm_weak(p.y); }
+            gej t; const int f = gej_add_ge(t, acc, p); acc = t;
             if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
         }
-    }
-    ge a; ge_set_gej(a, acc);
-    u32* e = bp_tab_entry(tab, gen, w, v);
-    for (int i = 0; i < 9; i++) { e[i] = a.x.n[i]; e[9 + i] = a.y.n[i]; }
-}
-// k * P_gen as 16 table additions (k: 8 little-endian words); the next operand is fetched while the current one is added
-S2K_HD void bp_term_fixed(gej& out, const u32* tab, u32 gen, const u32* k8) {
-    gej acc; gej_set_infinity(acc);
-    ge cur, nxt; u32 vcur, vnxt;
-    fe_set_zero(cur.x); fe_set_zero(cur.y);
-    vcur = k8[0] & 0xFFFFu;
-    { const u32* e = bp_tab_entry((u32*)tab, gen, 0, vcur); for (int i = 0; i < 9; i++) { cur.x.n[i] = e[i]; cur.y.n[i] = e[9 + i]; } }
-    for (u32 w = 0; w < BP_TAB_WINDOWS; w++) {
-        vnxt = 0; nxt = cur;
-        if (w + 1 < BP_TAB_WINDOWS) {
-            vnxt = (k8[(w + 1) >> 1] >> (16 * ((w + 1) & 1))) & 0xFFFFu;
-            const u32* e = bp_tab_entry((u32*)tab, gen, w + 1, vnxt);
-            for (int i = 0; i < 9; i++) { nxt.x.n[i] = e[i]; nxt.y.n[i] = e[9 + i]; }
-        }
-        if (vcur) {
-            gej t; const int f = gej_add_ge(t, acc, cur); acc = t;
-            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
-        }
-        cur = nxt; vcur = vnxt;
+        have = nhave; neg = nneg;
+        if (nhave) { for (int i = 0; i < 16; i++) raw[i] = nraw[i]; }
     }
     out = acc;
 }
 
 // ---- secp256k1_bppp_commit (bppp_norm_product_impl.h:105-151), batched ---------------------------------------
 //   commit = v G + sum_i n_i G_i + sum_j l_j H_j ,   v = sum_i n_i^2 mu^(i+1) + <l, c>     (:33-69, :131-134)
-// Every base is fixed: the generators use the set's fixed-base table above (16 additions each, no doubling), G the engine's
-// generator table (13 additions).  One lane per (commitment, base); the per-commitment sums reuse the segmented tree reduction.
+// Every base is fixed: the generators use the set's fixed-base tables above, G the engine's generator table -- the same format, the same
+// routine (bp_term_fixed: one addition per window, no doubling).  One lane per (commitment, base); the per-commitment sums reuse the segmented tree reduction.
 S2K_HD void bpc_v_scalar(u32 v8[8], const unsigned char* n_vec32, u32 g_len, const unsigned char* l_vec32, const unsigned char* c_vec32, u32 h_len,
                          const unsigned char* mu32) {
     scalar mu, mu_pow, v; sc_set_b32(mu, mu32, nullptr); mu_pow = mu; sc_set_zero(v);
@@ -263,23 +255,4 @@ S2K_HD void bpc_v_scalar(u32 v8[8], const unsigned char* n_vec32, u32 g_len, con
         sc_mul(t, a, b); sc_add(v, v, t);
     }
     for (int k = 0; k < 8; k++) v8[k] = v.d[k];
-}
-// k * G through the generator table (gtable.h): one addition per window of the table, no doubling
-S2K_HD void bpc_gmul(gej& out, const u32* gtab, const u32* k8) {
-    gej acc; gej_set_infinity(acc);
-    const gtab_geom GG = gtab_geometry(gtab);
-    u32 kr[S2K_GTAB_SWORDS]; gtab_recode(kr, k8, gtab);              // signed fixed-base digits (ecmult.h)
-    for (int w = 0; w < (int)GG.W; w++) {
-        const int word = (int)(((u32)w * GG.D) >> 5);
-        const u32* rec = gtab; int neg = 0;
-        if (gtab_locate(rec, neg, gtab, GG, w, kr[word], word + 1 < S2K_GTAB_SWORDS ? kr[word + 1] : 0u)) {
-            u32 raw[16];
-            for (int i = 0; i < 16; i++) raw[i] = rec[i];
-            ge p; fe_from_words(p.x, raw); fe_from_words(p.y, raw + 8);
-            if (neg) { fe_neg(p.y, p.y, 1); fe_norm_weak(p.y); }
-            gej t; const int f = gej_add_ge(t, acc, p); acc = t;
-            if (f == GEJ_ADD_NEEDS_DOUBLE) { gej_double(t, acc); acc = t; }
-        }
-    }
-    out = acc;
 }

@@ -44,24 +44,35 @@ k_bp_terms(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, 
 }
 // generator terms 0 .. n_gens - 1 of every proof through the generator set's fixed-base table
 __global__ void __launch_bounds__(256, 2)
-k_bp_terms_fixed(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* tab, size_t n) {
+k_bp_terms_fixed(u32* out28, unsigned char* term_ok, bp_shape sh, const u32* term_sc, const int* proof_ok, const u32* tab, size_t tab_stride, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t p = t / sh.n_gens; const u32 ti = (u32)(t % sh.n_gens);
     if (p >= n) return;
     gej o; gej_set_infinity(o);
-    if (proof_ok[p]) bp_term_fixed(o, tab, ti, term_sc + (p * sh.n_terms + ti) * 8);
+    if (proof_ok[p]) bp_term_fixed(o, tab + (size_t)ti * tab_stride, term_sc + (p * sh.n_terms + ti) * 8);
     gej_store28(out28 + (p * sh.n_terms + ti) * 28, o); term_ok[p * sh.n_terms + ti] = 1;
 }
-__global__ void k_bp_tab_base(u32* tab, const u32* gens18, u32 n_gens) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_gens * BP_TAB_WINDOWS) bp_tab_build_base(tab, gens18, t / BP_TAB_WINDOWS, t % BP_TAB_WINDOWS);
+// the set's tables (bppp.h): lane (generator, window) writes the window's base (and window 0's lane the table's header); then the seeds and
+// the fill of gtable.h for every generator at once -- the generator rides in the grid
+__global__ void k_bp_tab_base(u32* tab, size_t stride, const u32* gens18, u32 n_gens, u32 D) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, W = gtab_windows_for(D);
+    if (t >= n_gens * W) return;
+    const u32 gen = t / W, w = t % W;
+    u32* T = tab + (size_t)gen * stride;
+    if (w == 0) gtab_write_header(T, D);
+    ge p; for (int i = 0; i < 9; i++) { p.x.n[i] = gens18[18 * gen + i]; p.y.n[i] = gens18[18 * gen + 9 + i]; }
+    gtab_build_base(T, D, w, &p);
 }
 __global__ void __launch_bounds__(256)
-k_bp_tab_entries(u32* tab, size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const u32 v = (u32)(t & 0xFFFFu); const size_t gw = t >> BP_TAB_BITS;
-    if (v >= 2) bp_tab_build_entry(tab, (u32)(gw / BP_TAB_WINDOWS), (u32)(gw % BP_TAB_WINDOWS), v);
+k_bp_tab_seeds(u32* tab, size_t stride, gtab_fill_plan p) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, per = gtab_seeds_per_window(p);
+    const u32 w = t / per;
+    if (w < p.W) gtab_build_seed(tab + (size_t)blockIdx.y * stride, p, w, t % per);
+}
+__global__ void __launch_bounds__(256, 2)
+k_bp_tab_fill(u32* tab, size_t stride, gtab_fill_plan p, u32 runs) {
+    const u32 b = blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
+    if (b >= 1u && b < p.Kc) gtab_fill_run(tab + (size_t)blockIdx.z * stride, p, w, b, run * GTAB_FILL_RUN);
 }
 __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,14 +91,23 @@ static int bp_table_cached(const s2k_engine* e, const unsigned char* gens33, siz
 static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, const int* gens_ok_dev, const unsigned char* gens33, size_t n_gens, int* fixed) {
     *fixed = n_gens <= 256;
     if (*fixed && !bp_table_cached(e, gens33, n_gens)) {
-        HIPCHK(hipStreamSynchronize(st));
-        if (e->bp_tab) { hipFree(e->bp_tab); e->bp_tab = nullptr; }
+        // (the old table may still be read by this engine's earlier calls: retired, not freed -- no wait for the device)
+        if (e->bp_tab) { engine_retire_dev(e, e->bp_tab, e->bp_tab_bytes); e->bp_tab = nullptr; e->bp_tab_bytes = 0; }
         e->bp_key.clear();
-        if (hipMalloc((void**)&e->bp_tab, bp_tab_words(n_gens) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); e->bp_tab = nullptr; *fixed = 0; }
+        u32 D = bp_tab_bits_for(n_gens);
+        for (;; D--) {                                        // (narrower when the memory is not there; 17 bits = 0.07 GB per generator)
+            if (hipMalloc((void**)&e->bp_tab, bp_tab_words(n_gens, D) * sizeof(u32)) == hipSuccess) break;
+            (void)hipGetLastError(); e->bp_tab = nullptr;
+            if (D == 17u) break;
+        }
+        if (!e->bp_tab) *fixed = 0;
         else {
-            const size_t total = (n_gens * BP_TAB_WINDOWS) << BP_TAB_BITS;
-            hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * BP_TAB_WINDOWS + 63) / 64)), dim3(64), 0, st, e->bp_tab, gens18, (u32)n_gens);
-            hipLaunchKernelGGL(k_bp_tab_entries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->bp_tab, total);
+            e->bp_tab_bytes = bp_tab_words(n_gens, D) * sizeof(u32); e->bp_tab_stride = bp_tab_stride(D);
+            const gtab_fill_plan p = gtab_make_fill_plan(D);
+            const u32 seeds = p.W * gtab_seeds_per_window(p), runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
+            hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * p.W + 63) / 64)), dim3(64), 0, st, e->bp_tab, e->bp_tab_stride, gens18, (u32)n_gens, D);
+            hipLaunchKernelGGL(k_bp_tab_seeds, dim3((seeds + 255) / 256, (unsigned)n_gens), dim3(256), 0, st, e->bp_tab, e->bp_tab_stride, p);
+            hipLaunchKernelGGL(k_bp_tab_fill, dim3((p.Kc + 255) / 256, p.W * runs, (unsigned)n_gens), dim3(256), 0, st, e->bp_tab, e->bp_tab_stride, p, runs);
             HIPCHK(hipGetLastError());
             int ok_host = 0;
             HIPCHK(hipMemcpyAsync(&ok_host, gens_ok_dev, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -136,7 +156,7 @@ static int bpv_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_re
         if (fixed) {
             HIPCHK(hipEventRecord(e->ev_msm_fork, st));
             HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_msm_fork, 0));
-            hipLaunchKernelGGL(k_bp_terms_fixed, dim3((unsigned)((n * n_gens + 255) / 256)), dim3(256), 0, e->stream2, out28, term_ok, sh, term_sc, proof_ok, e->bp_tab, n);
+            hipLaunchKernelGGL(k_bp_terms_fixed, dim3((unsigned)((n * n_gens + 255) / 256)), dim3(256), 0, e->stream2, out28, term_ok, sh, term_sc, proof_ok, e->bp_tab, e->bp_tab_stride, n);
             HIPCHK(hipEventRecord(e->ev_msm_join, e->stream2));
         }
         hipLaunchKernelGGL(k_bp_terms, dim3((unsigned)((n * tcount + 255) / 256)), dim3(256), 0, st, out28, term_ok, sh, term_sc, proof_ok, gens18, d_pr, proof_len, d_cm,
@@ -215,7 +235,7 @@ k_bpc_scalars(u32* v8, const unsigned char* n_vec, const unsigned char* l_vec, c
 }
 // lane (item, t): t < n_gens -> scalar_t * generator_t (fixed-base table, or the general double-and-add when there is none), t == n_gens -> v * G
 __global__ void __launch_bounds__(256, 2)
-k_bpc_terms(u32* out28, const u32* v8, const unsigned char* n_vec, const unsigned char* l_vec, u32 g_len, u32 h_len, const u32* tab, const u32* gens18, const int* gens_ok,
+k_bpc_terms(u32* out28, const u32* v8, const unsigned char* n_vec, const unsigned char* l_vec, u32 g_len, u32 h_len, const u32* tab, size_t tab_stride, const u32* gens18, const int* gens_ok,
             const u32* gtab, u32* ptab, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 T = g_len + h_len + 1;
@@ -228,8 +248,8 @@ k_bpc_terms(u32* out28, const u32* v8, const unsigned char* n_vec, const unsigne
         for (int q = 0; q < 8; q++) k8[q] = live ? k.d[q] : 0u;
     } else for (int q = 0; q < 8; q++) k8[q] = live ? v8[8 * ii + q] : 0u;
     gej o;
-    if (ti == g_len + h_len) bpc_gmul(o, gtab, k8);
-    else if (tab) bp_term_fixed(o, tab, ti, k8);
+    if (ti == g_len + h_len) bp_term_fixed(o, gtab, k8);            // (the table of G has the same format: one routine)
+    else if (tab) bp_term_fixed(o, tab + (size_t)ti * tab_stride, k8);
     else {
         __shared__ u32 s_dig[S2K_DIG_WORDS * 256];
         const lane_mem lm{ptab + t * S2K_PTAB_WORDS, S2K_LANE_DIG(s_dig)};
@@ -266,7 +286,7 @@ static int bpc_launch(s2k_engine* e, hipStream_t st, ws_carver& c, unsigned char
     if (!fixed && !engine_ptab(e, ((n * T + 255) / 256) * 256)) return 0;
     hipLaunchKernelGGL(k_bpc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, v8, d_nv, d_lv, d_cv, d_mu, (u32)g_len, (u32)h_len, n);
     HIPCHK(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_bpc_terms, dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st, out28, v8, d_nv, d_lv, (u32)g_len, (u32)h_len, fixed ? e->bp_tab : (const u32*)nullptr,
+    hipLaunchKernelGGL(k_bpc_terms, dim3((unsigned)((n * T + 255) / 256)), dim3(256), 0, st, out28, v8, d_nv, d_lv, (u32)g_len, (u32)h_len, fixed ? e->bp_tab : (const u32*)nullptr, e->bp_tab_stride,
                        gens18, gens_ok, e->gtab, e->ptab, n);
     HIPCHK(hipEventRecord(e->ev[3], st));
     const u32* sums = launch_gej_reduce(st, out28, bufA, bufB, (u32)n, (u32)T);

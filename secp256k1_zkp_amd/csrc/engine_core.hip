@@ -27,15 +27,49 @@ extern "C" void s2k_clear_status(void) { g_last_status = S2K_STATUS_OK; g_last_e
 // ------------------------------------------------------------------------------------------------------------
 // engine scratch
 // ------------------------------------------------------------------------------------------------------------
+// ---- growth without a device-wide wait ------------------------------------------------------------------------------------------------
+void engine_retire_dev(s2k_engine* e, void* p, size_t bytes) { if (p) { e->retired_dev.push_back(p); e->retired_bytes += bytes; } }
+void engine_retire_host(s2k_engine* e, void* p) { if (p) e->retired_host.push_back(p); }
+// waits for the work of THIS engine only -- its own streams and, through the event every entry point leaves behind, the caller streams its
+// `_dev` calls were issued on -- and hands the outgrown buffers back
+int engine_make_room(s2k_engine* e) {
+    hipStream_t own[] = {e->stream, e->stream2, e->stream_pre, e->stream_copy, e->msm_slot[0].s, e->msm_slot[0].s2, e->msm_slot[1].s, e->msm_slot[1].s2};
+    for (hipStream_t s : own) if (s) HIPCHK(hipStreamSynchronize(s));
+    if (e->last_stream_valid) HIPCHK(hipEventSynchronize(e->ev_last));
+    for (void* p : e->retired_dev) (void)hipFree(p);
+    for (void* p : e->retired_host) (void)hipHostFree(p);
+    e->retired_dev.clear(); e->retired_host.clear(); e->retired_bytes = 0;
+    (void)hipGetLastError();
+    return 1;
+}
+// *buf (of *have bytes) becomes at least `need` bytes: a new allocation of max(need, 1.5 x have) beside the old buffer, which is retired, not
+// freed (launches in flight may still use it).  Only when there is no room beside it does the call wait -- for this engine's work alone --
+// give everything outgrown back and take exactly what it needs.
+#define S2K_RETIRED_MAX (size_t(16) << 30)
+int engine_grow_dev(s2k_engine* e, void** buf, size_t* have, size_t need, size_t unit) {
+    if (need <= *have) return 1;
+    auto round = [&](size_t b) { return (b + unit) & ~(unit - 1); };
+    size_t want = round(std::max(need, *have + *have / 2));
+    void* p = nullptr;
+    if (e->retired_bytes + *have > S2K_RETIRED_MAX || hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError(); p = nullptr;
+        if (!engine_make_room(e)) return 0;
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr; *have = 0;
+        want = round(need);
+        HIPCHK(hipMalloc(&p, want));
+    } else engine_retire_dev(e, *buf, *have);
+    *buf = p; *have = want;
+    return 1;
+}
 // per-lane table scratch for `lanes` concurrent ecmult_lane callers (lane = global thread index of the launch)
 int engine_ptab(s2k_engine* e, size_t lanes) {
     lanes = (lanes + 255) & ~size_t(255);
     if (lanes <= e->ptab_lanes) return 1;
-    HIPCHK(hipDeviceSynchronize());                 // earlier launches (possibly on a caller's stream) may still use the old arena
-    if (e->ptab) HIPCHK(hipFree(e->ptab));
-    e->ptab = nullptr; e->ptab_lanes = 0;
-    HIPCHK(hipMalloc((void**)&e->ptab, lanes * S2K_PTAB_WORDS * sizeof(u32)));
-    e->ptab_lanes = lanes;
+    size_t have = e->ptab_lanes * S2K_PTAB_WORDS * sizeof(u32); void* buf = e->ptab;
+    const size_t per = 256 * S2K_PTAB_WORDS * sizeof(u32);
+    if (!engine_grow_dev(e, &buf, &have, lanes * S2K_PTAB_WORDS * sizeof(u32), per)) { e->ptab = (u32*)buf; e->ptab_lanes = (have / per) * 256; return 0; }
+    e->ptab = (u32*)buf; e->ptab_lanes = (have / per) * 256;
     return 1;
 }
 // the arena of the rings kernels for `rings` rings: the general form wants S2K_PTAB_WORDS per ring; the shared form, with S2K_RP_K rings per
@@ -51,13 +85,10 @@ int engine_rtab(s2k_engine* e, size_t rings) {
 // (engine field max_lanes; default 2^20, $S2K_MAX_LANES overrides it -- the tests use a small value to exercise the split)
 int engine_workspace(s2k_engine* e, size_t bytes) {
     if (bytes <= e->ws_bytes) return 1;
-    HIPCHK(hipDeviceSynchronize());                 // earlier launches (possibly on a caller's stream) may still use the old workspace
-    if (e->ws) HIPCHK(hipFree(e->ws));
-    e->ws = nullptr; e->ws_bytes = 0;
-    bytes = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-    HIPCHK(hipMalloc((void**)&e->ws, bytes));
-    e->ws_bytes = bytes;
-    return 1;
+    void* buf = e->ws; size_t have = e->ws_bytes;
+    const int ok = engine_grow_dev(e, &buf, &have, bytes, size_t(1) << 20);
+    e->ws = (unsigned char*)buf; e->ws_bytes = have;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -84,6 +115,10 @@ k_gtab_fill(u32* gtab, gtab_fill_plan p, u32 runs) {
 // the three launches; `base_done`: the window bases (and the header) are already there (a generator's table: k_gen_base wrote them)
 static int launch_table_build(hipStream_t st, u32* tab, u32 D, int base_done) {
     const gtab_fill_plan p = gtab_make_fill_plan(D);
+    // the top window only has entries in its first top_rows rows: the slots behind them (never addressed by a digit) are cleared, so that the
+    // table's bytes are defined -- s2k_engine_gtable() shows the whole allocation, and a prefetch that strays there finds zeros, not stale HBM
+    {   const size_t first = gtab_slot(D, p.W - 1, 0) + (size_t)p.top_rows * p.Kc, end = gtab_slots_for(D);
+        if (end > first && hipMemsetAsync(tab + first * S2K_GTAB_ENTRY_WORDS, 0, (end - first) * S2K_GTAB_ENTRY_WORDS * sizeof(u32), st) != hipSuccess) return 0; }
     if (!base_done) hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, tab, D);
     const u32 seeds = p.W * gtab_seeds_per_window(p);
     hipLaunchKernelGGL(k_gtab_seeds, dim3((seeds + 255) / 256), dim3(256), 0, st, tab, p);
@@ -167,16 +202,18 @@ k_ecmult_batch(unsigned char* __restrict__ r_xy, int32_t* __restrict__ r_inf, co
 // no table memory and no table build.  Tables are built lazily, by the first call that needs one (s2k_engine_reserve warms them up).
 // Ordering between engines: a build is stream-ordered on the building engine's stream and publishes an event; every other stream
 // that is about to read the table waits for that event until it is known to have completed.  The pool's mutex is held while an engine
-// takes its view of the cache AND enqueues the kernels that use it, and a slot's memory is only ever rewritten (eviction, fewer slots)
-// after a device-wide synchronisation under that mutex, so no kernel in flight can read a table that is being replaced.
+// takes its view of the cache AND enqueues the kernels that use it AND records, per slot in the view, an event behind the last of them
+// (gen_note_read); a slot's memory is only ever rewritten (eviction) or freed (fewer slots) behind the events of the engines that read
+// it, so no kernel in flight can read a table that is being replaced -- and nobody waits for engines that never touched the slot.
 // Lock order: engine mutex, then pool mutex.
 // secp256k1_generator_h (src/modules/generator/main_impl.h:30-35): the generator of bench_rangeproof and of every non-asset caller
 static std::mutex g_pools_mu;
 static std::vector<s2k_dev_pool*> g_pools;
 static void pool_free_tables(s2k_dev_pool* p) {
     if (p->gtab) hipFree(p->gtab);
-    p->gtab = nullptr; p->gtab_state = 0;
+    p->gtab = nullptr; p->gtab_state = 0; p->gtab_bits = p->gtab_bits_wanted;
     for (int i = 0; i < RP_GEN_SLOTS; i++) {
+        p->gen[i].readers.clear();
         if (p->gen[i].tab) hipFree(p->gen[i].tab);
         if (p->gen[i].xmul) hipFree(p->gen[i].xmul);
         p->gen[i].tab = nullptr; p->gen[i].xmul = nullptr; p->gen[i].valid = 0;
@@ -192,6 +229,7 @@ static s2k_dev_pool* pool_acquire(int device) {
     p->gen_slots = 2; p->gen_clock = 0; p->gen_min = size_t(1) << 16; p->gen_h = 1;
     p->gtab_bits = S2K_GTAB_BITS;
     if (const char* gb = getenv("S2K_GTAB_BITS")) { const int v = atoi(gb); if (v >= 20 && v <= S2K_GTAB_MAX_BITS && gtab_bits_ok((u32)v)) p->gtab_bits = (u32)v; }
+    p->gtab_bits_wanted = p->gtab_bits;
     if (const char* gs = getenv("S2K_GEN_CACHE")) { const int v = atoi(gs); p->gen_slots = v < 0 ? 0 : (v > RP_GEN_SLOTS ? RP_GEN_SLOTS : v); }
     if (const char* gm = getenv("S2K_GEN_CACHE_MIN")) p->gen_min = (size_t)strtoull(gm, nullptr, 10);
 #ifdef S2K_DIAG
@@ -236,10 +274,18 @@ const u32* engine_gtab(s2k_engine* e, hipStream_t st) {
     if (p->gtab_state == 0) {
         // The widest table the device has room for, from the wanted width down (26 bits = 21.5 GB, 24 = 5.9 GB, 22 = 1.6 GB, 20 = 0.44 GB):
         // a partitioned or shared GPU still gets an engine, with one more addition per fixed-base multiplication for every step down.
+        // A width is only taken when the table leaves headroom: a device with 22-24 GB free would get the 21.5 GB table and then fail every
+        // call for want of workspace, where the 5.9 GB one works.  Headroom: the workspace this engine has reserved or 4 GB, whichever is
+        // larger, beside the table (generator-slot tables are optional: a slot that finds no memory leaves its proofs on the general form).
         p->gtab = nullptr;
-        for (u32 D = p->gtab_bits; D >= 20u; D -= 2u) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = ~size_t(0); }
+        const size_t headroom = std::max(size_t(4) << 30, e->ws_bytes / 2);
+        for (u32 D = p->gtab_bits_wanted; D >= 20u; D -= 2u) {
             if (!gtab_bits_ok(D)) continue;
-            if (hipMalloc((void**)&p->gtab, sizeof(u32) * gtab_words_for(D)) == hipSuccess) { p->gtab_bits = D; break; }
+            const size_t bytes = sizeof(u32) * gtab_words_for(D);
+            if (D > 20u && (free_b < bytes || free_b - bytes < headroom)) continue;
+            if (hipMalloc((void**)&p->gtab, bytes) == hipSuccess) { p->gtab_bits = D; break; }
             (void)hipGetLastError(); p->gtab = nullptr;
         }
         if (!p->gtab) { s2k_fail("engine_gtab", "no memory for the generator table (0.44 GB of HBM at the narrowest width)"); return nullptr; }
@@ -273,6 +319,17 @@ rp_gen_dev gen_dev_view(s2k_engine* e, hipStream_t st, hipStream_t sp) {
     }
     return gc;
 }
+// End of a call whose kernels read the tables of the slots in `valid_mask` (pool mutex still held since the view was taken): one event per
+// slot behind the call's last kernel on `st`, which every side stream of the call has been joined into
+void gen_note_read(s2k_engine* e, hipStream_t st, u32 valid_mask) {
+    s2k_dev_pool* p = e->pool;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) {
+        if (!((valid_mask >> i) & 1u)) continue;
+        if (hipEventRecord(e->ev_gen_read[i], st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); continue; }      // (cannot mark: make the reads over instead)
+        auto& r = p->gen[i].readers;
+        if (std::find(r.begin(), r.end(), e) == r.end()) r.push_back(e);
+    }
+}
 int gen_cache_find(s2k_dev_pool* p, const unsigned char* key) {
     for (int i = 0; i < p->gen_slots; i++) if (p->gen[i].valid && !memcmp(p->gen[i].key, key, 64)) { p->gen[i].stamp = ++p->gen_clock; return i; }
     return -1;
@@ -297,9 +354,15 @@ int gen_cache_build(s2k_engine* e, hipStream_t st, const unsigned char* key, int
     const u32* gtab = engine_gtab(e, st);
     if (!gtab) return -1;
     e->gtab = const_cast<u32*>(gtab);
-    // a slot whose memory may still be read -- by this engine's side streams or by another engine's kernels -- is rewritten only once the
-    // device is idle (an eviction is a 0.3 s table build anyway)
-    if (g.tab && hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
+    // a slot whose memory may still be read -- by this engine's side streams or by another engine's kernels -- is rewritten only behind its
+    // readers: the build's stream waits for the event each reading engine recorded behind its last reading kernel (gen_note_read).  Nothing
+    // waits on the host, and engines that never touched this slot are not involved at all (until round 5: hipDeviceSynchronize() here, with
+    // the engine's and the pool's locks held -- every verifier thread on the GPU stalled for the longest stream in flight).
+    if (g.tab) {
+        if (!g.done && hipStreamWaitEvent(st, g.ev_ready, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }      // (a build of this slot still in flight)
+        for (s2k_engine* r : g.readers) if (hipStreamWaitEvent(st, r->ev_gen_read[slot], 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        g.readers.clear();
+    }
     if (!g.tab) {
         if (hipMalloc((void**)&g.tab, sizeof(u32) * gtab_words_for(p->gtab_bits)) != hipSuccess) { (void)hipGetLastError(); g.tab = nullptr; return -1; }      // (the width of the table of G)
         if (hipMalloc((void**)&g.xmul, sizeof(u32) * RP_XMUL_WORDS) != hipSuccess) { (void)hipGetLastError(); hipFree(g.tab); g.tab = nullptr; g.xmul = nullptr; return -1; }
@@ -369,7 +432,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     if (device < 0 || device >= count) { s2k_fail("s2k_engine_create", "device ordinal out of range"); return nullptr; }
     HIPCHK_NULL(hipSetDevice(device));
     s2k_engine* e = new s2k_engine();
-    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr; e->bp_gens_ok = 0;
+    e->device = device; e->ws = nullptr; e->ws_bytes = 0; e->gtab = nullptr; e->ptab = nullptr; e->ptab_lanes = 0; e->host_flags = nullptr; e->dev_flags = nullptr; e->bp_tab = nullptr; e->bp_tab_bytes = 0; e->bp_tab_stride = 0; e->bp_gens_ok = 0;
     e->stream = nullptr; e->stream2 = nullptr; e->ev_fork = nullptr; e->ev_join = nullptr; for (int i = 0; i < 4; i++) e->ev[i] = nullptr;
     for (int i = 0; i < 32; i++) e->ev_ring[i][0] = e->ev_ring[i][1] = nullptr;
     e->ring_seq = 0;
@@ -377,7 +440,8 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     e->ev_rp_draws = nullptr; e->ev_rp_rewound = nullptr; e->rp_rewound_valid = 0;
     e->stream_pre = nullptr; e->ev_rp_in = nullptr; e->rp_mem_bytes = 0; e->rp_seq = 0; e->rp_inputs_ready = 0;
     e->rp_last_plan[0] = e->rp_last_plan[1] = nullptr;
-    e->ha_pin = nullptr; e->ha_pin_words = 0;
+    e->ha_pin = nullptr; e->ha_pin_words = 0; e->retired_bytes = 0;
+    for (int i = 0; i < RP_GEN_SLOTS; i++) e->ev_gen_read[i] = nullptr;
     for (int i = 0; i < 2; i++) { auto& m = e->msm_slot[i]; m.s = m.s2 = nullptr; m.fork = m.join = m.done = m.in = nullptr; m.ws = nullptr; m.ws_bytes = 0; m.seen_epoch = 0; }
     e->msm_seq = 0; e->cur_pipe = 0; e->ev_last_np = nullptr; e->np_epoch = 0; e->np_valid = 0;
     e->msm_pipeline = 0; e->halfagg_host_chain = 1; e->sync_split = 1; e->stage_log = 0;
@@ -443,6 +507,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     S2K_CREATE_CHK(hipMemset(e->gen_mbox, 0, sizeof(rp_gen_mbox)));
     S2K_CREATE_CHK(hipHostMalloc((void**)&e->gen_mbox_host, sizeof(rp_gen_mbox), hipHostMallocDefault));
     S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_mbox, hipEventDisableTiming));
+    for (int i = 0; i < RP_GEN_SLOTS; i++) S2K_CREATE_CHK(hipEventCreateWithFlags(&e->ev_gen_read[i], hipEventDisableTiming));
     e->pool = pool_acquire(device);            // the device's tables: shared with every other engine on it, built on first use
     if (!e->pool) { s2k_engine_destroy(e); return nullptr; }
 #undef S2K_CREATE_CHK
@@ -452,6 +517,11 @@ extern "C" void s2k_engine_destroy(s2k_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     hipDeviceSynchronize();            // `_dev` calls may have been issued on caller streams: nothing of this engine may still be in flight
+    for (void* p : e->retired_dev) hipFree(p);
+    for (void* p : e->retired_host) hipHostFree(p);
+    e->retired_dev.clear(); e->retired_host.clear();
+    if (e->pool) { std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu); for (int i = 0; i < RP_GEN_SLOTS; i++) { auto& r = e->pool->gen[i].readers; r.erase(std::remove(r.begin(), r.end(), e), r.end()); } }
+    for (int i = 0; i < RP_GEN_SLOTS; i++) if (e->ev_gen_read[i]) hipEventDestroy(e->ev_gen_read[i]);
     if (e->ws) hipFree(e->ws);
     if (e->ptab) hipFree(e->ptab);
     if (e->bp_tab) hipFree(e->bp_tab);
@@ -778,8 +848,12 @@ extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
         std::lock_guard<std::recursive_mutex> pool_lock(p->mu);
         const int v = value < 0 ? 0 : (value > RP_GEN_SLOTS ? RP_GEN_SLOTS : (int)value);
         if (v < p->gen_slots) {                            // slots that go away give their tables back once nothing can still read them
-            if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return s2k_fail("s2k_engine_set_option", "device synchronisation failed");
+            // (waits for the slots' own builds and readers -- their events -- not for the device)
+            if (hipSetDevice(e->device) != hipSuccess) return s2k_fail("s2k_engine_set_option", "hipSetDevice failed");
             for (int i = v; i < p->gen_slots; i++) {
+                if (p->gen[i].tab && p->gen[i].valid && hipEventSynchronize(p->gen[i].ev_ready) != hipSuccess) return s2k_fail("s2k_engine_set_option", "waiting for a table build failed");
+                for (s2k_engine* r : p->gen[i].readers) if (hipEventSynchronize(r->ev_gen_read[i]) != hipSuccess) return s2k_fail("s2k_engine_set_option", "waiting for a table's readers failed");
+                p->gen[i].readers.clear();
                 if (p->gen[i].valid && !memcmp(p->gen[i].key, k_generator_h, 64) && p->gen_h == 2) p->gen_h = 1;
                 if (p->gen[i].tab) hipFree(p->gen[i].tab);
                 if (p->gen[i].xmul) hipFree(p->gen[i].xmul);
@@ -808,6 +882,7 @@ extern "C" int s2k_engine_reserve(s2k_engine* e, size_t n_items) {
         if (e->pool->gen_slots > 0 && e->pool->gen_h == 1) { e->pool->gen_h = 2; (void)gen_cache_build(e, e->stream, k_generator_h, 1); }
     }
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (!e->retired_dev.empty() || !e->retired_host.empty()) return engine_make_room(e);      // an explicit sizing call: outgrown buffers go back now
     return 1;
 }
 

@@ -40,6 +40,22 @@ k_ha_chain(u32* states, const u32* __restrict__ wk, size_t nblocks) {
         if (threadIdx.x == 0) { for (int k = 0; k < 8; k++) states[8 * j + k] = st[k]; }
     }
 }
+// Chain states that came from the CALLER (secp256k1_schnorrsig_aggverify_dev_chain) are checked before they are believed: with every
+// intermediate state given, block j's state is compress(state[j - 1], block j) -- one compression per lane, all blocks in parallel -- and any
+// mismatch raises the flag that makes the verdict 0.  The randomizers z_i come out of these states: unchecked, a wrong array could turn
+// a forged aggregate into an accepted one (the reference always derives z_i from the inputs it verifies, main_impl.h:153-163).
+__global__ void __launch_bounds__(256)
+k_ha_check_chain(u32* flags, const u32* __restrict__ states, const unsigned char* aggsig, const unsigned char* pkx32, const unsigned char* msgs32, size_t nblocks) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nblocks) return;
+    u32 wk[64]; ha_schedule(wk, aggsig, pkx32, msgs32, j);
+    u32 st[8];
+    if (j == 0) ha_tag_midstate(st); else { for (int k = 0; k < 8; k++) st[k] = states[8 * (j - 1) + k]; }
+    ha_rounds(st, wk);
+    u32 diff = 0;
+    for (int k = 0; k < 8; k++) diff |= st[k] ^ states[8 * j + k];
+    if (diff) flags[0] = 1u;
+}
 __global__ void __launch_bounds__(256)
 k_ha_scalars(unsigned char* sc, unsigned char* g32, u32* flags, const u32* states, schnorr_midstate bip340, const unsigned char* aggsig,
              const unsigned char* pkx32, const unsigned char* msgs32, size_t n) {
@@ -99,7 +115,8 @@ static int ha_launch(s2k_engine* e, hipStream_t st, ws_carver& c, int32_t* d_res
     const unsigned bn = (unsigned)((n + 255) / 256);
     if (n) hipLaunchKernelGGL(k_ha_points, dim3(bn), dim3(256), 0, st, d_pts, d_pkx, d_flags, d_agg, d_pk, pk_format, n);
     if (nblocks && d_states_in) {
-        d_states = const_cast<u32*>(d_states_in);              // the caller has walked the chain (secp256k1_schnorrsig_aggverify_dev_chain)
+        d_states = const_cast<u32*>(d_states_in);              // the caller has walked the chain (secp256k1_schnorrsig_aggverify_dev_chain): checked, in parallel
+        hipLaunchKernelGGL(k_ha_check_chain, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, d_flags, (const u32*)d_states_in, d_agg, (const unsigned char*)d_pkx, d_msg, nblocks);
     } else if (nblocks && host) {
         HIPCHK(hipGetLastError());
         ha_host_chain(e->ha_pin, *host, nblocks);              // the GPU lifts the points meanwhile
@@ -138,7 +155,8 @@ extern "C" int secp256k1_schnorrsig_aggverify_dev(s2k_engine* e, void* stream, i
 // still HAS them on the host (it received them there): it walks the chain with s2k_halfagg_chain_states (or its own SHA-256), uploads the
 // 32 bytes per block, and the device only finalises every z_i in parallel.  chain_states: ((3 n) >> 1) x 8 words in HBM, state after every
 // full 64-byte block of the tagged hash's input behind the tag midstate; NULL: the device walks the chain itself (the plain `_dev` form).
-// A wrong state array gives a wrong verdict for THIS aggregate only -- it is input data of the caller, like the keys.
+// The states are CHECKED on the device (k_ha_check_chain: state[j] == compress(state[j - 1], block j) for every j, in parallel -- the chain is
+// serial to walk but not to verify), so a wrong or malicious array can only turn the verdict to 0, never to 1.
 extern "C" int secp256k1_schnorrsig_aggverify_dev_chain(s2k_engine* e, void* stream, int32_t* result_dev, const unsigned char* pubkeys, int pk_format,
                                                         const unsigned char* msgs32, size_t n, const unsigned char* aggsig, size_t aggsig_len,
                                                         const uint32_t* chain_states) {

@@ -68,7 +68,7 @@ struct s2k_engine {
     hipEvent_t ev_fork, ev_join;
     schnorr_midstate bip340;   // tagged-hash midstate, computed once on the host
     size_t max_lanes;          // lanes per launch (multiple of 256)
-    int rp_split;              // rangeproof rings use the two-piece double multiplication (ecmult_lane_split); $S2K_RP_SPLIT=0 turns it off
+    int rp_split;              // rangeproof rings use the two-piece double multiplication (ecmult_lane_split); S2K_OPT_RP_SPLIT = 0 turns it off (an option: product builds read no such variable from the environment)
     // Rangeproof pipeline (rp_launch): two sets of per-proof scratch records, so that the header / prologue / lift / key-sum stage of
     // one chunk (side streams, latency bound) runs underneath the rings kernel of the chunk before it (caller's stream).
     unsigned char* rp_mem[2]; size_t rp_mem_bytes;
@@ -85,7 +85,7 @@ struct s2k_engine {
     u32* host_flags;           // pinned, 64 bytes (diagnostic read-backs)
     u32* dev_flags;            // device, 64 bytes: [0] the most recent MSM launch overflowed a bucket region (exact path taken)
     std::vector<unsigned char> bp_key;   // serialised generator set the BP++ fixed-base table was built for
-    u32* bp_tab;               // [n_gens][16][65536] affine multiples (bppp.h), kept across calls
+    u32* bp_tab; size_t bp_tab_bytes, bp_tab_stride;   // the BP++ generator set's fixed-base tables (bppp.h: one table of G's format per generator, bp_tab_stride words apart), kept across calls
     int bp_gens_ok;            // every generator of the cached set parsed (what k_bp_gens found when the table was built)
     // The generator table and the cache of rangeproof generator tables live in the device's pool (below); per engine: the mailbox through
     // which k_rp_final reports which tables served verified proofs and which uncached generators keep coming.
@@ -126,6 +126,12 @@ struct s2k_engine {
     struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small, T2, old_tail, slice_r, slice_lds, slice_maxc; } msm_diag;
     size_t msm_max_terms_opt;  // S2K_OPT_MSM_MAX_TERMS: sums with more terms go as several launches whose partial sums add (0: the 32-bit reference limit)
     u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
+    // Buffers this engine has outgrown.  Growing a buffer never waits for the device (round 6; it used to be hipDeviceSynchronize() + hipFree
+    // under the engine's lock, i.e. a stall for the longest stream of EVERY engine on the GPU): the new buffer is allocated beside the old
+    // one, which may still be read by launches in flight and is only handed back when the engine is known to be idle -- at destruction, at
+    // s2k_engine_reserve, or when an allocation fails (engine_make_room: waits for THIS engine's streams only).
+    std::vector<void*> retired_dev, retired_host; size_t retired_bytes;
+    hipEvent_t ev_gen_read[RP_GEN_SLOTS];   // recorded behind the last kernel of a rangeproof call that read generator table i (see s2k_dev_pool::gen_slot::readers)
     std::recursive_mutex mu;
 };
 
@@ -146,6 +152,12 @@ struct stream_guard {
 };
 // per-lane table scratch / rings arena / workspace of an engine, grown on demand (engine_core.hip)
 int engine_ptab(s2k_engine* e, size_t lanes);
+// growth without a device-wide wait (see s2k_engine::retired_dev)
+int engine_grow_dev(s2k_engine* e, void** buf, size_t* have, size_t need, size_t unit);
+void engine_retire_dev(s2k_engine* e, void* p, size_t bytes);
+void engine_retire_host(s2k_engine* e, void* p);
+int engine_make_room(s2k_engine* e);
+void gen_note_read(s2k_engine* e, hipStream_t st, u32 valid_mask);
 int engine_rtab(s2k_engine* e, size_t rings);
 int engine_workspace(s2k_engine* e, size_t bytes);
 
@@ -188,14 +200,17 @@ struct s2k_dev_pool {
     std::recursive_mutex mu;
     u32* gtab; hipEvent_t ev_gtab; int gtab_state;           // 0: not built, 1: build queued (ev_gtab behind it), 2: known to be complete
     hipEvent_t ev_build[2];                                   // around the construction kernels of the table of G (s2k_engine_gtable_build_ms)
-    u32 gtab_bits;                                            // digit width of the device's tables: wanted ($S2K_GTAB_BITS, default 26) until the table of G exists, then what fitted
+    u32 gtab_bits, gtab_bits_wanted;                          // digit width of the device's tables: wanted ($S2K_GTAB_BITS, default 26) until the table of G exists, then what fitted (back to wanted when the tables are freed)
     // Fixed-base tables of rangeproof generators: a small cache keyed by the 64 generator bytes.  Slot tables have the layout of gtab
     // (allocated when a slot is first used and then reused by whatever generator takes the slot); xmul is the x-table of the ring-base
     // multiples (RP_XMUL_WORDS).  gen_keys (device) is what k_rp_header matches a proof's generator against; gen_seen counts the VERIFIED
     // proofs met per uncached generator (k_rp_final reports them through each engine's device mailbox, read at that engine's next call)
     // and a generator is built once it reaches gen_min.  pinned: secp256k1_generator_h and generators cached explicitly -- an automatic
     // build never evicts those.
-    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; int pinned; hipEvent_t ev_ready; int done; } gen[RP_GEN_SLOTS];
+    // readers: the engines whose kernels may still read this slot's tables (each records its ev_gen_read[slot] behind the last kernel of
+    // every call that took the slot into its view, pool mutex held from the view to the record): a build that REUSES the slot's memory makes
+    // its stream wait for exactly those events -- no host wait, no device-wide synchronisation (round 6).
+    struct gen_slot { unsigned char key[64]; u32* tab; u32* xmul; unsigned long long stamp; int valid; int pinned; hipEvent_t ev_ready; int done; std::vector<s2k_engine*> readers; } gen[RP_GEN_SLOTS];
     int gen_slots; unsigned long long gen_clock; size_t gen_min; int gen_h;
     unsigned char* gen_keys;   // device, [RP_GEN_SLOTS][64]
     std::vector<std::pair<std::array<unsigned char, 64>, size_t>> gen_seen;

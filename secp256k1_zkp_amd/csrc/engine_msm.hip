@@ -1056,13 +1056,11 @@ static int msm_pipelined(s2k_engine* e, hipStream_t st, int finish, uint32_t* ou
     const size_t need = msm_ws_bytes(e, nt + 1, pl);
     const unsigned si = e->msm_seq++ & 1u;
     auto& S = e->msm_slot[si];
-    if (need > S.ws_bytes) {
-        HIPCHK(hipStreamSynchronize(S.s)); HIPCHK(hipStreamSynchronize(S.s2));
-        if (S.ws) HIPCHK(hipFree(S.ws));
-        S.ws = nullptr; S.ws_bytes = 0;
-        const size_t bytes = (need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-        HIPCHK(hipMalloc((void**)&S.ws, bytes));
-        S.ws_bytes = bytes;
+    if (need > S.ws_bytes) {           // (the outgrown buffer may still be in use by the slot's previous call: retired, not freed)
+        void* buf = S.ws; size_t have = S.ws_bytes;
+        const int ok = engine_grow_dev(e, &buf, &have, need, size_t(1) << 20);
+        S.ws = (unsigned char*)buf; S.ws_bytes = have;
+        if (!ok) return 0;
     }
     // the slot's streams are not the caller's: work of an earlier call of another kind (it shares the engine's table arena with this
     // call's exact path) must be over first -- EVERY slot waits once for the latest such call (its epoch), not only the slot that happens to

@@ -224,11 +224,21 @@ static void rp_ws_carve(rp_ws& w, ws_carver& c, size_t n) {
 int engine_rp_slots(s2k_engine* e, size_t nw) {
     const size_t bytes = (rp_ws_bytes(nw) + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
     if (bytes <= e->rp_mem_bytes) return 1;
-    HIPCHK(hipDeviceSynchronize());                 // earlier launches may still use the old records
-    for (int i = 0; i < 2; i++) { if (e->rp_mem[i]) HIPCHK(hipFree(e->rp_mem[i])); e->rp_mem[i] = nullptr; e->rp_done_valid[i] = 0; e->rp_last_plan[i] = nullptr; }
-    e->rp_mem_bytes = 0;
-    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void**)&e->rp_mem[i], bytes));
-    e->rp_mem_bytes = bytes;
+    // (no device-wide wait: the outgrown sets are retired -- chunks in flight keep reading them -- and new ones allocated beside them)
+    const size_t want = std::max(bytes, e->rp_mem_bytes + e->rp_mem_bytes / 2);
+    void* nw2[2] = {nullptr, nullptr};
+    int ok = hipMalloc(&nw2[0], want) == hipSuccess && hipMalloc(&nw2[1], want) == hipSuccess;
+    size_t got = want;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int i = 0; i < 2; i++) if (nw2[i]) { (void)hipFree(nw2[i]); nw2[i] = nullptr; }
+        if (!engine_make_room(e)) return 0;
+        for (int i = 0; i < 2; i++) { if (e->rp_mem[i]) (void)hipFree(e->rp_mem[i]); e->rp_mem[i] = nullptr; }
+        e->rp_mem_bytes = 0; got = bytes;
+        for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&nw2[i], got));
+    } else for (int i = 0; i < 2; i++) engine_retire_dev(e, e->rp_mem[i], e->rp_mem_bytes);
+    for (int i = 0; i < 2; i++) { e->rp_mem[i] = (unsigned char*)nw2[i]; e->rp_done_valid[i] = 0; e->rp_last_plan[i] = nullptr; }
+    e->rp_mem_bytes = got;
     return 1;
 }
 // Launches the five stages, chunk by chunk (RP_CHUNK proofs), as a two-deep pipeline:
@@ -311,6 +321,7 @@ static int rp_launch(s2k_engine* e, hipStream_t st, int32_t* results, uint64_t* 
     }
     HIPCHK(hipGetLastError());
     gen_cache_collect(e, st);
+    gen_note_read(e, st, gc.valid);              // (an eviction of one of these slots waits for exactly this point of this stream)
     HIPCHK(hipEventRecord(e->ev[1], st));
     return 1;
 }
@@ -359,21 +370,24 @@ struct rp_host_src {
     const void* const* commit_objs; const unsigned char* const* proof_ptrs; const size_t* plens; const unsigned char* const* extra_ptrs; const size_t* elens; const void* const* gen_objs;
 };
 static int engine_stage(s2k_engine* e, s2k_engine::stage_set& S, size_t in_bytes, size_t out_bytes) {
+    // (the staging set belongs to this call alone -- its previous owner handed it back after its copies had completed -- so the old buffers
+    //  are not in use; they are retired rather than freed because hipFree / hipHostFree wait for the whole device)
     if (in_bytes > S.in_bytes || in_bytes + out_bytes + 512 > S.dev_bytes) {
-        HIPCHK(hipDeviceSynchronize());
-        if (S.in) HIPCHK(hipHostFree(S.in));
-        if (S.dev) HIPCHK(hipFree(S.dev));
+        engine_retire_host(e, S.in); engine_retire_dev(e, S.dev, S.dev_bytes);
         S.in = nullptr; S.in_bytes = 0; S.dev = nullptr; S.dev_bytes = 0;
         in_bytes = (in_bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-        HIPCHK(hipHostMalloc((void**)&S.in, in_bytes, hipHostMallocDefault));
-        S.in_bytes = in_bytes;
         const size_t db = in_bytes + ((out_bytes + 65535) & ~size_t(65535)) + 65536;
-        HIPCHK(hipMalloc((void**)&S.dev, db));
-        S.dev_bytes = db;
+        if (hipHostMalloc((void**)&S.in, in_bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&S.dev, db) != hipSuccess) {
+            (void)hipGetLastError();
+            if (S.in) { (void)hipHostFree(S.in); S.in = nullptr; }
+            if (!engine_make_room(e)) return 0;
+            HIPCHK(hipHostMalloc((void**)&S.in, in_bytes, hipHostMallocDefault));
+            HIPCHK(hipMalloc((void**)&S.dev, db));
+        }
+        S.in_bytes = in_bytes; S.dev_bytes = db;
     }
     if (out_bytes > S.out_bytes) {
-        HIPCHK(hipDeviceSynchronize());
-        if (S.out) HIPCHK(hipHostFree(S.out));
+        engine_retire_host(e, S.out);
         S.out = nullptr; S.out_bytes = 0;
         out_bytes = (out_bytes + 65535) & ~size_t(65535);
         HIPCHK(hipHostMalloc((void**)&S.out, out_bytes, hipHostMallocDefault));

@@ -182,3 +182,55 @@ def test_full_size_by_generator_kind(engine, ref, kind):
     assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx)
     bad = set(range(0, n, 41)) | set(range(h + 7, n, 97))
     assert e_res.sum() == n - len(bad)
+
+
+def test_eviction_waits_for_its_readers_not_for_the_device(eng2, ref):
+    """Rebuilding a generator slot used to be hipDeviceSynchronize() under the engine's and the pool's locks: every verifier thread on the GPU
+    stalled for the longest stream in flight.  Now the build's stream waits for the events of the engines that READ that slot and nothing
+    waits on the host: with a second engine's long queue of batches in flight on the very table that is evicted, the evicting call returns
+    at once, the queue keeps running, its verdicts (read from the old table) are right, and the new table serves its own proofs."""
+    import time
+    import torch
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(907)
+    eng_b = Engine(0)
+    try:
+        eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 30)
+        eng2.set_option(Engine.OPT_GEN_CACHE_SLOTS, 2)
+        gx, gy, gz = _gen(ref, rng), _gen(ref, rng), _gen(ref, rng)
+        eng2.cache_generator(gx); eng2.cache_generator(gy)             # both slots taken
+        n = 2048
+        gxy = np.tile(gx, (n, 1)); gxy[1::2] = gy                       # the queue reads BOTH tables: whichever slot is evicted is in use
+        c, p, g, _ = ref.make_rangeproofs(n, rng, min_bits=64, gens64=gxy, threads=8)
+        for i in range(0, n, 97):
+            q = bytearray(p[i]); q[100 + i % 50] ^= 1; p[i] = bytes(q)
+        e_res, e_mn, e_mx = ref.rangeproof_verify_many(c, p, g, threads=8)
+        dev = torch.device("cuda", 0)
+        pdata, poff = Engine.pack(p)
+        d_c = torch.tensor(c).to(dev); d_g = torch.tensor(np.ascontiguousarray(g)).to(dev)
+        d_p = torch.tensor(np.concatenate([pdata, np.zeros(64, np.uint8)])).to(dev); d_off = torch.tensor(poff.astype(np.int64)).to(dev)
+        rounds = 60
+        d_res = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(rounds)]
+        d_mn = torch.zeros(n, dtype=torch.int64, device=dev); d_mx = torch.zeros(n, dtype=torch.int64, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        eng_b.rangeproof_verify_batch_dev(d_res[0], d_mn, d_mx, d_c, d_p, d_off, d_g, n, stream=s.cuda_stream)      # (warm-up: workspace, tables)
+        s.synchronize(); torch.cuda.synchronize()
+        for k in range(rounds):
+            eng_b.rangeproof_verify_batch_dev(d_res[k], d_mn, d_mx, d_c, d_p, d_off, d_g, n, stream=s.cuda_stream)
+        ev = torch.cuda.Event(); ev.record(s)
+        t0 = time.perf_counter()
+        eng2.cache_generator(gz)                                        # evicts one of the two slots: a table eng_b's queue is reading
+        dt = time.perf_counter() - t0
+        still_running = not ev.query()
+        s.synchronize()
+        assert still_running, "the second engine's queue had drained before the eviction returned (%.1f ms)" % (dt * 1e3)
+        assert dt < 0.05, "evicting a slot took %.1f ms on the host with another engine's queue in flight" % (dt * 1e3)
+        for k in range(rounds):
+            assert np.array_equal(d_res[k].cpu().numpy(), e_res), k
+        assert eng2.generator_cached(gz) and eng2.generator_cached(gx) + eng2.generator_cached(gy) == 1
+        c2, p2, g2, _ = ref.make_rangeproofs(64, rng, min_bits=64, gens64=np.tile(gz, (64, 1)), threads=8)
+        _same(eng2, ref, c2, p2, g2)
+        _same(eng_b, ref, c[:64], p[:64], g[:64])                       # gx and gy again, one of them now without a table (general form)
+    finally:
+        eng_b.close()
+        eng2.set_option(Engine.OPT_GEN_CACHE_MIN, 1 << 16)

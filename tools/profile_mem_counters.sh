@@ -1,4 +1,4 @@
-# Memory-side and issue counters of k_rp_rings for both forms of the double multiplication (S2K_RP_SPLIT=0/1): separate rocprofv3
+# Memory-side and issue counters of k_rp_rings for both forms of the double multiplication (bench.py --rp-split 0/1 = S2K_OPT_RP_SPLIT; product builds read no S2K_RP_SPLIT from the environment): separate rocprofv3
 # --pmc passes, kernel-trace only.   usage (GPU box): bash tools/profile_mem_counters.sh <tag>  -> gpurun_out/<tag>/mem_counters.json
 TAG=${1:-r02mem}
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +12,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCC_READ_REQ_LATENCY TCP_TCP_LATENCY TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_TA_TCP_STATE_READ" \
            "TCC_REQ TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_WRREQ_STALL TCC_TAG_STALL TCC_BUSY" ; do
   i=$((i+1))
-  S2K_RP_SPLIT=$SPLIT timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/s${SPLIT}_pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm > /dev/null 2>$O/s${SPLIT}_pmc$i.err
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/s${SPLIT}_pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-secondary --no-dropin --no-group --no-distinct --rp-split $SPLIT > /dev/null 2>$O/s${SPLIT}_pmc$i.err
   tail -1 $O/s${SPLIT}_pmc$i.err
 done
 done
