@@ -48,7 +48,7 @@ int engine_make_room(s2k_engine* e) {
 #define S2K_RETIRED_MAX (size_t(16) << 30)
 int engine_grow_dev(s2k_engine* e, void** buf, size_t* have, size_t need, size_t unit) {
     if (need <= *have) return 1;
-    auto round = [&](size_t b) { return (b + unit) & ~(unit - 1); };
+    auto round = [&](size_t b) { return ((b + unit - 1) / unit) * unit; };          // (`unit` need not be a power of two: the per-lane table arena's is not)
     size_t want = round(std::max(need, *have + *have / 2));
     void* p = nullptr;
     if (e->retired_bytes + *have > S2K_RETIRED_MAX || hipMalloc(&p, want) != hipSuccess) {
