@@ -445,7 +445,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
     for (int i = 0; i < 2; i++) { auto& m = e->msm_slot[i]; m.s = m.s2 = nullptr; m.fork = m.join = m.done = m.in = nullptr; m.ws = nullptr; m.ws_bytes = 0; m.seen_epoch = 0; }
     e->msm_seq = 0; e->cur_pipe = 0; e->ev_last_np = nullptr; e->np_epoch = 0; e->np_valid = 0;
     e->msm_pipeline = 0; e->halfagg_host_chain = 1; e->sync_split = 1; e->stage_log = 0;
-    e->msm_diag = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; e->msm_max_terms_opt = 0;
+    e->msm_diag = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; e->msm_max_terms_opt = 0;
     for (int i = 0; i < 2; i++) { e->rp_mem[i] = nullptr; e->ev_rp_fork[i] = e->ev_rp_join[i] = e->ev_rp_pre[i] = e->ev_rp_done[i] = nullptr; e->rp_done_valid[i] = 0; }
     e->rp_debug = 0;
     for (int i = 0; i < 2; i++) { auto& S = e->stage[i]; S.in = S.out = S.dev = nullptr; S.in_bytes = S.out_bytes = S.dev_bytes = 0; S.ev_h2d = S.ev_out = nullptr; S.used = 0; S.ticket = 0; S.sync_owned = 0; }
@@ -459,7 +459,7 @@ extern "C" s2k_engine* s2k_engine_create(int device) {
         e->msm_diag.c = num("S2K_MSM_C"); e->msm_diag.T = num("S2K_MSM_T"); e->msm_diag.chunk = num("S2K_MSM_CHUNK"); e->msm_diag.T2 = num("S2K_MSM_T2");
         e->msm_diag.two_pass = getenv("S2K_MSM_TWO_PASS") != nullptr; e->msm_diag.one_pass = getenv("S2K_MSM_ONE_PASS") != nullptr;
         e->msm_diag.bin_plain = getenv("S2K_MSM_BIN_PLAIN") != nullptr; e->msm_diag.no_small = getenv("S2K_MSM_NO_SMALL") != nullptr;
-        e->msm_diag.old_tail = getenv("S2K_MSM_OLD_TAIL") != nullptr; e->msm_diag.slice_r = num("S2K_MSM_SLICE_R"); e->msm_diag.slice_lds = num("S2K_MSM_SLICE_LDS"); e->msm_diag.slice_maxc = num("S2K_MSM_SLICE_MAXC"); }
+        e->msm_diag.old_tail = getenv("S2K_MSM_OLD_TAIL") != nullptr; e->msm_diag.slice_r = num("S2K_MSM_SLICE_R"); e->msm_diag.slice_lds = num("S2K_MSM_SLICE_LDS"); e->msm_diag.slice_maxc = num("S2K_MSM_SLICE_MAXC"); e->msm_diag.run_major = num("S2K_MSM_RUN_MAJOR"); }
 #endif
     e->pool = nullptr;
     e->gen_mbox = nullptr; e->gen_mbox_host = nullptr; e->ev_mbox = nullptr; e->mbox_pending = 0;

@@ -123,7 +123,7 @@ struct s2k_engine {
     int sync_split;            // S2K_OPT_SYNC_SPLIT: a lone synchronous host-buffer rangeproof call goes as two halves
     int stage_log;             // diagnostic builds: phase times of a host-buffer call on stderr
     // diagnostic overrides of the MSM launcher (-DS2K_DIAG builds read them from the environment ONCE, at engine creation; 0 = the plan's choice)
-    struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small, T2, old_tail, slice_r, slice_lds, slice_maxc; } msm_diag;
+    struct { int c, T, chunk, two_pass, one_pass, bin_plain, no_small, T2, old_tail, slice_r, slice_lds, slice_maxc, run_major; } msm_diag;
     size_t msm_max_terms_opt;  // S2K_OPT_MSM_MAX_TERMS: sums with more terms go as several launches whose partial sums add (0: the 32-bit reference limit)
     u32* ha_pin; size_t ha_pin_words;    // pinned: the chain states of the half-aggregate randomizer hash, walked on the host (host_sha256.h)
     // Buffers this engine has outgrown.  Growing a buffer never waits for the device (round 6; it used to be hipDeviceSynchronize() + hipFree

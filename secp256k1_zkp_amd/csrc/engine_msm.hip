@@ -420,11 +420,26 @@ __global__ void k_msm_counts(u32* cnt_out, u32* cnt_clamped, const u32* cnt_in, 
 #ifndef MSM_R1_WAVES
 #define MSM_R1_WAVES 2
 #endif
+// RUN_MAJOR (the widest windows, from 2^22 terms): lane m takes run j = m / nk of bucket k = m % nk instead of the m-th run in bucket order.  The
+// binning passes fill a bucket's region roughly in term order (workgroups of consecutive terms reserve their slots as they arrive), so run j
+// of EVERY bucket draws its operands from about the same 1/runs-th of the term records -- and with the lanes of one run index in flight
+// together, the 64-byte operand gathers of the whole machine fall into a window of a few hundred MB that the Infinity Cache holds, where
+// bucket order sprays them over all 2.1 GB of records (2^24 terms) at every moment.  Lanes beyond a bucket's last run leave at once; the
+// partial sums land where bucket order puts them (off_out[k] + j), so the later rounds do not change.
+template <int RUN_MAJOR>
 __global__ void __launch_bounds__(256, MSM_R1_WAVES)
 k_msm_round1(u32* out28, const u32* refs, const u32* off_in, const u32* cnt_in, msm_layout L, msm_plan pl, const u32* off_out, const u32* term, u32 nk, u32 T) {
-    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= off_out[nk]) return;
-    const u32 k = msm_find_key(off_out, nk, m), j = m - off_out[k];
+    const size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 k, j, m;
+    if (RUN_MAJOR) {
+        j = (u32)(m0 / nk); k = (u32)(m0 - (size_t)j * nk);
+        const u32 o = off_out[k];
+        if (j >= off_out[k + 1] - o) return;
+        m = o + j;
+    } else {
+        if (m0 >= off_out[nk]) return;
+        m = (u32)m0; k = msm_find_key(off_out, nk, m); j = m - off_out[k];
+    }
     // bucket k's references: its region of the fixed-capacity layout
     const size_t first = msm_region(L, pl, k / pl.nb, k % pl.nb); (void)off_in;
     const size_t start = first + (size_t)j * T, end = min(start + T, first + cnt_in[k]);
@@ -1016,7 +1031,13 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
         if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3(1), dim3(1024), 0, st, cntA, gclamp, offA, gcnt, nk, T, L, pl);
         else { hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl); launch_scan(st, offA, nullptr, tile_sum, cntA, nk); }
         HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_msm_round1, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
+        // (measured, profiles/r06o_msm_runmajor.txt: 2^22 .. 2^24 terms the same either way -- 20.7 ms at 2^24, so the operand gathers are NOT what
+        //  holds round 1 back there; 2^25 terms, 4.3 GB of records: 42.2 -> 39.4 ms.  Run order from 2^25 terms.)
+        const int run_major = e->msm_diag.run_major ? e->msm_diag.run_major > 0 : (pl.c > 13 && nt >= (size_t(1) << 25));
+        if (run_major) {
+            const size_t lanes = (size_t)nk * ((maxcap + T - 1) / T);
+            hipLaunchKernelGGL(k_msm_round1<1>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
+        } else hipLaunchKernelGGL(k_msm_round1<0>, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
         HIPCHK(hipEventRecord(e->ev[3], st));
         // rounds 2..R: partial sums of partial sums until every bucket holds at most one
         u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
