@@ -262,7 +262,7 @@ __device__ __forceinline__ void msm_scan320(u32* off, const u32* cnt, u32 n) {
 // runs save; one workgroup per window with the ranks kept in registers: 3.27.)
 #define MSM_COARSE_PER_THREAD 2
 #define MSM_COARSE_TERMS (MSM_COARSE_PER_THREAD * MSM_BIN_THREADS)
-#define MSM_COARSE_LDS (9 * 257 + 7)          /* wn * nco: 9 x 257 (c = 16), 9 x 129 (c = 15), 10 x 65 (c = 14) */
+#define MSM_COARSE_LDS (9 * 257 + 7)          /* wn * nco: 9 x 257 (c = 16), 8 x 257 (c = 17), 9 x 129 (c = 15), 10 x 65 (c = 14) */
 __global__ void __launch_bounds__(MSM_BIN_THREADS)
 k_msm_bin_coarse(unsigned long long* __restrict__ pairs, u32* __restrict__ ccnt, u32* __restrict__ flags, const u32* __restrict__ halves, size_t nt,
                  msm_plan pl, msm_layout L, msm_coarse C) {
@@ -334,7 +334,7 @@ k_msm_bin_fine(u32* __restrict__ refs, u32* __restrict__ gcnt, u32* __restrict__
                msm_plan pl, msm_layout L, msm_coarse C) {
     __shared__ u32 stage[MSM_FINE_TILE];
     __shared__ unsigned char stage_f[MSM_FINE_TILE];
-    __shared__ u32 s_cnt[136], s_loff[136], s_tot[136];
+    __shared__ u32 s_cnt[264], s_loff[264], s_tot[264];          // (up to 256 buckets per coarse bin: c = 17)
     const u32 co = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nfine = 1u << C.shift, first = co << C.shift;
     if (tid < nfine) s_tot[tid] = 0;
     const int top = (pl.w0 + w + 1 == pl.windows);
@@ -683,8 +683,15 @@ __device__ __forceinline__ u32 msm_run_count(u32 c, u32 k, u32 T, u32 M, u32 top
 // with a test per entry the kernel was ~1 500 instructions and 130 branches per 2 048 entries, 43 us for 41 000 entries on its one CU.
 typedef unsigned int msm_u4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(1024)
-k_msm_counts_scan(u32* cnt_out, u32* cnt_clamped, u32* off_out, const u32* cnt_in, u32 nk, u32 T, msm_layout L, msm_plan pl) {
+k_msm_counts_scan(u32* cnt_all, u32* cnt_clamped0, u32* off_all, const u32* cnt_in, u32 nk, u32 stride, u32 T, u32 T2, msm_layout L, msm_plan pl) {
+    // workgroup r = partial-sum round r + 1: the run counts of EVERY round follow from the bucket counts alone (round r + 1 sums runs of T2 of
+    // round r's partial sums: ceil(ceil(min(count, capacity) / T) / T2 / ...)), so all the rounds' prefix arrays are made here, side by side,
+    // right behind the binning pass -- a launch per round between the rounds (round 6's first version) left ~10 us + a gap on the critical path each
     __shared__ u32 s_wave[17];
+    const u32 rnd = blockIdx.x;
+    u32* const cnt_out = cnt_all + (size_t)rnd * stride; u32* const off_out = off_all + (size_t)rnd * stride;
+    u32* const cnt_clamped = rnd == 0 ? cnt_clamped0 : nullptr;
+    const u32 M2 = 0xFFFFFFFFu / (T2 > 1u ? T2 : 2u) + 1u;
     const u32 t = threadIdx.x, wave = t >> 6, lane = t & 63u;
     const u32 seg = (((nk + 15u) / 16u) + 255u) & ~255u, lo = wave * seg, hi = min(lo + seg, nk);
     const u32 top_first = (pl.w0 + pl.wn == pl.windows) ? (pl.wn - 1u) * pl.nb : 0xFFFFFFFFu;
@@ -702,14 +709,23 @@ k_msm_counts_scan(u32* cnt_out, u32* cnt_clamped, u32* off_out, const u32* cnt_i
             c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (cnt_clamped) { const u32 kk = k + (u32)q; const u32 cap = kk >= top_first ? ((kk - top_first) < L.top_used ? L.cap_top : 0u) : L.cap; c[q] = c[q] < cap ? c[q] : cap; }
-                r[q] = msm_run_count(c[q], 0u, T, M, 0u, L, nullptr); sum += r[q];
+                { const u32 kk = k + (u32)q; const u32 cap = kk >= top_first ? ((kk - top_first) < L.top_used ? L.cap_top : 0u) : L.cap; c[q] = c[q] < cap ? c[q] : cap; }
+                r[q] = msm_run_count(c[q], 0u, T, M, 0u, L, nullptr);
+                for (u32 i = 0; i < rnd; i++) r[q] = msm_run_count(r[q], 0u, T2, M2, 0u, L, nullptr);
+                sum += r[q];
             }
             if (cnt_clamped) { msm_u4 o; o.x = c[0]; o.y = c[1]; o.z = c[2]; o.w = c[3]; *(msm_u4*)(cnt_clamped + k) = o; }
             msm_u4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3]; *(msm_u4*)(cnt_out + k) = o;
         } else {
 #pragma unroll 1
-            for (int q = 0; q < 4; q++) if (k + q < hi) { const u32 rr = msm_run_count(cnt_in[k + q], k + q, T, M, top_first, L, cnt_clamped); cnt_out[k + q] = rr; sum += rr; }
+            for (int q = 0; q < 4; q++) if (k + q < hi) {
+                const u32 kk = k + (u32)q; const u32 cap = kk >= top_first ? ((kk - top_first) < L.top_used ? L.cap_top : 0u) : L.cap;
+                u32 cc = cnt_in[kk]; cc = cc < cap ? cc : cap;
+                if (cnt_clamped) cnt_clamped[kk] = cc;
+                u32 rr = msm_run_count(cc, 0u, T, M, 0u, L, nullptr);
+                for (u32 i = 0; i < rnd; i++) rr = msm_run_count(rr, 0u, T2, M2, 0u, L, nullptr);
+                cnt_out[kk] = rr; sum += rr;
+            }
         }
     }
 #pragma unroll
@@ -820,7 +836,7 @@ static size_t msm_refs_words(const msm_plan& pl, const msm_layout& L) {
 // sizes), later rounds up to MSM_T2 partial sums -- short, because there are only a few per bucket left and lanes are scarce
 static msm_coarse msm_make_coarse(size_t nt, const msm_plan& pl, const msm_layout& L) {
     msm_coarse C;
-    C.shift = pl.c > 13 ? 7u : (pl.c > 7 ? 6u : 0u);
+    C.shift = pl.c > 16 ? 8u : (pl.c > 13 ? 7u : (pl.c > 7 ? 6u : 0u));
     C.nco = ((pl.nb - 1u) >> C.shift) + 1u;                       // <= 2^(16 - 1 - 7) + 1 = 257
     const double mean = 2.0 * (double)nt / (double)(pl.nb - 1) * (double)(1u << C.shift);
     // the layout's own capacities are per bucket: mean + 10 standard deviations (+ the non-uniform values of the highest windows, see
@@ -852,6 +868,7 @@ static u32 msm_run_len(const s2k_engine* e, size_t E, const msm_plan& pl, const 
 }
 #define MSM_T2 4u                        /* run length of the later rounds: the smallest that the buffer sizes below assume */
 #define MSM_T2_MAX 12u
+#define MSM_MAX_ROUNDS 6u                 /* T >= 8 and T2 = 12 reach any region (< 2^15 references) in 5 */
 // Run length of the later partial-sum rounds.  The NUMBER of rounds follows from the bucket-region capacity (nothing is read back): T, T T2,
 // T T2^2, ... until the fullest region is covered, and a round is two launches (counts + scan, sums) of latency: the fewest rounds that
 // T2 <= 12 allows are taken (2^20 terms: the top window's regions, capacity 2 516, need T2 = 11 for two later rounds).  WITHIN that number
@@ -880,7 +897,7 @@ size_t msm_ws_bytes(const s2k_engine* e, size_t nt, const msm_plan& pl) {
     const size_t nk = (size_t)pl.windows * pl.nb;
     const size_t E = nt * 2 * pl.windows;
     const msm_layout L = msm_make_layout(nt, pl); const size_t T = msm_run_len(e, E, pl, L);
-    return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4,
+    return ws_need({28 * 4, 64, (size_t)MSM_DIRECT_LANES * 28 * 4, 64 * 28 * 4 * 2, nt * MSM_TERM_WORDS * 4, nt * MSM_HALF_WORDS * 4, (nk + 1) * 4 * 7, 1024 * 4, (size_t)MSM_MAX_ROUNDS * (nk + 64) * 4, (size_t)MSM_MAX_ROUNDS * (nk + 64) * 4,
                     msm_refs_words(pl, L) * 4, nk * 28 * 4, msm_pairs_words(e, nt, pl, L) * 8, (size_t)pl.windows * 520 * 4, (nk + E / T + 2) * 28 * 4, (nk * 2 + E / T / MSM_T2 + 64) * 28 * 4,
                     (nk / 1024 + nt / 1024 + pl.windows + 64) * 28 * 4 * 2, msm_slice_words(pl) * 4, (size_t)pl.windows * 28 * 4}) + 32 * 256;
 }
@@ -980,6 +997,7 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
     u32* gcnt = c.take<u32>(nk + 1); u32* gclamp = c.take<u32>(nk + 1); u32* spare = c.take<u32>(nk + 1);
     u32* cntA = c.take<u32>(nk + 1); u32* cntB = c.take<u32>(nk + 1); u32* offA = c.take<u32>(nk + 1); u32* offB = c.take<u32>(nk + 1);
     u32* tile_sum = c.take<u32>(1024); (void)spare;
+    u32* cnt_all = c.take<u32>((size_t)MSM_MAX_ROUNDS * (nk + 64)); u32* off_all = c.take<u32>((size_t)MSM_MAX_ROUNDS * (nk + 64));
     u32* refs_cap = c.take<u32>(msm_refs_words(pl, L)); u32* buckets = c.take<u32>((size_t)nk * 28);
     unsigned long long* pairs = c.take<unsigned long long>(msm_pairs_words(e, nt, pl, L)); u32* ccnt = c.take<u32>((size_t)pl.windows * 520);
     u32* partA = c.take<u32>(bound1 * 28); u32* partB = c.take<u32>(((size_t)nk * 2 + E / T / MSM_T2 + 64) * 28);
@@ -1027,28 +1045,33 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
         const u32 maxcap = std::max(pl.wn > (has_top ? 1u : 0u) ? L.cap : 0u, has_top ? L.cap_top : 0u);
         const u32 T2 = msm_later_run_len(e, T, maxcap);
         int rounds = 1; { size_t reach = T; while (reach < maxcap) { reach *= T2; rounds++; } }
-        // round 1: references -> partial sums (at most T references each)
-        if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3(1), dim3(1024), 0, st, cntA, gclamp, offA, gcnt, nk, T, L, pl);
+        if (rounds > (int)MSM_MAX_ROUNDS) return s2k_fail("s2k_ecmult_multi", "internal: more partial-sum rounds than planned for");
+        // every round's run counts and prefix arrays, in one launch behind the binning pass
+        const u32 stride = (nk + 64u) & ~63u;
+        if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3((unsigned)rounds), dim3(1024), 0, st, cnt_all, gclamp, off_all, (const u32*)gcnt, nk, stride, T, T2, L, pl);
         else { hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cntA, gclamp, gcnt, nk, T, L, pl); launch_scan(st, offA, nullptr, tile_sum, cntA, nk); }
+        u32* const off1 = e->msm_diag.old_tail ? offA : off_all;
+        // round 1: references -> partial sums (at most T references each)
         HIPCHK(hipEventRecord(e->ev[2], st));
+        const int run_major = e->msm_diag.run_major ? e->msm_diag.run_major > 0 : (pl.c > 13 && nt >= (size_t(1) << 25));
         // (measured, profiles/r06o_msm_runmajor.txt: 2^22 .. 2^24 terms the same either way -- 20.7 ms at 2^24, so the operand gathers are NOT what
         //  holds round 1 back there; 2^25 terms, 4.3 GB of records: 42.2 -> 39.4 ms.  Run order from 2^25 terms.)
-        const int run_major = e->msm_diag.run_major ? e->msm_diag.run_major > 0 : (pl.c > 13 && nt >= (size_t(1) << 25));
         if (run_major) {
             const size_t lanes = (size_t)nk * ((maxcap + T - 1) / T);
-            hipLaunchKernelGGL(k_msm_round1<1>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
-        } else hipLaunchKernelGGL(k_msm_round1<0>, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, offA, term, nk, T);
+            hipLaunchKernelGGL(k_msm_round1<1>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, off1, term, nk, T);
+        } else hipLaunchKernelGGL(k_msm_round1<0>, dim3((unsigned)((bound1 + 255) / 256)), dim3(256), 0, st, partA, refs_cap, (const u32*)nullptr, gclamp, L, pl, off1, term, nk, T);
         HIPCHK(hipEventRecord(e->ev[3], st));
         // rounds 2..R: partial sums of partial sums until every bucket holds at most one
-        u32 *cin = cntA, *cout = cntB, *oin = offA, *oout = offB, *pin = partA, *pout = partB;
+        u32 *cin = cntA, *cout = cntB, *oin = off1, *oout = offB, *pin = partA, *pout = partB;
         size_t bound = bound1;
         for (int r = 2; r <= rounds; r++) {
             bound = (size_t)nk + bound / T2 + 2;
-            if (!e->msm_diag.old_tail) hipLaunchKernelGGL(k_msm_counts_scan, dim3(1), dim3(1024), 0, st, cout, (u32*)nullptr, oout, (const u32*)cin, nk, T2, L, pl);
+            if (!e->msm_diag.old_tail) oout = off_all + (size_t)(r - 1) * stride;
             else { hipLaunchKernelGGL(k_msm_counts, dim3(bk), dim3(256), 0, st, cout, (u32*)nullptr, cin, nk, T2, L, pl); launch_scan(st, oout, nullptr, tile_sum, cout, nk); }
             hipLaunchKernelGGL(k_msm_roundN, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pout, pin, oin, oout, nk, T2);
             u32* t;
-            t = cin; cin = cout; cout = t; t = oin; oin = oout; oout = t; t = pin; pin = pout; pout = t;
+            t = cin; cin = cout; cout = t; t = pin; pin = pout; pout = t;
+            if (!e->msm_diag.old_tail) oin = oout; else { t = oin; oin = oout; oout = t; }
         }
         if (new_tail) wsum = launch_window_sums(e, st, q28, wsum_new, pin, oin, pl, L);
         else {

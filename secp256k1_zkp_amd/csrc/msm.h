@@ -103,7 +103,7 @@ static inline msm_plan msm_make_plan(size_t n_terms, int c_override = 0) {
     } else if (lg <= 15) c = 10;
     else if (lg <= 17) c = 12;
     else if (lg >= 22) c = 16;      // 9 windows, the ninth only holds the carries: 8.2 bucket additions per half-scalar instead of 10 (k_msm_bin<1>)
-    if (c_override >= 4 && c_override <= 16) c = c_override;      // diagnostic override (the engine reads $S2K_MSM_C once, in -DS2K_DIAG builds only)
+    if (c_override >= 4 && c_override <= 17) c = c_override;      // diagnostic override (the engine reads $S2K_MSM_C once, in -DS2K_DIAG builds only)
     if (c > 13) {                   // the wide binning pass packs region offsets into 16 bits
         const msm_plan p = msm_plan_for((u32)c); const msm_layout L = msm_make_layout(n_terms, p);
         if (L.cap >= 32768u || L.cap_top >= 32768u) c = 13;

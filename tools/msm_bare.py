@@ -28,4 +28,4 @@ for n in sizes:
     for _ in range(K):
         eng.ecmult_multi_dev(r, ri, scs[:n], pts[:n]); eng.sync()
     tl = (time.perf_counter() - t) / K
-    print("n=%8d  queued %8.3f ms (%8.2f Mterm/s)   single call + wait %8.3f ms   device events %8.3f ms" % (n, tq * 1e3, n / tq / 1e6, tl * 1e3, eng.last_ms(0)))
+    print("n=%8d  queued %8.3f ms (%8.2f Mterm/s)   single call + wait %8.3f ms   device events %8.3f ms   result %s.. inf %d" % (n, tq * 1e3, n / tq / 1e6, tl * 1e3, eng.last_ms(0), bytes(r.cpu().numpy()[:6]).hex(), int(ri.item())))
