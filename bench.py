@@ -724,6 +724,7 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-memory (drop-in path) timing")
     ap.add_argument("--no-group", action="store_true", help="skip the single-process C-ABI engine-group block (rank 0 over all the run's GPUs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 1, 2 and 4 (bench_ecmult 1024 pairs, BIP-340 2^16, BP++ norm argument 2^12)")
+    ap.add_argument("--no-widths", action="store_true", help="skip the headline at 24- and 20-bit fixed-base tables")
     ap.add_argument("--no-next", action="store_true", help="skip the SURVEY 8(f) rows (surjection, half-aggregate, tallies, rewind, bppp_commit, batched small sums)")
     ap.add_argument("--rp-split", type=int, choices=(0, 1), default=None, help="S2K_OPT_RP_SPLIT of the engine (A/B of the two forms of the ring kernel's double multiplication: tools/profile_mem_counters.sh)")
     args = ap.parse_args()
@@ -1058,6 +1059,25 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # The headline at narrower fixed-base tables (S2K_OPT_GTAB_BITS: 24 bits = 5.9 GB per table, 20 bits = 0.44 GB, against 21.5 GB at the default
+    # 26): the same timed loop after the device's tables have been given back and rebuilt at that width -- what an engine on a partitioned or
+    # shared GPU gets.  Verdicts are checked again; the default width is restored afterwards.
+    width_values = None
+    if rank == 0 and world == 1 and not args.no_widths:
+        width_values = {}
+        try:
+            for bits in (24, 20):
+                eng.set_option(Engine.OPT_GTAB_BITS, bits)
+                d_res.zero_()
+                dtw, kw = timed(args.steps, pipeline)
+                assert bool(d_res.all().item()) and int(eng._lib.s2k_engine_gtable_bits(eng._h)) == bits, "verdicts or table width wrong at %d-bit tables" % bits
+                width_values[bits] = {"value": n * args.steps / dtw, "ms_per_step": dtw / args.steps * 1e3, "ring_kernel_ms": float(np.mean(kw)),
+                                      "table_gb_each": ((((256 + bits - 1) // bits) << (bits - 1)) + 1) * 64 / 1e9, "verified": True}
+        except Exception as ex:      # noqa: BLE001  (the headline must not be lost to a failure of this extra block)
+            width_values["error"] = repr(ex)
+        finally:
+            eng.set_option(Engine.OPT_GTAB_BITS, 26); eng.set_option(Engine.OPT_RP_INPUTS_READY, 0)
+
     if rank == 0:
         value = world * n * args.steps / dt
         kms = float(np.mean(kern_ms))
@@ -1111,6 +1131,9 @@ def main():
             "verified": ref is not None,
             "value_serialized_calls": world * n * ser_steps / dt_ser, "ms_per_step_serialized_calls": dt_ser / ser_steps * 1e3,
             "value_distinct_generators": distinct["value"] if distinct else None,
+            "value_gtab_bits_24": width_values.get(24, {}).get("value") if width_values else None,
+            "value_gtab_bits_20": width_values.get(20, {}).get("value") if width_values else None,
+            "table_widths": width_values,
             "ms_per_step_distinct_generators": distinct["ms_per_step"] if distinct else None,
             "generators": "value: secp256k1_generator_h for every proof (src/bench_rangeproof.c), fixed-base table of that generator cached by the engine; "
                           "value_distinct_generators: the same batch size, every proof its own random generator (no table applies: general form of the rings kernel)",

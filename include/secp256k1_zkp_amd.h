@@ -74,6 +74,10 @@ S2K_API void s2k_clear_status(void);
  *   s2k_ecmult_multi_partial_dev run a sum with more terms than this as consecutive launches over slices of the term arrays and add the
  *   partial sums -- the reference's own treatment of a sum that exceeds its scratch space (src/ecmult_impl.h:804-820, :856-865).  The
  *   result does not depend on the value; tests lower it to walk the loop at small sizes.
+ * S2K_OPT_GTAB_BITS (20, 22, 24 or 26; default 26, $S2K_GTAB_BITS): digit width of the device's fixed-base tables (G and the rangeproof generator
+ *   slots: 0.44 / 1.6 / 5.9 / 21.5 GB each, one more addition per fixed-base multiplication for every step down).  Changing it gives the device's
+ *   tables back (after a device-wide wait: an administrative call) and the next call that needs one builds it at the new width; a width that
+ *   does not fit still falls back to the next narrower one.  Results do not depend on it.
  * Environment: only start-up defaults are read from it, once, when an engine (or the device's table pool) is created: S2K_DEVICE,
  * S2K_GEN_CACHE, S2K_GEN_CACHE_MIN, S2K_STAGE_THREADS, S2K_GTAB_BITS.  Nothing on a call path reads the environment. */
 #define S2K_OPT_RP_INPUTS_READY 1
@@ -86,6 +90,7 @@ S2K_API void s2k_clear_status(void);
 #define S2K_OPT_HALFAGG_HOST_CHAIN 8
 #define S2K_OPT_SYNC_SPLIT 9
 #define S2K_OPT_MSM_MAX_TERMS 10
+#define S2K_OPT_GTAB_BITS 11
 S2K_API int s2k_engine_set_option(s2k_engine* e, int option, long value);
 /* Rangeproof generator tables.  The four public keys of a Borromean ring differ by multiples of the proof's generator
  * (secp256k1_rangeproof_pub_expand, src/modules/rangeproof/rangeproof_impl.h:19-51), so when the engine holds a fixed-base table of that

@@ -85,6 +85,7 @@ class Engine:
     OPT_HALFAGG_HOST_CHAIN = 8
     OPT_SYNC_SPLIT = 9
     OPT_MSM_MAX_TERMS = 10
+    OPT_GTAB_BITS = 11
 
     def cache_generator(self, gen64):
         """Build the fixed-base table of one rangeproof generator now (s2k_engine_cache_generator)."""

@@ -862,6 +862,22 @@ extern "C" int s2k_engine_set_option(s2k_engine* e, int option, long value) {
         }
         p->gen_slots = v; return 1;
     }
+    case S2K_OPT_GTAB_BITS: {                                   // (the tables belong to the device: every engine on it sees the change)
+        if (!(value == 20 || value == 22 || value == 24 || value == 26) || !gtab_bits_ok((u32)value)) return s2k_fail_arg("s2k_engine_set_option", "S2K_OPT_GTAB_BITS: 20, 22, 24 or 26");
+        s2k_dev_pool* p = e->pool;
+        std::lock_guard<std::recursive_mutex> pool_lock(p->mu);
+        if (p->gtab_bits_wanted == (u32)value && (p->gtab_state == 0 || p->gtab_bits == (u32)value)) return 1;
+        // an administrative call: the device's tables are given back and rebuilt at the new width by the next call that needs them; nothing
+        // of ANY engine on the device may still read them
+        if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return s2k_fail("s2k_engine_set_option", "device synchronisation failed");
+        int had_h = 0;
+        for (int i = 0; i < p->gen_slots; i++) if (p->gen[i].valid && !memcmp(p->gen[i].key, k_generator_h, 64)) had_h = 1;
+        p->gtab_bits_wanted = (u32)value;
+        pool_free_tables(p);
+        if (had_h && p->gen_h == 2) p->gen_h = 1;            // (secp256k1_generator_h gets its table again at the next rangeproof call)
+        e->gtab = nullptr;
+        return 1;
+    }
     case S2K_OPT_GEN_CACHE_MIN: { std::lock_guard<std::recursive_mutex> pool_lock(e->pool->mu); e->pool->gen_min = value < 1 ? 1 : (size_t)value; return 1; }
     default: return s2k_fail_arg("s2k_engine_set_option", "unknown option");
     }

@@ -120,3 +120,28 @@ def test_width_follows_the_memory_that_is_there(engine):
     j = _child({"S2K_LEAVE_GB": "9", "S2K_N": "2048"})
     assert 20 <= j["bits"] < 26 and j["table_bytes"] < 9 * 2**30
     print("\nunder a 9 GB cap: %s" % j)
+
+
+def test_width_changed_at_run_time(engine, ref):
+    """S2K_OPT_GTAB_BITS: the device's tables are given back and rebuilt at another width by the next call; every result stays the reference's
+    (rangeproofs on the shared-generator form, single multiplications through the table of G), whatever the width and in whatever order."""
+    import numpy as np
+    from secp256k1_zkp_amd import Engine
+    from tests.refapi import G_XY
+    rng = np.random.default_rng(2611)
+    c, p, g, _ = ref.make_rangeproofs(96, rng, min_bits=64)
+    q = bytearray(p[5]); q[300] ^= 2; p[5] = bytes(q)
+    e_res, e_mn, e_mx = ref.rangeproof_verify_many(c, p, g, threads=8)
+    k = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    gpts = np.frombuffer(G_XY * 64, np.uint8).reshape(64, 64)
+    w_xy, w_inf = ref.ecmult_batch(gpts, np.zeros((64, 32), np.uint8), ng=k, a_inf=np.ones(64, np.uint8))
+    try:
+        for bits in (24, 20, 26, 22):
+            engine.set_option(Engine.OPT_GTAB_BITS, bits)
+            res, mn, mx = engine.rangeproof_verify_batch(c, p, g)
+            assert int(engine._lib.s2k_engine_gtable_bits(engine._h)) == bits
+            assert np.array_equal(res, e_res) and np.array_equal(mn, e_mn) and np.array_equal(mx, e_mx), bits
+            xy, inf = engine.ecmult_batch(gpts, np.zeros((64, 32), np.uint8), ng=k, a_inf=np.ones(64, np.uint8))
+            assert np.array_equal(xy, w_xy) and not inf.any(), bits
+    finally:
+        engine.set_option(Engine.OPT_GTAB_BITS, 26)
