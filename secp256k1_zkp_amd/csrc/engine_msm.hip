@@ -808,6 +808,23 @@ k_msm_direct(u32* out28, const u32* gate, const unsigned char* g_sc, const unsig
     }
     gej_store28(out28 + lane * 28, acc);
 }
+// a handful of Jacobian records (the exchanged partials of one sharded sum: 112 bytes per GPU) -> their affine sum, in ONE launch of one
+// wavefront: cooperative additions (~3 us each; a 64-lane tree of complete per-lane additions + a separate inversion launch was ~115 us)
+__global__ void __launch_bounds__(64)
+k_gej_sum_small(unsigned char* r_xy, int32_t* r_inf, const u32* in28, u32 count) {
+    if (blockIdx.x) return;
+    cgej acc; int acc_inf = 1; acc.x.v = acc.y.v = acc.z.v = 0;
+    cgej nx; int nxi = count ? cgej_load28(nx, in28) : 1;
+    for (u32 i = 0; i < count; i++) {
+        const cgej v = nx; const int vi = nxi;
+        if (i + 1 < count) nxi = cgej_load28(nx, in28 + (size_t)(i + 1) * 28);
+        cgej_acc(acc, acc_inf, v, vi);
+    }
+    gej r; if (acc_inf) gej_set_infinity(r); else cgej_to_gej(r, acc);
+    if (threadIdx.x) return;
+    if (r.inf) { for (int k = 0; k < 64; k++) r_xy[k] = 0; } else { ge a; ge_set_gej(a, r); ge_store_b64(r_xy, a); }
+    *r_inf = r.inf;
+}
 __global__ void k_gej_finish(unsigned char* r_xy, int32_t* r_inf, const u32* in28) {
     if (threadIdx.x || blockIdx.x) return;
     gej r; gej_load28(r, in28);
@@ -1211,6 +1228,11 @@ extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy,
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
+    if (count <= 64) {             // the partials of a node's GPUs: one wavefront adds them up in the cooperative arithmetic and publishes the affine sum
+        hipLaunchKernelGGL(k_gej_sum_small, dim3(1), dim3(64), 0, st, r_xy, r_inf, (const u32*)gej28, (u32)count);
+        HIPCHK(hipGetLastError());
+        return 1;
+    }
     if (!engine_workspace(e, ws_need({(count / 1024 + 64) * 28 * 4, (count / 1024 + 64) * 28 * 4}))) return 0;
     ws_carver c{e->ws, 0};
     u32* bufA = c.take<u32>((count / 1024 + 64) * 28); u32* bufB = c.take<u32>((count / 1024 + 64) * 28);
