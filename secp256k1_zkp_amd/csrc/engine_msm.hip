@@ -926,7 +926,7 @@ static void launch_scan(hipStream_t st, u32* off, u32* cur, u32* tile_sum, const
 // core: leaves the Jacobian result (28 words) at *result28 (device).  Workspace must already be large enough.
 // Fully stream-ordered: nothing is read back.  The number of partial-sum rounds follows from the bucket-region capacity (a
 // bucket never holds more than its region), and an input that overflows a region (adversarially equal scalars) raises a
-// device flag that un-gates the exact bucket-free path queued behind the bucket pipeline; k_msm_pick then publishes its
+// device flag that un-gates the exact bucket-free path queued behind the bucket pipeline; k_msm_combine then publishes its
 // result instead.  (part, parts): the share of the digit windows this launch owns (msm_plan_share) -- (0, 1) = all of them.
 __global__ void k_set_word(u32* p, u32 v) { *p = v; }
 void launch_set_word(hipStream_t st, u32* p, u32 v) { hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, st, p, v); }

@@ -16,16 +16,19 @@
 //   msm_roundN   1 lane / <=T part.: the same on the partial sums, repeated until every bucket has at most one -- bucket
 //                                  sizes are data dependent (the top window of a 129-bit half only has 2-3 live bits, and
 //                                  equal scalars put every point in one bucket), so no lane ever owns a whole bucket
-//   msm_finish   1 lane / bucket : the bucket's own weight  b * B_b  by a short double-and-add (replaces the reference's
-//                                  serial running sum :581-588, which has no parallelism inside a window)
-//   gej_reduce   tree sums       : per-window totals S_w
-//   msm_combine  1 wavefront     : Horner over windows  r = sum_w 2^(c w) S_w   (c*W ~ 136 doublings, wave-cooperative: cofield.h)
+//   window sums                  : the reference's running sum (:581-588) has no parallelism inside a window.  Up to c = 13 the bucket
+//                                  weights are taken apart into bits,  sum_b b B_b = sum_j 2^j (sum of the buckets whose weight has bit j),
+//                                  as masked trees + a wavefront per bit in the wave-cooperative arithmetic (engine_msm.hip: k_msm_slices,
+//                                  k_msm_window_sums; round 6); the widest plans keep a double-and-add by the weight per bucket (msm_scale)
+//                                  and segmented trees (k_msm_finish, k_gej_reduce)
+//   msm_combine  1 wavefront     : Horner over windows  r = sum_w 2^(c w) S_w   (c*W ~ 136 doublings, wave-cooperative: cofield.h), then the
+//                                  affine result from the same launch
 //
 // Any order of additions gives the same group element, so the atomics-driven bucket order does not affect the
 // (bit-exact) serialised result.  Very small inputs (n < MSM_SMALL_N) skip the bucket machinery: one full
 // double multiplication per lane (ecmult.h) and a tree sum -- the analogue of the reference switching to Strauss below 88
 // points (:55, :848-855).  The switch sits much lower here (32): one double multiplication is ~0.6 ms of latency on a single
-// wavefront, more than the whole bucket pipeline's ~0.8 ms floor leaves over (measured: profiles/r02x_msm_sweep.txt).
+// wavefront, more than the whole bucket pipeline's floor (0.4 ms since round 6) leaves over.
 #pragma once
 #include "gtable.h"
 #include "cofield.h"

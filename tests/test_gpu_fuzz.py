@@ -22,7 +22,7 @@ def test_bounded_differential_fuzz(engine, ref, seed):
         assert r.returncode == 0, r.stderr[-2000:]
         out += r.stdout
     lines = [l for l in out.splitlines() if "mismatches" in l]
-    assert len(lines) >= 9 and any("crafted" in l for l in lines), out
+    assert len(lines) >= 11 and any("crafted" in l for l in lines) and any("many sums" in l for l in lines), out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "fuzz_tally.txt"), "a") as f:
         f.write("seed %d\n" % seed + "\n".join(lines) + "\n")

@@ -142,6 +142,40 @@ def more(seed, n):
         r_xy, r_inf = eng.ecmult_multi(sc, sel, g, None)
         bad += int(e_inf != r_inf or not np.array_equal(e_xy, r_xy))
     print("msm with colliding points: mismatches:", bad)
+    # K independent sums in one call (s2k_ecmult_multi_many): ragged sizes, colliding points, zero scalars, infinite points, with and without G terms --
+    # every sum against the reference's single call; and single sums cut into several launches (S2K_OPT_MSM_MAX_TERMS lowered)
+    bad = 0; nsums = 0
+    for rep in range(3):
+        K = int(rng.integers(1, 48))
+        sizes = [int(x) for x in rng.choice([0, 1, 2, 7, 31, 32, 33, 87, 88, 89, 300, 1000, 2500], K)]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64); m = int(off[-1])
+        fresh = np.stack([np.frombuffer(ref.rand_point(rng), np.uint8) for _ in range(24)])
+        sel = np.concatenate([pool, fresh])[rng.integers(0, 30, max(m, 1))][:m]
+        sc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        if m:
+            sc[rng.integers(0, m, m // 8 + 1)] = sc[0]
+            sc[rng.integers(0, m, m // 16 + 1)] = 0
+        inf = (rng.integers(0, 20, m) == 0).astype(np.uint8)
+        gs = rng.integers(0, 256, (K, 32), dtype=np.uint8) if rep != 1 else None
+        r_xy, r_inf = eng.ecmult_multi_many(sc, sel, off, gs, inf)
+        for s_ in range(K):
+            lo, hi = int(off[s_]), int(off[s_ + 1])
+            e_xy, e_inf = ref.ecmult_multi(sc[lo:hi], sel[lo:hi], None if gs is None else bytes(gs[s_]), inf[lo:hi])
+            bad += int(e_inf != int(r_inf[s_]) or not np.array_equal(e_xy, r_xy[s_])); nsums += 1
+    print("many sums in one call: %d sums, mismatches: %d" % (nsums, bad))
+    bad = 0
+    for m, cap in ((5000, 700), (40000, 9973)):
+        sel = np.concatenate([pool, fresh])[rng.integers(0, 30, m)]
+        sc = rng.integers(0, 256, (m, 32), dtype=np.uint8); sc[rng.integers(0, m, m // 8)] = sc[0]
+        g = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        e_xy, e_inf = ref.ecmult_multi(sc, sel, g, None)
+        eng.set_option(10, cap)                                      # S2K_OPT_MSM_MAX_TERMS
+        try:
+            r_xy, r_inf = eng.ecmult_multi(sc, sel, g, None)
+        finally:
+            eng.set_option(10, 0)
+        bad += int(e_inf != r_inf or not np.array_equal(e_xy, r_xy))
+    print("sums cut into several launches: mismatches:", bad)
     # rewind
     C, PR, G, NN = [], [], [], []
     for kw in (dict(msg_len=100, min_bits=64), dict(msg_len=0, min_bits=0, exp=-1, values=rng.integers(0, 2**50, n // 8, dtype=np.uint64)), dict(msg_len=33, min_bits=9, exp=1, min_value=3),
