@@ -12,8 +12,12 @@ k_msm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned cha
     for (size_t z = i; z < words_b; z += (size_t)gridDim.x * blockDim.x) zero_b[z] = 0u;
     if (i >= nt) return;
     const int isg = (i == n);       // only when g_sc != NULL (nt == n + 1)
-    msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, isg ? g_sc : sc + 32 * i, isg ? sc : pt + 64 * i,
-                  isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg);
+    const unsigned char* ks = isg ? g_sc : sc + 32 * i;
+    const int pinf = isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0);
+    // (the caller's arrays are plain byte arrays: the vector loads only when all three happen to be 16-byte aligned -- they are for every
+    //  allocation of their own -- and then for every lane alike)
+    if (((((size_t)sc) | ((size_t)pt) | ((size_t)g_sc)) & 15u) == 0u) msm_prep_term_aligned(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, ks, isg ? sc : pt + 64 * i, pinf, isg);
+    else msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, ks, isg ? sc : pt + 64 * i, pinf, isg);
 }
 // Binning: workgroup (chunk, window).  One sweep over the chunk's half-scalar records: the LDS histogram gives every digit its
 // rank inside the workgroup, one global atomic per non-empty bucket reserves the workgroup's slots, then the references are

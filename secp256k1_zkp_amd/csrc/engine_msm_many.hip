@@ -52,8 +52,10 @@ k_mm_prep(u32* term, u32* halves, const unsigned char* g_sc, const unsigned char
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)P.n_terms + (P.has_g ? (size_t)P.n_sums : 0);
     if (i >= nt) return;
     const int isg = i >= P.n_terms;
-    msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, isg ? g_sc + 32 * (i - P.n_terms) : sc + 32 * i, isg ? sc : pt + 64 * i,
-                  isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0), isg);
+    const unsigned char* ks = isg ? g_sc + 32 * (i - P.n_terms) : sc + 32 * i;
+    const int pinf = isg ? 0 : (pt_inf ? pt_inf[i] != 0 : 0);
+    if (((((size_t)sc) | ((size_t)pt) | ((size_t)g_sc)) & 15u) == 0u) msm_prep_term_aligned(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, ks, isg ? sc : pt + 64 * i, pinf, isg);
+    else msm_prep_term(term + i * MSM_TERM_WORDS, halves + i * MSM_HALF_WORDS, ks, isg ? sc : pt + 64 * i, pinf, isg);
 }
 // bucket of digit magnitude v (>= 1) of term j in window w.  (v <= top_vals in the top window: both halves are below 2^128,
 // scalar_impl.h:183-285; the clamp only keeps an impossible value inside the bucket array)

@@ -44,7 +44,17 @@
 S2K_HD void msm_store_term(u32* term, const ge& P, const fe& bx_in) {          // P.x, P.y, beta*x: any magnitude <= 2
     fe x = P.x, y = P.y, bx = bx_in; fe_normalize(x); fe_normalize(y); fe_normalize(bx);
     u32 wx[8], wy[8], wb[8]; fe_to_words(wx, x); fe_to_words(wy, y); fe_to_words(wb, bx);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (records are 128-byte aligned: eight 16-byte stores instead of 32 lone words -- one L2 request per quarter sector, round 6)
+    typedef unsigned int msm_st4 __attribute__((ext_vector_type(4)));
+    msm_st4* q = (msm_st4*)term;
+    msm_st4 v;
+    v.x = wx[0]; v.y = wx[1]; v.z = wx[2]; v.w = wx[3]; q[0] = v;  v.x = wx[4]; v.y = wx[5]; v.z = wx[6]; v.w = wx[7]; q[1] = v;
+    v.x = wy[0]; v.y = wy[1]; v.z = wy[2]; v.w = wy[3]; q[2] = v; q[6] = v;  v.x = wy[4]; v.y = wy[5]; v.z = wy[6]; v.w = wy[7]; q[3] = v; q[7] = v;
+    v.x = wb[0]; v.y = wb[1]; v.z = wb[2]; v.w = wb[3]; q[4] = v;  v.x = wb[4]; v.y = wb[5]; v.z = wb[6]; v.w = wb[7]; q[5] = v;
+#else
     for (int i = 0; i < 8; i++) { term[i] = wx[i]; term[8 + i] = wy[i]; term[16 + i] = wb[i]; term[24 + i] = wy[i]; }
+#endif
 }
 
 // nb = buckets per window = 2^(c-1) + 1 (bucket 0 unused).  [w0, w0 + wn) is the range of digit windows this launch owns:
@@ -184,22 +194,61 @@ S2K_HD int msm_digit_full(const msm_sfull& sf, u32 w, u32 c, u32 windows) {
 }
 // half-scalar record of a term: k1 magnitude [5], k2 magnitude [5], flags (bit0 k1 negative, bit1 k2 negative, bit2 active), pad
 #define MSM_HALF_WORDS 12
-// byte decode + GLV split of one term (no digits): term record as below, half-scalar record as above
-S2K_HD void msm_prep_term(u32* term, u32* halves, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g) {
-    scalar k; sc_set_b32(k, sc32, nullptr);
-    ge P;
+// GLV split of one term (no digits): term record as below, half-scalar record as above.  k: the scalar, reduced; P: the point (limbs, weakly
+// normalised; ignored for the G term)
+S2K_HD void msm_prep_term_kp(u32* term, u32* halves, const scalar& k, ge P, int pt_inf, int is_g) {
     if (is_g) ge_set_generator(P);
-    else { fe_set_b32_mod(P.x, pt64); fe_set_b32_mod(P.y, pt64 + 32); fe_norm_weak(P.x); fe_norm_weak(P.y); }
     const int active = (!pt_inf) & (!sc_is_zero(k));
     fe beta, bx; fe_set_beta(beta); fe_mul(bx, P.x, beta);
     msm_store_term(term, P, bx);
     scalar k1s, k2s; half_scalar h0, h1;
     sc_split_lambda(k1s, k2s, k);
     sc_to_half(h0, k1s); sc_to_half(h1, k2s);
+    const u32 fl = (u32)h0.neg | ((u32)h1.neg << 1) | ((u32)active << 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int msm_st4 __attribute__((ext_vector_type(4)));
+    msm_st4* q = (msm_st4*)halves;                                  // (48-byte records: 16-byte aligned)
+    msm_st4 v;
+    v.x = h0.w[0]; v.y = h0.w[1]; v.z = h0.w[2]; v.w = h0.w[3]; q[0] = v;
+    v.x = h0.w[4]; v.y = h1.w[0]; v.z = h1.w[1]; v.w = h1.w[2]; q[1] = v;
+    v.x = h1.w[3]; v.y = h1.w[4]; v.z = fl; v.w = 0u; q[2] = v;
+#else
     for (int i = 0; i < 5; i++) { halves[i] = h0.w[i]; halves[5 + i] = h1.w[i]; }
-    halves[10] = (u32)h0.neg | ((u32)h1.neg << 1) | ((u32)active << 2);
+    halves[10] = fl;
     halves[11] = 0;
+#endif
 }
+// byte decode + the above
+S2K_HD void msm_prep_term(u32* term, u32* halves, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g) {
+    scalar k; sc_set_b32(k, sc32, nullptr);
+    ge P;
+    if (is_g) ge_set_generator(P);
+    else { fe_set_b32_mod(P.x, pt64); fe_set_b32_mod(P.y, pt64 + 32); fe_norm_weak(P.x); fe_norm_weak(P.y); }
+    msm_prep_term_kp(term, halves, k, P, pt_inf, is_g);
+}
+#if defined(__HIPCC__)
+// the same from 16-byte aligned inputs: two + four vector loads and byte swaps instead of 96 byte loads per term (round 6: the decode kernel
+// was 100 us per 2^20 terms, most of it waiting for byte loads and lone word stores)
+S2K_D void msm_prep_term_aligned(u32* term, u32* halves, const unsigned char* sc32, const unsigned char* pt64, int pt_inf, int is_g) {
+    typedef unsigned int msm_ld4 __attribute__((ext_vector_type(4)));
+    scalar k; ge P;
+    {   const msm_ld4* q = (const msm_ld4*)sc32; const msm_ld4 a = q[0], b = q[1];
+        const u32 be[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) k.d[i] = __builtin_bswap32(be[7 - i]);
+        const int o = sc_check_overflow(k.d); sc_reduce_once(k.d, o); }
+    if (is_g) ge_set_generator(P);
+    else {
+        const msm_ld4* q = (const msm_ld4*)pt64; const msm_ld4 a = q[0], b = q[1], c = q[2], d = q[3];
+        const u32 xb[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, yb[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        u32 xw[8], yw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xw[i] = __builtin_bswap32(xb[7 - i]); yw[i] = __builtin_bswap32(yb[7 - i]); }
+        fe_from_words(P.x, xw); fe_from_words(P.y, yw); fe_norm_weak(P.x); fe_norm_weak(P.y);
+    }
+    msm_prep_term_kp(term, halves, k, P, pt_inf, is_g);
+}
+#endif
 // bucket key of (half-scalar record, half, window): (w*nb + |d|) << 1 | sign, 0 = no contribution
 S2K_HD u32 msm_key_at(const u32* halves, int half, u32 w, const msm_wconst& wc, const msm_plan& pl) {
     const u32 fl = halves[10];

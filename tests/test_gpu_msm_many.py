@@ -175,3 +175,27 @@ def test_sum_of_2p28_terms(engine):
     engine.sync()
     exp, einf = engine.ecmult_batch(np.frombuffer(G_XY, np.uint8).reshape(1, 64), np.zeros((1, 32), np.uint8), np.frombuffer(total.to_bytes(32, "big"), np.uint8).reshape(1, 32))
     assert int(ri.cpu()[0]) == int(einf[0]) == 0 and np.array_equal(r.cpu().numpy(), exp[0])
+
+
+def test_unaligned_device_arrays(engine, ref):
+    """the caller's arrays are plain byte arrays: at odd addresses the decode takes its byte-wise form, at 16-byte aligned ones the vector form --
+    same results (single sum and many sums)."""
+    import torch
+    rng = np.random.default_rng(31)
+    n = 700
+    pts = _points(engine, rng, n); sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); g = rng.integers(0, 256, 32, dtype=np.uint8)
+    exp, einf = ref.ecmult_multi(sc, pts, bytes(g), None)
+    for shift in (0, 1, 7):
+        buf_s = torch.zeros(32 * n + 64, dtype=torch.uint8, device="cuda"); buf_p = torch.zeros(64 * n + 64, dtype=torch.uint8, device="cuda"); buf_g = torch.zeros(96, dtype=torch.uint8, device="cuda")
+        d_s = buf_s[shift:shift + 32 * n]; d_p = buf_p[shift:shift + 64 * n]; d_g = buf_g[shift:shift + 32]
+        d_s.copy_(torch.tensor(sc.reshape(-1))); d_p.copy_(torch.tensor(pts.reshape(-1))); d_g.copy_(torch.tensor(g))
+        r = torch.zeros(64, dtype=torch.uint8, device="cuda"); ri = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        engine.ecmult_multi_dev(r, ri, d_s, d_p, d_g); engine.sync()
+        assert int(ri.item()) == einf and np.array_equal(r.cpu().numpy(), exp), shift
+        off = np.array([0, 300, 700], np.uint64)
+        r2 = torch.zeros(2, 64, dtype=torch.uint8, device="cuda"); ri2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+        engine.ecmult_multi_many_dev(r2, ri2, d_s, d_p, off); engine.sync()
+        for s_, (lo, hi) in enumerate(((0, 300), (300, 700))):
+            e2, i2 = ref.ecmult_multi(sc[lo:hi], pts[lo:hi], None, None)
+            assert int(ri2[s_].item()) == i2 and np.array_equal(r2[s_].cpu().numpy(), e2), (shift, s_)
