@@ -10,14 +10,14 @@ mkdir -p $O
 # (the counter and stats passes time the shared-generator batch only: --no-distinct, --no-dropin; S2K_BENCH_PIPELINE=0 keeps one call in flight,
 #  so that a kernel's duration is its own)
 export S2K_BENCH_PIPELINE=0
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-distinct --no-dropin --no-msm-big --no-group --no-secondary > $O/bench_under_rocprof.json 2>$O/stats.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary > /dev/null 2>$O/fetch.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary > /dev/null 2>$O/write.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-distinct --no-dropin --no-msm-big --no-group --no-secondary --no-widths > $O/bench_under_rocprof.json 2>$O/stats.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary --no-widths > /dev/null 2>$O/fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary --no-widths > /dev/null 2>$O/write.err
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_FLAT" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/sq$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary > /dev/null 2>$O/sq$i.err
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/sq$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary --no-widths > /dev/null 2>$O/sq$i.err
 done
 unset S2K_BENCH_PIPELINE
 cd $R
@@ -68,7 +68,7 @@ timeout 300 python tests/tools/msm_sweep.py > gpurun_out/$TAG/msm_sweep.txt 2>&1
 # board power and shader clock under the sustained workload (sampled next to a separate 60-step run, never next to the bench line above)
 (set +x; while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed -e 's/=//g' | tr "\n" " "; echo; sleep 0.25; done) > gpurun_out/$TAG/power_clock.txt 2>&1 &
 SMI=$!
-timeout 300 python bench.py --steps 200 --warmup 2 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary > gpurun_out/$TAG/bench_200_steps_with_smi_sampling.json 2>/dev/null
+timeout 300 python bench.py --steps 200 --warmup 2 --no-cpu-baseline --no-msm --no-distinct --no-dropin --no-group --no-secondary --no-widths > gpurun_out/$TAG/bench_200_steps_with_smi_sampling.json 2>/dev/null
 kill $SMI
 grep -c "W" gpurun_out/$TAG/power_clock.txt; sort -t: -k5 gpurun_out/$TAG/power_clock.txt | tail -3
 # the MSM alone: through the device entry point at a range of sizes, and its per-kernel times at 1 024, 2^20 and 2^24 terms
