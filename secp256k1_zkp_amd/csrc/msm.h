@@ -111,7 +111,9 @@ static inline msm_plan msm_make_plan(size_t n_terms, int c_override = 0) {
     u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n_terms) lg++;
     int c = (int)lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
     if (lg <= 13) {
-        c = 13;
+        // (no width of the one-round kind: measured, profiles/r06v_msm_small_plans.txt -- 13 bits, the fallback until round 6, cost 0.50-0.52 ms from
+        //  3 000 to 12 000 terms where 11 / 12 / 10 bits take 0.45-0.50)
+        c = lg <= 11 ? 11 : (lg == 12 ? 12 : 10);
         for (int t = 7; t <= 13; t++) { const msm_plan p = msm_plan_for((u32)t); if (msm_max_cap(p, msm_make_layout(n_terms, p)) <= MSM_ONE_ROUND_CAP) { c = t; break; } }
     } else if (lg <= 15) c = 10;
     else if (lg <= 17) c = 12;

@@ -207,3 +207,35 @@ def test_unaligned_device_arrays(engine, ref):
         for s_, (lo, hi) in enumerate(((0, 300), (300, 700))):
             e2, i2 = ref.ecmult_multi(sc[lo:hi], pts[lo:hi], None, None)
             assert int(ri2[s_].item()) == i2 and np.array_equal(r2[s_].cpu().numpy(), e2), (shift, s_)
+
+
+def test_many_edges(engine, ref):
+    """one empty sum with only its G term, a batch of empty sums, 70 000 three-term sums (the batch dimension of every launch), and the exact
+    boundaries of the multi-launch split (n == cap, cap + 1, 2 cap, 2 cap + 1; with the G term riding in the first slice)."""
+    from secp256k1_zkp_amd import Engine
+    rng = np.random.default_rng(41)
+    g1 = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    r, inf = engine.ecmult_multi_many(np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8), np.array([0, 0], np.uint64), g1)
+    exp, einf = ref.ecmult_multi(np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8), bytes(g1[0]), None)
+    assert int(inf[0]) == einf == 0 and np.array_equal(r[0], exp)
+    r, inf = engine.ecmult_multi_many(np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8), np.zeros(6, np.uint64))
+    assert inf.tolist() == [1] * 5 and not r.any()
+    k = 70000
+    pts = np.tile(_points(engine, rng, 3000), (k // 1000, 1))[:3 * k]
+    sc = rng.integers(0, 256, (3 * k, 32), dtype=np.uint8)
+    off = (np.arange(k + 1) * 3).astype(np.uint64)
+    r, inf = engine.ecmult_multi_many(sc, pts, off)
+    for s_ in (0, 1, 999, 65535, 65536, k - 1):
+        exp, einf = ref.ecmult_multi(sc[3 * s_:3 * s_ + 3], pts[3 * s_:3 * s_ + 3], None, None)
+        assert int(inf[s_]) == einf and np.array_equal(r[s_], exp), s_
+    cap = 1000
+    engine.set_option(Engine.OPT_MSM_MAX_TERMS, cap)
+    try:
+        for n in (cap - 1, cap, cap + 1, 2 * cap, 2 * cap + 1):
+            p2 = _points(engine, rng, n); s2 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            for g in (None, bytes(rng.integers(0, 256, 32, dtype=np.uint8))):
+                exp, einf = ref.ecmult_multi(s2, p2, g, None)
+                got, ginf = engine.ecmult_multi(s2, p2, g, None)
+                assert ginf == einf and np.array_equal(got, exp), (n, g is not None)
+    finally:
+        engine.set_option(Engine.OPT_MSM_MAX_TERMS, 0)
