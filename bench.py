@@ -268,7 +268,9 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     out["bip340_2p16"] = {"metric": "BIP-340 signature verifies/sec (BASELINE config 2)", "value": n / sec, "unit": "verifies/s", "ms": sec * 1e3, "batch": n,
                           "verified": True, "result_check": "every verdict as constructed (%d broken signatures / keys rejected), %d items compared with the reference's secp256k1_schnorrsig_verify" % (int(bad.sum()), chk.size),
                           "roofline": roof(MAC64_PER_SCHNORR, n, sec, "algorithmic %.1fe3 MAC64 per signature (SURVEY 8d: ~45 k for the double multiplication + one inversion + the key's square root)" % (MAC64_PER_SCHNORR / 1e3)),
-                          "hbm_roofline": {"achieved": 160.0 * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * n / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_signature": 160}}
+                          "hbm_roofline": {"achieved": 160.0 * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 160.0 * n / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_signature": 160},
+                          "occupancy_note": "one call of BASELINE's size is occupancy bound: 2^16 signatures are 1 024 wavefronts, ONE per SIMD, where a wavefront issues an instruction every ~7.6 cycles whatever it is; "
+                                            "`two_engines` (two submitting threads) or a larger batch fill the issue slots this figure leaves free"}
     # the same batches through TWO engines on the device (two streams): 2^16 signatures are 1 024 wavefronts -- exactly ONE per SIMD, where a
     # wavefront issues an instruction every ~7.6 cycles whatever it is -- so a second batch in flight runs in the issue slots the first leaves
     # free.  What a verifier with two submitting threads (an engine each) gets at this batch size; `value` above stays the one-engine figure.
@@ -308,7 +310,9 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     out["bppp_2p12"] = {"metric": "BP++ norm-argument verifies/sec (BASELINE config 4: the norm argument is the measurable unit, SURVEY 8d)", "value": nb / sec, "unit": "verifies/s",
                         "ms": sec * 1e3, "batch": nb, "g_len": 64, "h_len": 8, "verified": True,
                         "result_check": "== secp256k1_bppp_rangeproof_norm_product_verify of the reference on the 64 distinct proofs (61 valid, 3 broken), tiled %d times" % reps,
-                        "roofline": roof(MAC64_PER_MSM_TERM_SMALL * terms, nb, sec, "algorithmic %d terms x 10.6e3 MAC64 per term per proof (SURVEY 8d, the 1 024-term schedule)" % terms)}
+                        "roofline": roof(MAC64_PER_MSM_TERM_SMALL * terms, nb, sec, "algorithmic %d terms x 10.6e3 MAC64 per term per proof (SURVEY 8d, the 1 024-term schedule)" % terms),
+                        "occupancy_note": "one call of BASELINE's size is occupancy bound: 2^12 proofs put 832 wavefronts (13 full double multiplications per proof) on 1 024 SIMDs; 2^16 proofs per call run at 3.6e6/s "
+                                          "(profiles/r06n_bppp_tables_ab.txt), `two_engines` shows what a second submitting thread gets at this size"}
     # the same batches through TWO engines on the device (each its own stream and scratch; the tables of G are the device's): a call is a chain of
     # latency-bound stages -- 13 full double multiplications per proof on ~40 % of the lane slots -- so what a verifier with two submitting
     # threads sees is two chains side by side
