@@ -25,3 +25,14 @@ def test_c_program_on_fixed_vectors(tmp_path):
         lines = out.stdout.split("\n")
         assert lines[0] == "%d %s %s" % (v["result"], v["min_value"], v["max_value"]), v["name"]
         assert lines[1] == lines[0] and lines[2] == "0", v["name"]
+
+
+def test_c_program_many_sums(tmp_path):
+    """examples/ecmult_multi_many.c: K sums in one call against K single calls, from plain C (ragged: one empty sum, one of double length)"""
+    exe = str(tmp_path / "mm")
+    libdir = os.path.join(ROOT, "secp256k1_zkp_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "ecmult_multi_many.c"), "-o", exe,
+                    os.path.join(libdir, "libsecp256k1_zkp_amd.so"), "-Wl,-rpath," + libdir], check=True)
+    for args in (["8", "200"], ["3", "1"], ["40", "33"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("OK %s sums" % args[0]), (out.stdout, out.stderr)
