@@ -88,6 +88,14 @@ def load():
             raise OSError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        # PyTorch-ROCm wheels bundle their OWN copy of the HIP / HSA runtime and load it by path; this library links the system's
+        # (/opt/rocm).  Two HSA runtimes in one process cannot both own the device: whichever initialises second sees "no HIP device".
+        # With torch imported FIRST its copy is already mapped under the same SONAME and this library binds to it -- one runtime, and both
+        # sides see the GPU (measured on the GPU box in every order: tools/r6_load_order.sh).  Plain C callers never load torch: system runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:
