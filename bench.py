@@ -941,7 +941,8 @@ def main():
         def msm_time(scs, pts):
             """K sharded MSMs queued back to back (partial -> all-gather -> sum is one stream-ordered chain; nothing waits for the GPU inside
             the timed region), waited for once"""
-            msm_fn(be, scs, pts, to_host=False)
+            for _ in range(max(1, args.warmup)):          # (W untimed calls, as for the headline)
+                msm_fn(be, scs, pts, to_host=False)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
