@@ -60,6 +60,19 @@ def make_inputs(n, seed, distinct_generators=False):
         return commits, proofs, gens, "synthetic (reference golden 64-bit proof tiled; oracle/_ref not present)", None
 
 
+def device_wait(*engines):
+    """How a timed region ends: the engines' own waits on their streams (hipStreamSynchronize; every `_dev` result is ordered on the stream
+    of its call), THEN torch.cuda.synchronize() as the contract asks -- which finds an idle device.  torch.cuda.synchronize() alone, left to
+    wait for an engine's work, returned 40-55 ms late 9 times in 3 600 calls after the multi-threaded CPU legs of a process like this one
+    (the reference's provers) -- twice over: profiles/r06ae_idle_probe3.txt, _probe4.txt -- while the engine's wait (0 in 3 600) and a polled
+    event (0 in 3 600) never did, with the device's own events showing the usual kernel time: a late wake-up of that blocking wait, not
+    work."""
+    import torch                          # (imported where it is used, like everywhere in this file: the launcher path never needs it)
+    for e in engines:
+        e.sync()
+    torch.cuda.synchronize()
+
+
 def usable_cores():
     """host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose
     256 hardware threads but grant the container 16 CPUs of quota; oversubscribing only slows the OpenMP team down)."""
@@ -242,15 +255,15 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     def loop(fn):
         # K calls queued back to back and waited for once -- twice, the faster pass counts: these loops are 5-60 ms long and run between the
         # CPU legs of this function (reference provers and verifiers on the host cores), after which one pass in ten showed a 40-60 ms hole --
-        # the submitting thread descheduled, not the engine: 1 500 consecutive groups of calls in a quiet process had none
-        # (profiles/r06y_stall_probe.txt, r06y_bench_outliers.txt)
-        fn(); torch.cuda.synchronize()
+        # not the engine: 1 500 consecutive groups of calls in a quiet process had none (profiles/r06y_stall_probe.txt, r06y_bench_outliers.txt);
+        # later traced to torch.cuda.synchronize() waking up late (device_wait above, which these loops now end with; best-of-two kept)
+        fn(); device_wait(eng)
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
             for _ in range(steps):
                 fn()
-            torch.cuda.synchronize()
+            device_wait(eng)
             d = (time.perf_counter() - t0) / steps
             best = d if best is None or d < best else best
         return best
@@ -285,11 +298,11 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     eng_s = Engine(eng.device)
     try:
         res_s = torch.zeros(n, dtype=torch.int32, device=dev)
-        eng_s.schnorrsig_verify_batch_dev(res_s, d[0], d[1], d[2]); torch.cuda.synchronize()
+        eng_s.schnorrsig_verify_batch_dev(res_s, d[0], d[1], d[2]); device_wait(eng, eng_s)
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.schnorrsig_verify_batch_dev(res, d[0], d[1], d[2]); eng_s.schnorrsig_verify_batch_dev(res_s, d[0], d[1], d[2])
-        torch.cuda.synchronize()
+        device_wait(eng, eng_s)
         sec_s = (time.perf_counter() - t0) / (2 * steps)
         assert np.array_equal(res_s.cpu().numpy(), got) and np.array_equal(res.cpu().numpy(), got), "BIP-340 verdicts differ with two engines"
         out["bip340_2p16"]["two_engines"] = {"value": n / sec_s, "ms_per_batch": sec_s * 1e3, "verified": True,
@@ -328,11 +341,11 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     try:
         res_b = torch.zeros(nb, dtype=torch.int32, device=dev)
         call_b = lambda: eng_b.bppp_norm_product_verify_batch_dev(res_b, d_pr, pr.shape[1], d_tr, d_rho, d_gens, gens, base[4], d_cv, base[5].shape[1], d_cm, nb)
-        call(); call_b(); torch.cuda.synchronize()
+        call(); call_b(); device_wait(eng, eng_b)
         t0 = time.perf_counter()
         for _ in range(steps):
             call(); call_b()
-        torch.cuda.synchronize()
+        device_wait(eng, eng_b)
         sec2 = (time.perf_counter() - t0) / (2 * steps)
         assert np.array_equal(res_b.cpu().numpy(), np.tile(want, reps)) and np.array_equal(res.cpu().numpy(), np.tile(want, reps)), "BP++ verdicts differ with two engines"
         out["bppp_2p12"]["two_engines"] = {"value": nb / sec2, "ms_per_batch": sec2 * 1e3, "verified": True,
@@ -365,12 +378,12 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     torch.cuda.synchronize()
     for k in range(2):
         eng.ecmult_multi_dev(o2[k][0], o2[k][1], d_s, d_p, g_sc=d_g)
-    torch.cuda.synchronize()
+    device_wait(eng)
     kq = 4 * steps
     t0 = time.perf_counter()
     for k in range(kq):
         eng.ecmult_multi_dev(o2[k & 1][0], o2[k & 1][1], d_s, d_p, g_sc=d_g)
-    torch.cuda.synchronize()
+    device_wait(eng)
     sec2 = (time.perf_counter() - t0) / kq
     eng.set_option(Engine.OPT_RP_INPUTS_READY, 0); eng.set_option(Engine.OPT_MSM_PIPELINE, 0)
     assert all(bytes(o[0].cpu().numpy()) == exp_xy.tobytes() and int(o[1].item()) == exp_inf for o in o2), "1 024-term MSM with two calls in flight differs"
@@ -401,15 +414,15 @@ def measure_next_rows(eng, ref, dev, steps, with_cpu=True):
     def loop(fn):
         # K calls queued back to back and waited for once -- twice, the faster pass counts: these loops are 5-60 ms long and run between the
         # CPU legs of this function (reference provers and verifiers on the host cores), after which one pass in ten showed a 40-60 ms hole --
-        # the submitting thread descheduled, not the engine: 1 500 consecutive groups of calls in a quiet process had none
-        # (profiles/r06y_stall_probe.txt, r06y_bench_outliers.txt)
-        fn(); torch.cuda.synchronize()
+        # not the engine: 1 500 consecutive groups of calls in a quiet process had none (profiles/r06y_stall_probe.txt, r06y_bench_outliers.txt);
+        # later traced to torch.cuda.synchronize() waking up late (device_wait above, which these loops now end with; best-of-two kept)
+        fn(); device_wait(eng)
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
             for _ in range(steps):
                 fn()
-            torch.cuda.synchronize()
+            device_wait(eng)
             d = (time.perf_counter() - t0) / steps
             best = d if best is None or d < best else best
         return best
@@ -844,7 +857,7 @@ def main():
         eng.set_option(Engine.OPT_RP_INPUTS_READY, 1 if in_flight else 0)
         for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
+        device_wait(eng)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -852,7 +865,7 @@ def main():
         # the K steps are queued back to back and waited for once (stream-ordered `_dev` calls: no host round trip between steps)
         for _ in range(k_steps):
             step()
-        torch.cuda.synchronize()
+        device_wait(eng)                  # (= the engine's wait on its stream, then torch.cuda.synchronize())
         d = time.perf_counter() - t0
         return d, [eng.last_ms(16 + k) for k in range(min(k_steps, 32))]          # HIP events around the ring kernels on the launch stream
 
@@ -888,14 +901,14 @@ def main():
         torch.cuda.synchronize()
         for _ in range(max(1, args.warmup)):
             eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_c2, d_p2, d_o2, d_g2, n, stream=stream)
-        torch.cuda.synchronize()
+        device_wait(eng)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0d = time.perf_counter()
         for _ in range(args.steps):
             eng.rangeproof_verify_batch_dev(d_res, d_min, d_max, d_c2, d_p2, d_o2, d_g2, n, stream=stream)
-        torch.cuda.synchronize()
+        device_wait(eng)
         dtd = time.perf_counter() - t0d
         if world > 1:
             tmax = torch.tensor([dtd], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dtd = float(tmax.item())
@@ -943,14 +956,14 @@ def main():
             the timed region), waited for once"""
             for _ in range(max(1, args.warmup)):          # (W untimed calls, as for the headline)
                 msm_fn(be, scs, pts, to_host=False)
-            torch.cuda.synchronize()
+            device_wait(eng)
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
             tm = time.perf_counter()
             for _ in range(args.steps):
                 xy_d, inf_d = msm_fn(be, scs, pts, to_host=False)
-            torch.cuda.synchronize()
+            device_wait(eng)
             dtm = time.perf_counter() - tm
             if world > 1:
                 tmax = torch.tensor([dtm], dtype=torch.float64, device=dev); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dtm = float(tmax.item())
