@@ -71,8 +71,8 @@ k_bp_tab_seeds(u32* tab, size_t stride, gtab_fill_plan p) {
 }
 __global__ void __launch_bounds__(256, 2)
 k_bp_tab_fill(u32* tab, size_t stride, gtab_fill_plan p, u32 runs) {
-    const u32 b = blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
-    if (b >= 1u && b < p.Kc) gtab_fill_run(tab + (size_t)blockIdx.z * stride, p, w, b, run * GTAB_FILL_RUN);
+    const u32 b = 1u + blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
+    if (b <= gtab_fill_cols(p)) gtab_fill_run(tab + (size_t)blockIdx.z * stride, p, w, b, 1u + run * GTAB_FILL_RUN);
 }
 __global__ void k_bp_final(int32_t* results, const u32* sums28, const int* proof_ok, const unsigned char* term_ok, const int* gens_ok, u32 n_terms, size_t n) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,10 +104,10 @@ static int bp_ensure_table(s2k_engine* e, hipStream_t st, const u32* gens18, con
         else {
             e->bp_tab_bytes = bp_tab_words(n_gens, D) * sizeof(u32); e->bp_tab_stride = bp_tab_stride(D);
             const gtab_fill_plan p = gtab_make_fill_plan(D);
-            const u32 seeds = p.W * gtab_seeds_per_window(p), runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
+            const u32 seeds = p.W * gtab_seeds_per_window(p), runs = gtab_fill_runs(p);
             hipLaunchKernelGGL(k_bp_tab_base, dim3((unsigned)((n_gens * p.W + 63) / 64)), dim3(64), 0, st, e->bp_tab, e->bp_tab_stride, gens18, (u32)n_gens, D);
             hipLaunchKernelGGL(k_bp_tab_seeds, dim3((seeds + 255) / 256, (unsigned)n_gens), dim3(256), 0, st, e->bp_tab, e->bp_tab_stride, p);
-            hipLaunchKernelGGL(k_bp_tab_fill, dim3((p.Kc + 255) / 256, p.W * runs, (unsigned)n_gens), dim3(256), 0, st, e->bp_tab, e->bp_tab_stride, p, runs);
+            hipLaunchKernelGGL(k_bp_tab_fill, dim3((gtab_fill_cols(p) + 255) / 256, p.W * runs, (unsigned)n_gens), dim3(256), 0, st, e->bp_tab, e->bp_tab_stride, p, runs);
             HIPCHK(hipGetLastError());
             int ok_host = 0;
             HIPCHK(hipMemcpyAsync(&ok_host, gens_ok_dev, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -109,8 +109,8 @@ k_gtab_seeds(u32* gtab, gtab_fill_plan p) {
 // block = 256 consecutive columns of one (window, run of rows)
 __global__ void __launch_bounds__(256, 2)
 k_gtab_fill(u32* gtab, gtab_fill_plan p, u32 runs) {
-    const u32 b = blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
-    if (b >= 1u && b < p.Kc) gtab_fill_run(gtab, p, w, b, run * GTAB_FILL_RUN);
+    const u32 b = 1u + blockIdx.x * 256u + threadIdx.x, run = blockIdx.y % runs, w = blockIdx.y / runs;
+    if (b <= gtab_fill_cols(p)) gtab_fill_run(gtab, p, w, b, 1u + run * GTAB_FILL_RUN);
 }
 // the three launches; `base_done`: the window bases (and the header) are already there (a generator's table: k_gen_base wrote them)
 static int launch_table_build(hipStream_t st, u32* tab, u32 D, int base_done) {
@@ -122,8 +122,8 @@ static int launch_table_build(hipStream_t st, u32* tab, u32 D, int base_done) {
     if (!base_done) hipLaunchKernelGGL(k_gtab_base, dim3(1), dim3(64), 0, st, tab, D);
     const u32 seeds = p.W * gtab_seeds_per_window(p);
     hipLaunchKernelGGL(k_gtab_seeds, dim3((seeds + 255) / 256), dim3(256), 0, st, tab, p);
-    const u32 runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
-    hipLaunchKernelGGL(k_gtab_fill, dim3((p.Kc + 255) / 256, p.W * runs), dim3(256), 0, st, tab, p, runs);
+    const u32 runs = gtab_fill_runs(p);
+    hipLaunchKernelGGL(k_gtab_fill, dim3((gtab_fill_cols(p) + 255) / 256, p.W * runs), dim3(256), 0, st, tab, p, runs);
     return hipGetLastError() == hipSuccess;
 }
 

@@ -132,8 +132,8 @@ int emu_gtab_seeded_construction(unsigned D, const unsigned char* point64) {
     gtab_write_header(tab.data(), D);
     for (u32 w = 0; w < p.W; w++) gtab_build_base(tab.data(), D, w, point);
     for (u32 w = 0; w < p.W; w++) for (u32 t = 0; t < gtab_seeds_per_window(p); t++) gtab_build_seed(tab.data(), p, w, t);
-    const u32 runs = (p.NA + GTAB_FILL_RUN - 1) / GTAB_FILL_RUN;
-    for (u32 w = 0; w < p.W; w++) for (u32 run = 0; run < runs; run++) for (u32 b = 1; b < p.Kc; b++) gtab_fill_run(tab.data(), p, w, b, run * GTAB_FILL_RUN);
+    const u32 runs = gtab_fill_runs(p);
+    for (u32 w = 0; w < p.W; w++) for (u32 run = 0; run < runs; run++) for (u32 b = 1; b <= gtab_fill_cols(p); b++) gtab_fill_run(tab.data(), p, w, b, 1u + run * GTAB_FILL_RUN);
     // reference: v * base by repeated addition
     int bad = 0;
     for (u32 w = 0; w < p.W; w++) {

@@ -462,7 +462,7 @@ def test_emu_seeded_table_construction(emu, ref):
     shared inversion per run of rows) run sequentially at small widths, for G and for another point: every entry a digit can address equals
     v * 2^(D w) * point, and none is left unwritten"""
     rng = np.random.default_rng(5)
-    for D in (9, 10, 11, 12, 13):
+    for D in (9, 10, 11, 12, 13, 14, 15):           # (round 6: every denominator yields R + C and R - C; odd and even widths split rows / columns differently)
         assert emu.emu_gtab_seeded_construction(D, None) == 0, D
     assert emu.emu_gtab_seeded_construction(12, ref.rand_point(rng)) == 0
 

@@ -6,7 +6,7 @@ T=${1:-r06ad}
 for lib in tools/ab_libs/lib_r6_inplace.so secp256k1_zkp_amd/libsecp256k1_zkp_amd.so; do
   b=$(basename $lib .so)
   rm -rf gpurun_out/_p; 
-  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/_p -o t -- python tools/ab_probe.py $lib 1 > gpurun_out/${T}_bip340_probe_$b.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_p -o t -- python tools/ab_probe.py $lib 1 > gpurun_out/${T}_bip340_probe_$b.txt 2>&1
   f=$(find gpurun_out/_p -name '*kernel_stats.csv' | head -1)
   echo "== $b" ; grep RESULT gpurun_out/${T}_bip340_probe_$b.txt
   python - "$f" <<'P'
