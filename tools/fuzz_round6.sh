@@ -4,7 +4,8 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r06}; mkdir -p gpurun_out/$TAG; OUT=gpurun_out/$TAG/fuzz_tally.txt
 : > $OUT
-for spec in "601 26" "602 26" "603 26" "604 24" "605 20" "606 20"; do
+IFS=";" read -ra SPECS <<< "${S2K_FUZZ_SPECS:-601 26;602 26;603 26;604 24;605 20;606 20}"      # "seed bits;seed bits;..."
+for spec in "${SPECS[@]}"; do
   set -- $spec
   for extra in "" more; do
     echo "seed $1 $extra, $2-bit tables" >> $OUT
