@@ -52,7 +52,7 @@ def make_inputs(n, seed, distinct_generators=False):
         commits, proofs, gens, _ = ref.make_rangeproofs(n, rng, min_bits=64, gens64=gens_in, threads=min(usable_cores() * 2, 64))
         return commits, proofs, gens, "synthetic (secp256k1_rangeproof_sign via oracle/_ref, %d unique 64-bit proofs)" % n, ref
     except OSError:
-        from tests.refapi import GENERATOR_H
+        from secp256k1_zkp_amd.constants import GENERATOR_H
         v = [x for x in json.load(open(os.path.join(ROOT, "tests", "golden", "rangeproof_vectors.json")))["vectors"] if x["name"].startswith("repro_0")][0]
         commits = np.tile(np.frombuffer(bytes.fromhex(v["commit33"]), np.uint8), (n, 1))
         proofs = [bytes.fromhex(v["proof"])] * n
@@ -248,7 +248,7 @@ def measure_secondary(eng, ref, dev, steps, with_cpu=True):
     argument: a (g_len + h_len) + 13-point multi-scalar multiplication per proof at ~10.6 k MAC64 per term; MSM of 1 024 terms: 10.6 k)."""
     import torch
     from secp256k1_zkp_amd import Engine
-    from tests.refapi import G_XY
+    from secp256k1_zkp_amd.constants import G_XY
     out = {}
     rng = np.random.default_rng(777)
 
@@ -404,7 +404,7 @@ def measure_next_rows(eng, ref, dev, steps, with_cpu=True):
     import ctypes
     import torch
     from secp256k1_zkp_amd import Engine
-    from tests.refapi import G_XY, GENERATOR_H
+    from secp256k1_zkp_amd.constants import G_XY, GENERATOR_H
     L, H = eng._lib, eng._h
     out = {}
     rng = np.random.default_rng(4321)
@@ -596,7 +596,7 @@ def measure_group(devices, commits, proofs, gens, ref, steps):
     (hipMemcpyPeerAsync) and summed there.  Both checked in-run."""
     import torch
     from secp256k1_zkp_amd import Group
-    from tests.refapi import G_XY, N as ORDER
+    from secp256k1_zkp_amd.constants import G_XY, N as ORDER
     k = len(devices)
     g = Group(devices)
     out = {"devices": list(devices), "engines": k}
@@ -932,7 +932,7 @@ def main():
         # (the loops above leave the board at its power limit; a different workload is timed from an idle board, as a caller would meet it)
         torch.cuda.synchronize(); time.sleep(1.0)
         from secp256k1_zkp_amd import parallel
-        from tests.refapi import G_XY, N as ORDER
+        from secp256k1_zkp_amd.constants import G_XY, N as ORDER
         be = parallel.EngineBackend(eng)
         msm_fn = parallel.msm_sharded if (world == 1 or os.environ.get("S2K_MSM_SHARDING", "terms") == "terms") else parallel.msm_window_sharded
 

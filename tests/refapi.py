@@ -7,12 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libsecp256k1_ref.so")
 
-P = 2**256 - 2**32 - 977
-N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
-G_XY = bytes.fromhex("79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798"
-                     "483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8")
-GENERATOR_H = bytes.fromhex("50929b74c1a04954b78b4b6035e97a5e078a5a0f28ec96d547bfee9ace803ac0"
-                            "31d3c6863973926e049e637cb1b5f40a36dac28af1766968c30c2313f3a38904")
+from secp256k1_zkp_amd.constants import P, N, G_XY, GENERATOR_H  # noqa: F401  (one definition: the package's)
 
 
 def _p(a):
