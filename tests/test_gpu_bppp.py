@@ -28,7 +28,7 @@ def test_verify_vectors(engine):
         assert res[0] == v["result"], v["index"]
 
 
-@pytest.mark.parametrize("g_len,h_len,n", [(64, 8, 24), (64, 64, 8), (1, 1, 4), (2, 16, 4), (8, 1, 4)])
+@pytest.mark.parametrize("g_len,h_len,n", [(64, 8, 24), (64, 64, 8), (1, 1, 4), (2, 16, 4), (8, 1, 4), (32, 8, 6)])      # (72 / 128 / <= 36 / 40 generators: 18- / 17- / 20- / 19-bit set tables)
 def test_random_proofs(engine, ref, g_len, h_len, n):
     rng = np.random.default_rng(g_len * 100 + h_len)
     proofs, trs, rhos, gens, gl, cvs, commits = ref.make_bppp(n, rng, g_len, h_len)
