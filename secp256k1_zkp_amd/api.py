@@ -430,6 +430,45 @@ class Group:
         self._check(self._lib.s2k_ecmult_multi_group(self._h, _p(r), _p(inf), _p(g_sc), _p(sc), _p(pt_xy), _p(pt_inf), n), "s2k_ecmult_multi_group")
         return r, int(inf[0])
 
+    def ecmult_multi_many(self, sc, pt_xy, offsets, g_sc=None, pt_inf=None):
+        """K independent sums over the members of the group (s2k_ecmult_multi_many per member): the sums are independent objects, so they are
+        cut into contiguous ranges of about equal numbers of TERMS, one range per member, one host thread per member (the call releases
+        the GIL) -- no exchange between the GPUs, results in the caller's order.  A C caller does the same split over the engines of its
+        s2k_group (s2k_group_engine); the reference has no counterpart (one sum per secp256k1_ecmult_multi_var call, ecmult_impl.h:822-867)."""
+        import threading
+        sc = _u8(sc); pt_xy = _u8(pt_xy); off = np.ascontiguousarray(offsets, dtype=np.uint64); k = off.size - 1
+        n = int(off[-1]) if off.size else 0
+        g_sc = None if g_sc is None else _u8(g_sc); pt_inf = None if pt_inf is None else _u8(pt_inf)
+        _need("ecmult_multi_many_group sc", sc, 32 * n); _need("ecmult_multi_many_group pt_xy", pt_xy, 64 * n)
+        if g_sc is not None: _need("ecmult_multi_many_group g_sc", g_sc, 32 * k)
+        if pt_inf is not None: _need("ecmult_multi_many_group pt_inf", pt_inf, n)
+        if k > 0 and (int(off[0]) != 0 or np.any(off[1:] < off[:-1])):
+            raise S2KError("ecmult_multi_many_group failed: offsets must start at 0 and not decrease")
+        m = len(self)
+        # member i takes sums [cut[i], cut[i+1]): the first sum whose end passes i/m of the terms starts the next range
+        cut = [0] + [int(np.searchsorted(off[1:], (n * (i + 1)) // m, side="left")) + 1 if i + 1 < m else k for i in range(m)]
+        cut = [min(max(c, 0), k) for c in cut]
+        for i in range(1, len(cut)): cut[i] = max(cut[i], cut[i - 1])
+        r = np.zeros((max(k, 0), 64), np.uint8); inf = np.zeros(max(k, 0), np.int32)
+        errs = [None] * m
+
+        def run(i):
+            a, b = cut[i], cut[i + 1]
+            if b <= a: return
+            t0, t1 = int(off[a]), int(off[b])
+            try:
+                xy, fl = self.engine(i).ecmult_multi_many(sc.reshape(-1)[32 * t0:32 * t1], pt_xy.reshape(-1)[64 * t0:64 * t1], off[a:b + 1] - off[a],
+                                                          None if g_sc is None else g_sc.reshape(-1)[32 * a:32 * b], None if pt_inf is None else pt_inf.reshape(-1)[t0:t1])
+                r[a:b] = xy; inf[a:b] = fl
+            except Exception as ex:                  # (reported by the calling thread)
+                errs[i] = ex
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(m)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        for ex in errs:
+            if ex is not None: raise ex
+        return r, inf
+
     def ecmult_multi_dev(self, sc_list, pt_list, g_sc_dev0=None, inf_list=None):
         """per engine: torch uint8 tensors resident on that engine's GPU (sc (n_i,32), pt (n_i,64)); returns (xy bytes, inf)"""
         k = len(self)

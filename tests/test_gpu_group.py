@@ -187,3 +187,29 @@ def test_group_behind_the_reference_side_hook(group2, ref):
         assert np.array_equal(res, want[0]) and np.array_equal(mx, want[2]) and s1[0] == s0[0] + 1 and s1[1] == s0[1]
     finally:
         hk.set_backend()
+
+
+def test_group_many_sums(group2, engine, ref):
+    """Group.ecmult_multi_many: K independent sums cut into contiguous ranges over the members (balanced by terms, one host thread per
+    member, no exchange); every sum equals the one-engine call's and the reference's secp256k1_ecmult_multi_var (src/ecmult_impl.h:822-867).
+    Ragged sizes with empty sums at both ends, a sum that is most of the terms, generator terms, infinite points; K below the group size."""
+    from tests.test_gpu_msm import _points
+    rng = np.random.default_rng(1207)
+    for sizes, with_g in (([0, 5, 300, 0, 1, 88, 89, 1024, 2, 0], True), ([3000, 1, 1, 1], False), ([7], True), ([0], False), ([], False), ([64] * 50, True)):
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        n = int(off[-1]); k = len(sizes)
+        pts = _points(engine, rng, max(n, 1))[:n]
+        sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); sc[::13] = 0
+        inf = np.zeros(n, np.uint8); inf[5::29] = 1
+        g = rng.integers(0, 256, (k, 32), dtype=np.uint8) if with_g else None
+        got, ginf = group2.ecmult_multi_many(sc, pts, off, g, inf)
+        assert got.shape == (k, 64) and ginf.shape == (k,)
+        if k:
+            one, oinf = engine.ecmult_multi_many(sc, pts, off, g, inf)
+            assert np.array_equal(one, got) and np.array_equal(oinf, ginf), sizes
+        for s in range(k):
+            lo, hi = int(off[s]), int(off[s + 1])
+            exp, einf = ref.ecmult_multi(sc[lo:hi], pts[lo:hi], None if g is None else bytes(g[s]), inf[lo:hi])
+            assert int(ginf[s]) == einf and np.array_equal(got[s], exp), (sizes, s)
+    with pytest.raises(Exception):
+        group2.ecmult_multi_many(np.zeros((4, 32), np.uint8), np.zeros((4, 64), np.uint8), np.array([0, 3, 2, 4], np.uint64))
