@@ -444,11 +444,9 @@ class Group:
         if pt_inf is not None: _need("ecmult_multi_many_group pt_inf", pt_inf, n)
         if k > 0 and (int(off[0]) != 0 or np.any(off[1:] < off[:-1])):
             raise S2KError("ecmult_multi_many_group failed: offsets must start at 0 and not decrease")
+        from .parallel import shard_sums
         m = len(self)
-        # member i takes sums [cut[i], cut[i+1]): the first sum whose end passes i/m of the terms starts the next range
-        cut = [0] + [int(np.searchsorted(off[1:], (n * (i + 1)) // m, side="left")) + 1 if i + 1 < m else k for i in range(m)]
-        cut = [min(max(c, 0), k) for c in cut]
-        for i in range(1, len(cut)): cut[i] = max(cut[i], cut[i - 1])
+        cut = shard_sums(off, m)                 # member i takes sums [cut[i], cut[i + 1])
         r = np.zeros((max(k, 0), 64), np.uint8); inf = np.zeros(max(k, 0), np.int32)
         errs = [None] * m
 

@@ -12,6 +12,9 @@ Shapes, as SURVEY.md section 8e lays out:
     sum are exactly those of term sharding (`msm_window_sharded`).  Which is faster depends on n and on the rank count:
     term sharding divides all per-term work by the world size, window sharding repeats the decode / GLV split on every rank
     but needs no slicing of the inputs and gives each rank whole windows; `msm_auto` picks by a size rule.
+  * K independent sums (`s2k_ecmult_multi_many`): independent objects again -- `shard_sums` cuts them into contiguous ranges of about
+    equal numbers of TERMS, every rank runs its range as one launch chain, and the only exchange is the gather of the K x 68 result
+    bytes (`msm_many_sharded`).
 """
 import numpy as np
 
@@ -21,6 +24,19 @@ def shard_range(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sums(offsets, world):
+    """K sums with terms back to back (offsets[K + 1]) -> cut[world + 1]: rank r takes sums [cut[r], cut[r + 1]), contiguous, about equal
+    numbers of terms (a rank's range ends with the first sum whose end passes its share of the terms)."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    k = off.size - 1
+    n = int(off[-1]) if off.size else 0
+    cut = [0] + [int(np.searchsorted(off[1:], (n * (r + 1)) // world, side="left")) + 1 if r + 1 < world else k for r in range(world)]
+    cut = [min(max(c, 0), max(k, 0)) for c in cut]
+    for i in range(1, len(cut)):
+        cut[i] = max(cut[i], cut[i - 1])
+    return cut
 
 
 class _NoStream:
@@ -104,6 +120,36 @@ def msm_auto(backend, sc, pt_xy, g_sc=None, pt_inf=None, group=None, to_host=Tru
     return msm_sharded(backend, sc, pt_xy, g_sc, pt_inf, group, to_host)
 
 
+def msm_many_sharded(backend, sc, pt_xy, offsets, g_sc=None, pt_inf=None, group=None):
+    """K independent sums (terms back to back, host array offsets[K + 1], optional g_sc[K, 32]) sharded over the ranks of `group` as objects.
+
+    `backend.msm_many(sc, pt_xy, offsets, g_sc, pt_inf) -> (xy uint8[k, 64], inf int32[k])` runs a range of sums (EngineBackend: one
+    s2k_ecmult_multi_many_dev launch chain).  Every rank passes the full input and computes only its range; the results are gathered
+    (K x 68 bytes: the path's only exchange) and returned on all ranks as (xy uint8[K, 64], inf int32[K]) tensors on the backend's device."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    k = off.size - 1
+    cut = shard_sums(off, world)
+    a, b = cut[rank], cut[rank + 1]
+    t0, t1 = (int(off[a]), int(off[b])) if k > 0 else (0, 0)
+    with _chain(backend):
+        xy, inf = backend.msm_many(sc[t0:t1], pt_xy[t0:t1], off[a:b + 1] - (off[a] if k > 0 else 0), None if g_sc is None else g_sc[a:b],
+                                   None if pt_inf is None else pt_inf[t0:t1])
+        if world == 1:
+            return xy, inf
+        # one buffer per rank: 64 result bytes + the flag as 4 bytes, padded to the longest range
+        rec = torch.cat([xy.reshape(-1, 64), inf.reshape(-1, 1).to(torch.int32).contiguous().view(torch.uint8).reshape(-1, 4)], dim=1)
+        longest = max(cut[r + 1] - cut[r] for r in range(world))
+        pad = torch.zeros((longest, 68), dtype=torch.uint8, device=rec.device); pad[: rec.shape[0]] = rec
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        full = torch.cat([bufs[r][: cut[r + 1] - cut[r]] for r in range(world)])
+        return full[:, :64].contiguous(), full[:, 64:].contiguous().view(torch.int32).reshape(-1)
+
+
 def gather_results(local, n_total, group=None):
     """concatenate per-rank result arrays of a replica-sharded batch (rank order = index order)."""
     import torch
@@ -179,6 +225,19 @@ class EngineBackend:
             return r, inf
         self.stream.synchronize()
         return r.cpu().numpy(), int(inf.item())
+
+    def msm_many(self, sc, pt_xy, offsets, g_sc, pt_inf):
+        """a range of independent sums as one launch chain (s2k_ecmult_multi_many_dev); nothing waits for the GPU"""
+        import torch
+        k = len(offsets) - 1
+        r = torch.empty((max(k, 0), 64), dtype=torch.uint8, device=self.dev); inf = torch.empty(max(k, 0), dtype=torch.int32, device=self.dev)
+        if k > 0:
+            sc = sc.contiguous(); pt_xy = pt_xy.contiguous()
+            h = self._enter()
+            self.engine.ecmult_multi_many_dev(r, inf, sc, pt_xy, offsets, g_sc=None if g_sc is None else g_sc.contiguous(),
+                                              pt_inf=None if pt_inf is None else pt_inf.contiguous(), stream=h)
+            self._leave()
+        return r, inf
 
     def msm_window_partial(self, sc, pt_xy, g_sc, pt_inf, part, parts):
         import torch

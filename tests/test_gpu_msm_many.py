@@ -239,3 +239,31 @@ def test_many_edges(engine, ref):
                 assert ginf == einf and np.array_equal(got, exp), (n, g is not None)
     finally:
         engine.set_option(Engine.OPT_MSM_MAX_TERMS, 0)
+
+
+def test_many_sums_through_the_distributed_layer(engine, ref):
+    """parallel.msm_many_sharded with the engine's backend (one rank: the whole range as one s2k_ecmult_multi_many_dev chain on the backend's
+    stream; the two-rank protocol runs on gloo in tests/test_cpu_distributed.py): same bytes as the host-buffer call, each sum the reference's."""
+    import torch
+    from secp256k1_zkp_amd import parallel
+    rng = np.random.default_rng(91)
+    sizes = [0, 17, 1, 900, 88, 0, 1024, 3]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(off[-1]); k = len(sizes)
+    pts = _points(engine, rng, n)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8); sc[::19] = 0
+    inf = np.zeros(n, np.uint8); inf[7::31] = 1
+    g = rng.integers(0, 256, (k, 32), dtype=np.uint8)
+    dev = torch.device("cuda", engine.device)
+    be = parallel.EngineBackend(engine)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a)).to(dev)
+    d_sc, d_pt, d_g, d_inf = t(sc), t(pts), t(g), t(inf)
+    torch.cuda.synchronize()
+    xy, fl = parallel.msm_many_sharded(be, d_sc, d_pt, off, d_g, d_inf)
+    be.stream.synchronize()
+    want_xy, want_fl = engine.ecmult_multi_many(sc, pts, off, g, inf)
+    assert np.array_equal(xy.cpu().numpy(), want_xy) and np.array_equal(fl.cpu().numpy(), want_fl)
+    for s in (1, 3, 6):
+        lo, hi = int(off[s]), int(off[s + 1])
+        exp, einf = ref.ecmult_multi(sc[lo:hi], pts[lo:hi], bytes(g[s]), inf[lo:hi])
+        assert int(want_fl[s]) == einf and np.array_equal(want_xy[s], exp)
