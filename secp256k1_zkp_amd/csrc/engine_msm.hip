@@ -787,8 +787,8 @@ k_msm_combine(u32* out28, u32* copy28, unsigned char* r_xy, int32_t* r_inf, cons
     }
 }
 // Bucket-free form: lane l sums (share of k_i)*P_i over the terms i = l, l + lanes, ... with one full double-and-add each
-// (ecmult.h); the term with index n carries g_sc*G.  Two uses: small inputs (n < MSM_SMALL_N, the analogue of the reference
-// switching to Strauss), and -- gated by the overflow flag -- the exact path of a bucket launch whose regions overflowed.
+// (ecmult.h); the term with index n carries g_sc*G.  Gated by the overflow flag: the exact path of a bucket launch whose regions
+// overflowed (until round 6 also the whole call for sums below 32 terms: 0.8 ms where the bucket pipeline takes 0.37, msm.h).
 __global__ void __launch_bounds__(256, 2)
 k_msm_direct(u32* out28, const u32* gate, const unsigned char* g_sc, const unsigned char* sc, const unsigned char* pt, const unsigned char* pt_inf,
              const u32* gtab, u32* ptab, size_t n, size_t nt, msm_plan pl) {
@@ -992,20 +992,6 @@ int msm_launch(s2k_engine* e, hipStream_t st, ws_carver& c, u32** result28, cons
         HIPCHK(hipGetLastError());
         return msm_emit(st, out, final28);
     }
-    if (nt < MSM_SMALL_N) {
-        const unsigned dl = (unsigned)(((nt + 255) / 256) * 256);
-        if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
-        HIPCHK(hipMemsetAsync(flags, 0, 64, st));
-        HIPCHK(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(k_msm_direct, dim3(dl / 256), dim3(256), 0, st, lanes, (const u32*)nullptr, g_sc, sc, pt, pt_inf, e->gtab,
-                           e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS, n, nt, pl);
-        HIPCHK(hipEventRecord(e->ev[3], st));
-        const u32* r = launch_gej_reduce(st, lanes, dbufA, dbufB, 1, dl);
-        HIPCHK(hipMemcpyAsync(final28, r, 28 * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_msm_flag_copy, dim3(1), dim3(1), 0, st, e->dev_flags, flags);
-        HIPCHK(hipGetLastError());
-        return msm_emit(st, out, final28);
-    }
     if (!engine_ptab(e, 3 * (size_t)MSM_DIRECT_LANES)) return 0;
     u32* const direct_ptab = e->ptab + (size_t)X.arena * MSM_DIRECT_LANES * S2K_PTAB_WORDS;
     const u32 nk = pl.wn * pl.nb;
@@ -1194,7 +1180,7 @@ extern "C" int s2k_ecmult_multi_partial_dev(s2k_engine* e, void* stream, uint32_
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
-    if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
+    if (e->msm_pipeline && nt >= 1 && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 0, r_gej28, nullptr, nullptr, g_sc, sc, pt_xy, pt_inf, n);
     return msm_run(e, st, 0, msm_out{nullptr, nullptr, r_gej28}, g_sc, sc, pt_xy, pt_inf, n);
 }
 extern "C" int s2k_ecmult_multi_window_partial_dev(s2k_engine* e, void* stream, uint32_t* r_gej28, const unsigned char* g_sc, const unsigned char* sc,
@@ -1222,7 +1208,7 @@ extern "C" int s2k_ecmult_multi_dev(s2k_engine* e, void* stream, unsigned char* 
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     stream_guard sg(e, st);
     const size_t nt = n + (g_sc ? 1 : 0);
-    if (e->msm_pipeline && nt >= MSM_SMALL_N && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
+    if (e->msm_pipeline && nt >= 1 && nt <= MSM_PIPE_MAX_TERMS) return msm_pipelined(e, st, 1, nullptr, r_xy, r_inf, g_sc, sc, pt_xy, pt_inf, n);
     return msm_run(e, st, 0, msm_out{r_xy, r_inf, nullptr}, g_sc, sc, pt_xy, pt_inf, n);
 }
 extern "C" int s2k_gej_sum_dev(s2k_engine* e, void* stream, unsigned char* r_xy, int32_t* r_inf, const uint32_t* gej28, size_t count) {

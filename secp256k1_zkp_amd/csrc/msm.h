@@ -25,16 +25,15 @@
 //                                  affine result from the same launch
 //
 // Any order of additions gives the same group element, so the atomics-driven bucket order does not affect the
-// (bit-exact) serialised result.  Very small inputs (n < MSM_SMALL_N) skip the bucket machinery: one full
-// double multiplication per lane (ecmult.h) and a tree sum -- the analogue of the reference switching to Strauss below 88
-// points (:55, :848-855).  The switch sits much lower here (32): one double multiplication is ~0.6 ms of latency on a single
-// wavefront, more than the whole bucket pipeline's floor (0.4 ms since round 6) leaves over.
+// (bit-exact) serialised result.  The reference switches to Strauss below 88 points (:55, :848-855); here NO size skips the bucket
+// machinery since round 6: one double multiplication per lane is ~0.8 ms of latency on a single wavefront whatever the number of
+// terms, the whole bucket pipeline 0.36-0.39 ms from one term up (profiles/r06an_msm_tiny.txt; until then sums below 32 terms took the
+// bucket-free form, which is what the exact path of an overflowing launch still is: k_msm_direct).
 #pragma once
 #include "gtable.h"
 #include "cofield.h"
 #include <cstdlib>
 
-#define MSM_SMALL_N 32
 #define MSM_MAX_WINDOWS 33          // c >= 4  ->  ceil(129/4)
 // Term record (round 5): two aligned 64-byte sectors of canonical words, [ x | y ] and [ beta*x | y ] -- the operand record format of the
 // rest of the engine (ecmult.h) -- so that a bucket reference gathers exactly ONE sector (the 28-word limb record of rounds 1-4 put the 72
